@@ -1,0 +1,82 @@
+/*
+ * oracle/gadgets.h -- TEST INFRASTRUCTURE ONLY (CPU oracle).
+ *
+ * Plain-C restatement of the reference's gadget layer, function for function:
+ *   /root/reference/src/allocated_scalar.rs:17-30   AllocatedScalar, allocate
+ *   /root/reference/src/errors.rs:13-18             Error::NonExistingInverse
+ *   /root/reference/src/range.rs:21-189             range_proof, range_check, min_bound, max_bound,
+ *                                                   scalar_decomposition_gadget, scalar_to_bits,
+ *                                                   bits_count, num_bits_closest_power_of_two
+ *   /root/reference/src/scalar.rs:21-140            conditionally_select_zero/one, is_non_zero, maybe_equal
+ * Same names, same argument order, same sequence of composer calls, same
+ * per-bit `pow` (range.rs:146) -- it is the checker for the HIP path and the
+ * timed "port" CPU baseline.  The shipped library never links it.
+ */
+#ifndef PG_ORACLE_GADGETS_H
+#define PG_ORACLE_GADGETS_H
+
+#include "composer.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { var_t var; fr_t scalar; } allocated_scalar_t;
+
+enum { GADGET_OK = 0, GADGET_ERR_NON_EXISTING_INVERSE = 1 };
+
+allocated_scalar_t allocated_scalar_allocate(composer_t *c, fr_t scalar);
+
+var_t range_check(composer_t *c, fr_t min_range, fr_t max_range, allocated_scalar_t witness);
+var_t max_bound(composer_t *c, fr_t max_range, allocated_scalar_t witness, uint64_t *num_bits_pow_2);
+/* private in the reference; exposed so the tests can reach every function */
+var_t min_bound(composer_t *c, fr_t min_range, allocated_scalar_t witness, uint64_t num_bits);
+var_t range_proof(composer_t *c, allocated_scalar_t value, uint64_t num_bits);
+/* returns is_equal; bit variables (first num_bits) written to bits_out if non-NULL.
+ * num_bits > 256 panics in the reference (slice [..num_bits], range.rs:134): returns (var_t)-1. */
+var_t scalar_decomposition_gadget(composer_t *c, size_t num_bits, allocated_scalar_t witness, var_t *bits_out);
+void scalar_to_bits(fr_t scalar, uint8_t out[256]);
+uint64_t bits_count(fr_t scalar);
+uint64_t num_bits_closest_power_of_two(fr_t scalar);
+
+var_t conditionally_select_zero(composer_t *c, var_t x, var_t select);
+var_t conditionally_select_one(composer_t *c, var_t y, var_t selector);
+int is_non_zero(composer_t *c, var_t var, fr_t value_assigned);
+var_t maybe_equal(composer_t *c, allocated_scalar_t a, allocated_scalar_t b);
+
+/* ---- batch drivers (what the HIP path is compared with) --------------- */
+
+/* The 8 live columns + variable table the engine materialises
+ * (SURVEY.md section 8a row a14).  Arrays are caller-allocated. */
+typedef struct {
+    fr_t *q_m, *q_l, *q_r, *q_o, *q_c;
+    uint64_t *w_l, *w_r, *w_o;
+    fr_t *var_values;
+} oracle_columns_t;
+
+/* for w in witnesses: allocate(w); range_check(min,max,w)  on one fresh
+ * composer.  Copies rows [gate_base, n) / variables [var_base, nvars) into
+ * `out` (may be NULL for timing only), result variables into result_vars (may
+ * be NULL).  Returns 0, or -1 if some row is unsatisfied (check != 0 only). */
+int oracle_range_check_batch(fr_t min_range, fr_t max_range, const fr_t *witness, size_t batch, int check,
+                             oracle_columns_t *out, uint64_t *result_vars, uint64_t *gate_base, uint64_t *var_base,
+                             uint64_t *n_gates, uint64_t *n_vars);
+
+/* for i: allocate(witness[i]); max_bound(max_range[i], .) */
+int oracle_max_bound_batch(const fr_t *max_range, const fr_t *witness, size_t batch, int check, oracle_columns_t *out,
+                           uint64_t *result_vars, uint64_t *num_bits, uint64_t *gate_base, uint64_t *var_base,
+                           uint64_t *n_gates, uint64_t *n_vars);
+
+/* for i: v,y,s,a,b = add_input x5; is_non_zero(var v, v); conditionally_select_one(y, s); maybe_equal(a, b)
+ * (SURVEY.md section 8d, config C3).  err_mask[i] = 1 where is_non_zero
+ * returned NonExistingInverse (the partial emission stays in the columns, and
+ * the remaining two gadgets of the item still run).  out3[i*2+0]=select var,
+ * out3[i*2+1]=maybe_equal var. */
+int oracle_scalar_mix_batch(const fr_t *v, const fr_t *y, const fr_t *s, const fr_t *a, const fr_t *b, size_t batch,
+                            int check, oracle_columns_t *out, uint64_t *result_vars, uint8_t *err_mask,
+                            uint64_t *gate_base, uint64_t *var_base, uint64_t *n_gates, uint64_t *n_vars);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,184 @@
+"""oracle/pyoracle.py -- TEST INFRASTRUCTURE ONLY: ctypes binding of oracle/liboracle.so.
+
+Scalars cross this boundary as numpy uint64 arrays of shape [..., 4]
+(Montgomery limbs, little-endian), the same memory image the HIP path emits.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+
+
+class Fr(C.Structure):
+    _fields_ = [("l", C.c_uint64 * 4)]
+
+
+class AllocatedScalar(C.Structure):
+    _fields_ = [("var", C.c_uint64), ("scalar", Fr)]
+
+
+class Columns(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("q_m", "q_l", "q_r", "q_o", "q_c", "w_l", "w_r", "w_o", "var_values")]
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in ("fr.c", "composer.c", "gadgets.c", "fr.h", "composer.h", "gadgets.h")]
+    stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = C.CDLL(build())
+    u64, vp, sz = C.c_uint64, C.c_void_p, C.c_size_t
+    P = C.POINTER
+    sig = {
+        "fr_add": (Fr, [Fr, Fr]), "fr_sub": (Fr, [Fr, Fr]), "fr_neg": (Fr, [Fr]), "fr_mul": (Fr, [Fr, Fr]),
+        "fr_square": (Fr, [Fr]), "fr_from_u64": (Fr, [u64]), "fr_from_raw": (Fr, [P(u64)]), "fr_reduce": (Fr, [Fr]),
+        "fr_to_bytes": (None, [Fr, P(C.c_uint8)]), "fr_pow": (Fr, [Fr, P(u64)]), "fr_pow_of_2": (Fr, [u64]),
+        "fr_invert": (C.c_int, [Fr, P(Fr)]),
+        "composer_new": (vp, []), "composer_new_without_dummy": (vp, []), "composer_free": (None, [vp]),
+        "composer_circuit_size": (sz, [vp]), "composer_num_variables": (sz, [vp]), "composer_zero_var": (u64, [vp]),
+        "composer_add_input": (u64, [vp, Fr]), "composer_add_witness_to_circuit_description": (u64, [vp, Fr]),
+        "composer_constrain_to_constant": (None, [vp, u64, Fr, P(Fr)]), "composer_assert_equal": (None, [vp, u64, u64]),
+        "composer_poly_gate": (None, [vp, u64, u64, u64, Fr, Fr, Fr, Fr, Fr, P(Fr)]),
+        "composer_add": (u64, [vp, Fr, u64, Fr, u64, Fr, P(Fr)]), "composer_mul": (u64, [vp, Fr, u64, u64, Fr, P(Fr)]),
+        "composer_mul_gate": (None, [vp, u64, u64, u64, Fr, Fr, Fr, P(Fr)]), "composer_boolean_gate": (u64, [vp, u64]),
+        "composer_value": (Fr, [vp, u64]), "composer_selector": (P(Fr), [vp, C.c_int]),
+        "composer_wire": (P(u64), [vp, C.c_int]), "composer_values_dense": (None, [vp, vp]),
+        "composer_perm_count": (sz, [vp, u64]), "composer_dense_pi": (None, [vp, vp]), "composer_check": (C.c_long, [vp]),
+        "allocated_scalar_allocate": (AllocatedScalar, [vp, Fr]),
+        "range_check": (u64, [vp, Fr, Fr, AllocatedScalar]), "max_bound": (u64, [vp, Fr, AllocatedScalar, P(u64)]),
+        "min_bound": (u64, [vp, Fr, AllocatedScalar, u64]), "range_proof": (u64, [vp, AllocatedScalar, u64]),
+        "scalar_decomposition_gadget": (u64, [vp, sz, AllocatedScalar, P(u64)]),
+        "scalar_to_bits": (None, [Fr, P(C.c_uint8)]), "bits_count": (u64, [Fr]),
+        "num_bits_closest_power_of_two": (u64, [Fr]),
+        "conditionally_select_zero": (u64, [vp, u64, u64]), "conditionally_select_one": (u64, [vp, u64, u64]),
+        "is_non_zero": (C.c_int, [vp, u64, Fr]), "maybe_equal": (u64, [vp, AllocatedScalar, AllocatedScalar]),
+        "oracle_range_check_batch": (C.c_int, [Fr, Fr, vp, sz, C.c_int, P(Columns), vp, P(u64), P(u64), P(u64), P(u64)]),
+        "oracle_max_bound_batch": (C.c_int, [vp, vp, sz, C.c_int, P(Columns), vp, vp, P(u64), P(u64), P(u64), P(u64)]),
+        "oracle_scalar_mix_batch": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_int, P(Columns), vp, vp, P(u64), P(u64),
+                                            P(u64), P(u64)]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    _lib = L
+    return L
+
+
+# ---- scalar helpers ---------------------------------------------------------
+
+def fr(limbs) -> Fr:
+    f = Fr()
+    for i in range(4):
+        f.l[i] = int(limbs[i])
+    return f
+
+
+def limbs(f: Fr) -> list[int]:
+    return [int(f.l[i]) for i in range(4)]
+
+
+def fr_from_int(x: int) -> Fr:
+    """canonical integer -> Montgomery scalar, through the C code (fr_from_raw)."""
+    from .model import Q
+    x %= Q
+    raw = (C.c_uint64 * 4)(*[(x >> (64 * i)) & ((1 << 64) - 1) for i in range(4)])
+    return lib().fr_from_raw(raw)
+
+
+def fr_to_int(f: Fr) -> int:
+    r = lib().fr_reduce(f)
+    return sum(int(r.l[i]) << (64 * i) for i in range(4))
+
+
+def ints_to_mont_array(xs) -> np.ndarray:
+    """list of canonical ints -> uint64[N,4] Montgomery limbs (via the big-int model: independent of fr.c)."""
+    from .model import mont_limbs
+    return np.array([mont_limbs(int(x)) for x in xs], dtype=np.uint64).reshape(-1, 4)
+
+
+def _alloc_columns(n_gates: int, n_vars: int):
+    arrs = {k: np.zeros((n_gates, 4), dtype=np.uint64) for k in ("q_m", "q_l", "q_r", "q_o", "q_c")}
+    arrs.update({k: np.zeros(n_gates, dtype=np.uint64) for k in ("w_l", "w_r", "w_o")})
+    arrs["var_values"] = np.zeros((n_vars, 4), dtype=np.uint64)
+    cols = Columns(**{k: v.ctypes.data for k, v in arrs.items()})
+    return arrs, cols
+
+
+def _as_fr_array(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    assert a.ndim == 2 and a.shape[1] == 4
+    return a
+
+
+def range_check_batch(min_mont, max_mont, witness: np.ndarray, check: bool = True, want_columns: bool = True):
+    """allocate + range_check per witness on a fresh composer -> dict of columns (rows after the initial state)."""
+    L = lib()
+    witness = _as_fr_array(witness)
+    batch = witness.shape[0]
+    mn, mx = fr(min_mont), fr(max_mont)
+    n = int(L.num_bits_closest_power_of_two(L.fr_sub(mx, L.fr_from_u64(1))))
+    G, V = 4 * n + 11, 2 * n + 524
+    res = np.zeros(batch, dtype=np.uint64)
+    gb, vb, ng, nv = (C.c_uint64() for _ in range(4))
+    arrs, cols = _alloc_columns(G * batch if want_columns else 0, V * batch if want_columns else 0)
+    rc = L.oracle_range_check_batch(mn, mx, witness.ctypes.data, batch, int(check),
+                                    C.byref(cols) if want_columns else None, res.ctypes.data, C.byref(gb),
+                                    C.byref(vb), C.byref(ng), C.byref(nv))
+    assert ng.value == G * batch and nv.value == V * batch, (ng.value, nv.value, G, V, batch)
+    arrs.update(result_vars=res, gate_base=gb.value, var_base=vb.value, n_gates=ng.value, n_vars=nv.value,
+                num_bits=n, satisfied=(rc == 0))
+    return arrs
+
+
+def max_bound_batch(max_mont: np.ndarray, witness: np.ndarray, check: bool = True):
+    L = lib()
+    max_mont, witness = _as_fr_array(max_mont), _as_fr_array(witness)
+    batch = witness.shape[0]
+    one = L.fr_from_u64(1)
+    ns = [int(L.num_bits_closest_power_of_two(L.fr_sub(fr(m), one))) for m in max_mont]
+    G, V = sum(2 * n + 5 for n in ns), sum(n + 262 for n in ns)
+    res, nb = np.zeros(batch, dtype=np.uint64), np.zeros(batch, dtype=np.uint64)
+    gb, vb, ng, nv = (C.c_uint64() for _ in range(4))
+    arrs, cols = _alloc_columns(G, V)
+    rc = L.oracle_max_bound_batch(max_mont.ctypes.data, witness.ctypes.data, batch, int(check), C.byref(cols),
+                                  res.ctypes.data, nb.ctypes.data, C.byref(gb), C.byref(vb), C.byref(ng), C.byref(nv))
+    assert ng.value == G and nv.value == V
+    arrs.update(result_vars=res, num_bits=nb, gate_base=gb.value, var_base=vb.value, n_gates=G, n_vars=V,
+                satisfied=(rc == 0))
+    return arrs
+
+
+def scalar_mix_batch(v, y, s, a, b, check: bool = True):
+    L = lib()
+    v, y, s, a, b = (_as_fr_array(x) for x in (v, y, s, a, b))
+    batch = v.shape[0]
+    nerr = int((v == 0).all(axis=1).sum())
+    G, V = 10 * batch - 2 * nerr, 15 * batch - 2 * nerr
+    res, err = np.zeros(2 * batch, dtype=np.uint64), np.zeros(batch, dtype=np.uint8)
+    gb, vb, ng, nv = (C.c_uint64() for _ in range(4))
+    arrs, cols = _alloc_columns(G, V)
+    rc = L.oracle_scalar_mix_batch(v.ctypes.data, y.ctypes.data, s.ctypes.data, a.ctypes.data, b.ctypes.data, batch,
+                                   int(check), C.byref(cols), res.ctypes.data, err.ctypes.data, C.byref(gb),
+                                   C.byref(vb), C.byref(ng), C.byref(nv))
+    assert ng.value == G and nv.value == V, (ng.value, nv.value, G, V)
+    arrs.update(result_vars=res.reshape(batch, 2), err_mask=err, gate_base=gb.value, var_base=vb.value, n_gates=G,
+                n_vars=V, satisfied=(rc == 0))
+    return arrs
