@@ -1,0 +1,119 @@
+/*
+ * plonk_gadgets_hip.h -- C ABI of libplonk_gadgets_hip.so, the MI355X (gfx950)
+ * batched constraint-evaluation engine for the gadget hot path of
+ * dusk-network/plonk_gadgets.
+ *
+ * The reference has no FFI of its own: it is a safe-Rust library whose whole
+ * interface is six public gadget functions + `AllocatedScalar` + `Error`
+ * (/root/reference/src/lib.rs:37-45), every one taking
+ * `&mut StandardComposer`.  Each entry point below names the reference
+ * function(s) it replaces; INTEGRATION.md shows the Rust `extern "C"` shim a
+ * maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - plain C types only; no HIP or torch types in any signature.
+ *   - `pg_scalar` is bit-identical to BlsScalar's inner `[u64; 4]`
+ *     (Montgomery limbs, little-endian, fully reduced).
+ *   - pointers named `d_*` and every pointer inside `pg_columns` are DEVICE
+ *     pointers on the engine's GPU; everything else is host memory.
+ *   - the caller allocates and frees every buffer; the engine owns only its
+ *     constant tables.  Sizes come from the `pg_*_layout` queries.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *     Batch calls enqueue and return; synchronise the stream (or call
+ *     pg_engine_sync) before reading results.
+ *   - every function returns a pg_status; nothing aborts.  Conditions on
+ *     which the reference panics map to PG_ERR_INVALID_ARGUMENT.
+ *   - an engine handle is not thread-safe (the reference is single-threaded
+ *     per composer by its `&mut` borrow, e.g. src/range.rs:27-32): use one
+ *     handle per host thread.
+ */
+#ifndef PLONK_GADGETS_HIP_H
+#define PLONK_GADGETS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pg_status {
+    PG_OK = 0,
+    PG_ERR_NON_EXISTING_INVERSE = 1, /* Error::NonExistingInverse, src/errors.rs:17 (raised at src/scalar.rs:79) */
+    PG_ERR_INVALID_ARGUMENT = 2,     /* NULL / misaligned pointer, num_bits > 256 (src/range.rs:134 panics), ... */
+    PG_ERR_NO_DEVICE = 3,            /* no gfx950 device / HIP runtime failure at engine creation */
+    PG_ERR_HIP = 4,                  /* a HIP call failed; pg_last_error() has the text */
+    PG_ERR_CAPACITY = 5              /* composer buffers too small for the append */
+} pg_status;
+
+typedef struct pg_scalar { uint64_t l[4]; } pg_scalar; /* BlsScalar */
+typedef uint64_t pg_variable;                         /* Variable(usize) */
+
+/* AllocatedScalar, src/allocated_scalar.rs:17-23.  The Rust struct has no
+ * #[repr(C)]; a shim converts field by field. */
+typedef struct pg_allocated_scalar {
+    pg_variable var;
+    pg_scalar scalar;
+} pg_allocated_scalar;
+
+/* The live columns a gate row occupies on this path (SURVEY.md section 8a row
+ * a14) plus the variable-assignment table.  Row r of a batch call is gate
+ * `gate_base + r`; entry v of var_values is Variable(var_base + v).  Every
+ * row has q_4 = 0, q_arith = 1, the other selectors 0 and w_4 = zero_var;
+ * those constant columns are not materialised here (pg_composer does). */
+typedef struct pg_columns {
+    pg_scalar *q_m, *q_l, *q_r, *q_o, *q_c; /* device, 16-byte aligned */
+    uint64_t *w_l, *w_r, *w_o;              /* device, 8-byte aligned   */
+    pg_scalar *var_values;                  /* device, 16-byte aligned */
+} pg_columns;
+
+typedef struct pg_layout {
+    uint64_t num_bits;       /* ladder length n (0 for gadgets without a ladder / ragged batches) */
+    uint64_t gates_per_item; /* rows one item emits (0 if ragged)      */
+    uint64_t vars_per_item;  /* variables one item creates (0 if ragged) */
+    uint64_t n_gates;        /* total rows of the batch                 */
+    uint64_t n_vars;         /* total variables of the batch            */
+} pg_layout;
+
+typedef struct pg_engine pg_engine;
+
+/* ---- engine ----------------------------------------------------------- */
+pg_status pg_engine_create(int device, pg_engine **out);
+void pg_engine_destroy(pg_engine *e);
+pg_status pg_engine_sync(pg_engine *e, void *stream);
+const char *pg_status_string(pg_status s);
+const char *pg_last_error(void);
+/* "gfx950" etc.; what the library was built for and what it runs on */
+const char *pg_build_arch(void);
+
+/* ---- BlsScalar helpers (host) ------------------------------------------
+ * what a host needs to form the public arguments: BlsScalar::from(u64),
+ * from_raw/to canonical, neg/sub/add/mul, and the two pure functions of
+ * src/range.rs:173-189. */
+void pg_scalar_from_u64(uint64_t v, pg_scalar *out);
+void pg_scalar_from_canonical(const uint64_t raw[4], pg_scalar *out);
+void pg_scalar_to_canonical(const pg_scalar *s, uint64_t raw[4]);
+void pg_scalar_add(const pg_scalar *a, const pg_scalar *b, pg_scalar *out);
+void pg_scalar_sub(const pg_scalar *a, const pg_scalar *b, pg_scalar *out);
+void pg_scalar_neg(const pg_scalar *a, pg_scalar *out);
+void pg_scalar_mul(const pg_scalar *a, const pg_scalar *b, pg_scalar *out);
+uint64_t pg_bits_count(const pg_scalar *s);                    /* src/range.rs:173-181 */
+uint64_t pg_num_bits_closest_power_of_two(const pg_scalar *s); /* src/range.rs:185-189 */
+
+/* ---- range gadgets, batched --------------------------------------------
+ * pg_range_check_batch: for every witness i, in order,
+ *     w = AllocatedScalar::allocate(composer, witness[i]);   src/allocated_scalar.rs:27
+ *     result[i] = range_check(composer, min, max, w);        src/range.rs:27-43
+ * emitting 4n+11 rows and 2n+524 variables per witness, rows and variables
+ * numbered exactly as that loop numbers them starting at (gate_base,
+ * var_base).  n = num_bits_closest_power_of_two(max - 1). */
+pg_status pg_range_check_layout(const pg_scalar *min_range, const pg_scalar *max_range, uint64_t batch,
+                                pg_layout *out);
+pg_status pg_range_check_batch(pg_engine *e, const pg_scalar *min_range, const pg_scalar *max_range,
+                               const pg_scalar *d_witness, uint64_t batch, uint64_t gate_base, uint64_t var_base,
+                               const pg_columns *out, pg_variable *d_result_vars /* may be NULL */, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,80 @@
+"""ctypes loader for libplonk_gadgets_hip.so.  Fails loudly when the library is missing: there is no CPU path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libplonk_gadgets_hip.so")
+
+
+class Scalar(C.Structure):
+    """pg_scalar == BlsScalar's inner [u64; 4]"""
+    _fields_ = [("l", C.c_uint64 * 4)]
+
+    @staticmethod
+    def of(limbs) -> "Scalar":
+        s = Scalar()
+        for i in range(4):
+            s.l[i] = int(limbs[i])
+        return s
+
+    def limbs(self):
+        return [int(self.l[i]) for i in range(4)]
+
+
+class AllocatedScalarC(C.Structure):
+    _fields_ = [("var", C.c_uint64), ("scalar", Scalar)]
+
+
+class ColumnsC(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("q_m", "q_l", "q_r", "q_o", "q_c", "w_l", "w_r", "w_o", "var_values")]
+
+
+class LayoutC(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("num_bits", "gates_per_item", "vars_per_item", "n_gates", "n_vars")]
+
+
+# every symbol include/plonk_gadgets_hip.h declares: name -> (restype, argtypes)
+_P = C.POINTER
+SIGNATURES = {
+    "pg_engine_create": (C.c_int, [C.c_int, _P(C.c_void_p)]),
+    "pg_engine_destroy": (None, [C.c_void_p]),
+    "pg_engine_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pg_status_string": (C.c_char_p, [C.c_int]),
+    "pg_last_error": (C.c_char_p, []),
+    "pg_build_arch": (C.c_char_p, []),
+    "pg_scalar_from_u64": (None, [C.c_uint64, _P(Scalar)]),
+    "pg_scalar_from_canonical": (None, [_P(C.c_uint64), _P(Scalar)]),
+    "pg_scalar_to_canonical": (None, [_P(Scalar), _P(C.c_uint64)]),
+    "pg_scalar_add": (None, [_P(Scalar), _P(Scalar), _P(Scalar)]),
+    "pg_scalar_sub": (None, [_P(Scalar), _P(Scalar), _P(Scalar)]),
+    "pg_scalar_neg": (None, [_P(Scalar), _P(Scalar)]),
+    "pg_scalar_mul": (None, [_P(Scalar), _P(Scalar), _P(Scalar)]),
+    "pg_bits_count": (C.c_uint64, [_P(Scalar)]),
+    "pg_num_bits_closest_power_of_two": (C.c_uint64, [_P(Scalar)]),
+    "pg_range_check_layout": (C.c_int, [_P(Scalar), _P(Scalar), C.c_uint64, _P(LayoutC)]),
+    "pg_range_check_batch": (C.c_int, [C.c_void_p, _P(Scalar), _P(Scalar), C.c_void_p, C.c_uint64, C.c_uint64,
+                                       C.c_uint64, _P(ColumnsC), C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library (importing torch first so that its bundled HIP runtime -- the one that owns the
+    tensors' device memory -- is the libamdhip64.so.7 the library binds to)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m plonk_gadgets_amd.build` "
+            "(or __graft_entry__.build()). plonk_gadgets_amd has no CPU fallback.")
+    import torch  # noqa: F401  (loads libamdhip64.so.7)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        f = getattr(lib, name)  # AttributeError here == header/library mismatch
+        f.restype, f.argtypes = res, args
+    _lib = lib
+    return lib

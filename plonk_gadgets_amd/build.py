@@ -1,0 +1,42 @@
+"""Builds libplonk_gadgets_hip.so in-tree with hipcc for gfx950 (no torch dependency in the library)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libplonk_gadgets_hip.so")
+SOURCES = ["capi.hip"]
+HEADERS = ["fr.hpp", "range_check.hpp"]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "plonk_gadgets_hip.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, extra_flags: list[str] | None = None, out: str | None = None) -> str:
+    out = out or LIB
+    if not force and out == LIB and not is_stale():
+        return out
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-o", out] + [os.path.join(CSRC, s) for s in SOURCES] + (extra_flags or [])
+    subprocess.check_call(cmd)
+    return out
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,204 @@
+// fr.hpp -- BLS12-381 scalar field (BlsScalar) for the engine: 4 x 64-bit limbs,
+// Montgomery form x*R mod q with R = 2^256, values always fully reduced in
+// [0, q) so that equal field elements have identical limbs (the property the
+// limb-for-limb parity tests rely on).  One source for host and gfx950 device
+// code.  Replaces, for this path, the slice of dusk-bls12_381 `Scalar` the
+// reference calls (call sites: /root/reference/src/range.rs:63,69,87,94,102,
+// 130,146,152,163,174-177,187; src/scalar.rs:47,73,91,113,121-126).
+#pragma once
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PG_HD __host__ __device__ __forceinline__
+#else
+#define PG_HD inline
+#endif
+
+namespace pg {
+
+struct Fr {
+    uint64_t l[4];
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PG_CONST_SPACE __constant__
+#else
+#define PG_CONST_SPACE
+#endif
+
+// q
+#define PG_Q0 0xffffffff00000001ull
+#define PG_Q1 0x53bda402fffe5bfeull
+#define PG_Q2 0x3339d80809a1d805ull
+#define PG_Q3 0x73eda753299d7d48ull
+// -q^{-1} mod 2^64
+#define PG_INV 0xfffffffeffffffffull
+
+PG_HD Fr fr_modulus() { return Fr{{PG_Q0, PG_Q1, PG_Q2, PG_Q3}}; }
+PG_HD Fr fr_zero() { return Fr{{0, 0, 0, 0}}; }
+// mont(1) = R mod q
+PG_HD Fr fr_one() { return Fr{{0x00000001fffffffeull, 0x5884b7fa00034802ull, 0x998c4fefecbc4ff5ull, 0x1824b159acc5056full}}; }
+// mont(-1)
+PG_HD Fr fr_neg_one() { return Fr{{0xfffffffd00000003ull, 0xfb38ec08fffb13fcull, 0x99ad88181ce5880full, 0x5bc8f5f97cd877d8ull}}; }
+// R^2 mod q
+PG_HD Fr fr_r2() { return Fr{{0xc999e990f3f29c6dull, 0x2b6cedcb87925c23ull, 0x05d314967254398full, 0x0748d9d99f59ff11ull}}; }
+
+PG_HD bool fr_is_zero(const Fr &a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
+PG_HD bool fr_eq(const Fr &a, const Fr &b) {
+    return ((a.l[0] ^ b.l[0]) | (a.l[1] ^ b.l[1]) | (a.l[2] ^ b.l[2]) | (a.l[3] ^ b.l[3])) == 0;
+}
+
+typedef unsigned __int128 pg_u128;
+
+PG_HD uint64_t adc64(uint64_t a, uint64_t b, uint64_t &carry) {
+    pg_u128 t = (pg_u128)a + b + carry;
+    carry = (uint64_t)(t >> 64);
+    return (uint64_t)t;
+}
+PG_HD uint64_t sbb64(uint64_t a, uint64_t b, uint64_t &borrow) {
+    pg_u128 t = (pg_u128)a - b - borrow;
+    borrow = (uint64_t)(t >> 64) & 1;
+    return (uint64_t)t;
+}
+PG_HD uint64_t mac64(uint64_t a, uint64_t b, uint64_t c, uint64_t &carry) {
+    pg_u128 t = (pg_u128)a + (pg_u128)b * c + carry;
+    carry = (uint64_t)(t >> 64);
+    return (uint64_t)t;
+}
+
+// r (with a virtual 5th limb `top`, value < 2q) -> r mod q
+PG_HD Fr fr_final_sub(const uint64_t r[4], uint64_t top) {
+    uint64_t bw = 0;
+    uint64_t d0 = sbb64(r[0], PG_Q0, bw), d1 = sbb64(r[1], PG_Q1, bw), d2 = sbb64(r[2], PG_Q2, bw),
+             d3 = sbb64(r[3], PG_Q3, bw);
+    bool keep = top < bw;  // borrowed past the top: r < q
+    return Fr{{keep ? r[0] : d0, keep ? r[1] : d1, keep ? r[2] : d2, keep ? r[3] : d3}};
+}
+
+PG_HD Fr fr_add(const Fr &a, const Fr &b) {
+    uint64_t c = 0, r[4];
+    for (int i = 0; i < 4; i++) r[i] = adc64(a.l[i], b.l[i], c);
+    return fr_final_sub(r, c);
+}
+
+PG_HD Fr fr_sub(const Fr &a, const Fr &b) {
+    uint64_t bw = 0, d[4];
+    for (int i = 0; i < 4; i++) d[i] = sbb64(a.l[i], b.l[i], bw);
+    uint64_t m = 0 - bw, c = 0;
+    Fr o;
+    o.l[0] = adc64(d[0], PG_Q0 & m, c);
+    o.l[1] = adc64(d[1], PG_Q1 & m, c);
+    o.l[2] = adc64(d[2], PG_Q2 & m, c);
+    o.l[3] = adc64(d[3], PG_Q3 & m, c);
+    return o;
+}
+
+PG_HD Fr fr_neg(const Fr &a) {
+    uint64_t bw = 0;
+    uint64_t d0 = sbb64(PG_Q0, a.l[0], bw), d1 = sbb64(PG_Q1, a.l[1], bw), d2 = sbb64(PG_Q2, a.l[2], bw),
+             d3 = sbb64(PG_Q3, a.l[3], bw);
+    uint64_t nz = fr_is_zero(a) ? 0 : ~0ull;
+    return Fr{{d0 & nz, d1 & nz, d2 & nz, d3 & nz}};
+}
+
+// 8-limb product -> Montgomery reduction (4 rounds) -> final conditional subtraction
+PG_HD Fr fr_mont_reduce(uint64_t t[8]) {
+    const uint64_t Q[4] = {PG_Q0, PG_Q1, PG_Q2, PG_Q3};
+    uint64_t carry2 = 0;
+    for (int i = 0; i < 4; i++) {
+        uint64_t k = t[i] * PG_INV, carry = 0;
+        (void)mac64(t[i], k, Q[0], carry);
+        for (int j = 1; j < 4; j++) t[i + j] = mac64(t[i + j], k, Q[j], carry);
+        t[i + 4] = adc64(t[i + 4], carry2, carry);
+        carry2 = carry;
+    }
+    return fr_final_sub(t + 4, carry2);
+}
+
+PG_HD Fr fr_mul(const Fr &a, const Fr &b) {
+    uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        uint64_t carry = 0;
+        for (int j = 0; j < 4; j++) t[i + j] = mac64(t[i + j], a.l[i], b.l[j], carry);
+        t[i + 4] = carry;
+    }
+    return fr_mont_reduce(t);
+}
+
+PG_HD Fr fr_square(const Fr &a) { return fr_mul(a, a); }
+
+// canonical integer (raw limbs, < q) -> Montgomery form
+PG_HD Fr fr_to_mont(const Fr &raw) { return fr_mul(raw, fr_r2()); }
+// Montgomery form -> canonical integer as raw limbs (Scalar::reduce / to_bytes)
+PG_HD Fr fr_from_mont(const Fr &a) {
+    uint64_t t[8] = {a.l[0], a.l[1], a.l[2], a.l[3], 0, 0, 0, 0};
+    return fr_mont_reduce(t);
+}
+PG_HD Fr fr_from_u64(uint64_t v) { return fr_to_mont(Fr{{v, 0, 0, 0}}); }
+
+// raw-limb helpers on canonical integers
+PG_HD uint32_t raw_bit(const Fr &c, uint32_t i) { return (uint32_t)(c.l[i >> 6] >> (i & 63)) & 1u; }
+// c mod 2^nbits, nbits in [0, 256]
+PG_HD Fr raw_low_bits(const Fr &c, uint32_t nbits) {
+    Fr o;
+    for (int i = 0; i < 4; i++) {
+        uint32_t lo = 64u * i;
+        uint64_t m = nbits >= lo + 64 ? ~0ull : (nbits <= lo ? 0ull : ((1ull << (nbits - lo)) - 1));
+        o.l[i] = c.l[i] & m;
+    }
+    return o;
+}
+// c >> nbits != 0, nbits in [0, 256]
+PG_HD bool raw_has_high_bits(const Fr &c, uint32_t nbits) {
+    Fr lo = raw_low_bits(c, nbits);
+    return !fr_eq(lo, c);
+}
+// bit length of a canonical integer (0 for 0)
+PG_HD uint32_t raw_bit_length(const Fr &c) {
+    for (int i = 3; i >= 0; i--)
+        if (c.l[i]) {
+            uint32_t n = 0;
+            uint64_t v = c.l[i];
+            while (v) { n++; v >>= 1; }
+            return 64u * i + n;
+        }
+    return 0;
+}
+
+// a^(q-2): plain square-and-multiply over the fixed exponent.  Returns 0 for 0
+// (CtOption::unwrap_or(zero) at scalar.rs:122; the caller tests for zero where
+// the reference distinguishes, scalar.rs:73-80).
+PG_HD Fr fr_invert_or_zero(const Fr &a) {
+    const uint64_t E[4] = {0xfffffffeffffffffull, PG_Q1, PG_Q2, PG_Q3};  // q - 2
+    Fr res = fr_one();
+    bool started = false;
+    for (int e = 3; e >= 0; e--) {
+        for (int i = 63; i >= 0; i--) {
+            if (started) res = fr_square(res);
+            if ((E[e] >> i) & 1) {
+                res = started ? fr_mul(res, a) : a;
+                started = true;
+            }
+        }
+    }
+    return res;
+}
+
+// 2^by mod q in Montgomery form, by repeated doubling (BlsScalar::pow_of_2, range.rs:187)
+PG_HD Fr fr_pow_of_2(uint64_t by) {
+    Fr r = fr_one();
+    for (uint64_t i = 0; i < by; i++) r = fr_add(r, r);
+    return r;
+}
+
+// range.rs:173-181: bit length of the canonical value, minimum 1
+PG_HD uint64_t bits_count(const Fr &s) {
+    uint32_t n = raw_bit_length(fr_from_mont(s));
+    return n < 1 ? 1 : n;
+}
+// range.rs:185-189
+PG_HD uint64_t num_bits_closest_power_of_two(const Fr &s) { return bits_count(fr_pow_of_2(bits_count(s))); }
+
+}  // namespace pg
