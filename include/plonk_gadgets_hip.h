@@ -113,6 +113,73 @@ pg_status pg_range_check_batch(pg_engine *e, const pg_scalar *min_range, const p
                                const pg_scalar *d_witness, uint64_t batch, uint64_t gate_base, uint64_t var_base,
                                const pg_columns *out, pg_variable *d_result_vars /* may be NULL */, void *stream);
 
+
+/* pg_max_bound_batch: one public bound for the whole batch.  For every witness i,
+ *     w = AllocatedScalar::allocate(composer, witness[i]);
+ *     (result[i], n) = max_bound(composer, max_range, w);             src/range.rs:82-113
+ * 2n+5 rows and n+262 variables per witness; layout->num_bits is the u64 the reference returns. */
+pg_status pg_max_bound_layout(const pg_scalar *max_range, uint64_t batch, pg_layout *out);
+pg_status pg_max_bound_batch(pg_engine *e, const pg_scalar *max_range, const pg_scalar *d_witness, uint64_t batch,
+                             uint64_t gate_base, uint64_t var_base, const pg_columns *out,
+                             pg_variable *d_result_vars /* may be NULL */, void *stream);
+
+/* Ragged max_bound: one public bound PER ITEM (device array), so the ladder length n_i and with it the rows
+ * (2 n_i + 5) and variables (n_i + 262) of an item depend on public data.  The plan computes n_i
+ * (src/range.rs:87-90) and the exclusive prefix sums of rows / variables on the device, returns the totals
+ * (it synchronises `stream`), and the batch call emits at those offsets.
+ * Caller-allocated device buffers: d_num_bits[batch] (u32), d_row_off[batch+1], d_var_off[batch+1] (u64). */
+pg_status pg_max_bound_ragged_plan(pg_engine *e, const pg_scalar *d_max_range, uint64_t batch, uint32_t *d_num_bits,
+                                   uint64_t *d_row_off, uint64_t *d_var_off, pg_layout *out, void *stream);
+pg_status pg_max_bound_ragged_batch(pg_engine *e, const pg_scalar *d_max_range, const pg_scalar *d_witness,
+                                    uint64_t batch, const uint32_t *d_num_bits, const uint64_t *d_row_off,
+                                    const uint64_t *d_var_off, uint64_t gate_base, uint64_t var_base,
+                                    const pg_columns *out, pg_variable *d_result_vars /* may be NULL */, void *stream);
+
+/* ---- scalar gadgets, batched ----------------------------------------------
+ * The stand-alone gadgets take EXISTING Variables: d_*_var are their indices, d_*_val their assignments (what
+ * the reference reads from composer.variables).  Each emits, per item i and in order, the rows/variables of
+ *   conditionally_select_zero(composer, x, select) -> Variable          src/scalar.rs:21-27   (1 row, 1 var)
+ *   conditionally_select_one(composer, y, selector) -> Variable         src/scalar.rs:36-59   (4 rows, 4 vars)
+ *   maybe_equal(composer, a, b) -> Variable                             src/scalar.rs:105-140 (3 rows, 3 vars)
+ *   is_non_zero(composer, var, value_assigned) -> Result<(), Error>     src/scalar.rs:63-97   (3 rows, 3 vars) */
+pg_status pg_conditionally_select_zero_batch(pg_engine *e, const pg_variable *d_x_var, const pg_scalar *d_x_val,
+                                             const pg_variable *d_select_var, const pg_scalar *d_select_val,
+                                             uint64_t batch, uint64_t gate_base, uint64_t var_base,
+                                             const pg_columns *out, pg_variable *d_result_vars, void *stream);
+pg_status pg_conditionally_select_one_batch(pg_engine *e, const pg_variable *d_y_var, const pg_scalar *d_y_val,
+                                            const pg_variable *d_selector_var, const pg_scalar *d_selector_val,
+                                            uint64_t batch, uint64_t gate_base, uint64_t var_base,
+                                            const pg_columns *out, pg_variable *d_result_vars, void *stream);
+pg_status pg_maybe_equal_batch(pg_engine *e, const pg_variable *d_a_var, const pg_scalar *d_a_val,
+                               const pg_variable *d_b_var, const pg_scalar *d_b_val, uint64_t batch,
+                               uint64_t gate_base, uint64_t var_base, const pg_columns *out,
+                               pg_variable *d_result_vars, void *stream);
+/* is_non_zero returns Err(NonExistingInverse) AFTER one variable and one row were pushed (src/scalar.rs:69-79):
+ * an item whose value is 0 therefore occupies 1 row / 1 variable instead of 3 / 3 and the batch is ragged.
+ * The plan writes the per-item error mask (1 = Err), the prefix sums and the totals; it returns
+ * PG_ERR_NON_EXISTING_INVERSE when any item failed (the layout is still valid and the batch may be emitted:
+ * it reproduces a loop that records the error and carries on) and synchronises `stream`. */
+pg_status pg_is_non_zero_plan(pg_engine *e, const pg_scalar *d_value_assigned, uint64_t batch, uint64_t *d_row_off,
+                              uint64_t *d_var_off, uint8_t *d_err_mask /* may be NULL */, pg_layout *out,
+                              uint64_t *err_count /* may be NULL */, void *stream);
+pg_status pg_is_non_zero_batch(pg_engine *e, const pg_variable *d_var, const pg_scalar *d_value_assigned,
+                               uint64_t batch, const uint64_t *d_row_off, const uint64_t *d_var_off,
+                               uint64_t gate_base, uint64_t var_base, pg_variable zero_var, const pg_columns *out,
+                               void *stream);
+
+/* The fused mix (BASELINE.json config 3), one launch: per item
+ *     v, y, s = composer.add_input x3; a, b = AllocatedScalar::allocate x2;
+ *     is_non_zero(composer, v_var, v); conditionally_select_one(composer, y_var, s_var); maybe_equal(composer, a, b)
+ * 10 rows + 15 variables per item (8 + 13 where v = 0).  d_result_vars[2i] = select_one's Variable,
+ * d_result_vars[2i+1] = maybe_equal's.  Plan semantics as pg_is_non_zero_plan. */
+pg_status pg_scalar_mix_plan(pg_engine *e, const pg_scalar *d_v, uint64_t batch, uint64_t *d_row_off,
+                             uint64_t *d_var_off, uint8_t *d_err_mask /* may be NULL */, pg_layout *out,
+                             uint64_t *err_count /* may be NULL */, void *stream);
+pg_status pg_scalar_mix_batch(pg_engine *e, const pg_scalar *d_v, const pg_scalar *d_y, const pg_scalar *d_s,
+                              const pg_scalar *d_a, const pg_scalar *d_b, uint64_t batch, const uint64_t *d_row_off,
+                              const uint64_t *d_var_off, uint64_t gate_base, uint64_t var_base, pg_variable zero_var,
+                              const pg_columns *out, pg_variable *d_result_vars /* may be NULL */, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

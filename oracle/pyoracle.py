@@ -182,3 +182,50 @@ def scalar_mix_batch(v, y, s, a, b, check: bool = True):
     arrs.update(result_vars=res.reshape(batch, 2), err_mask=err, gate_base=gb.value, var_base=vb.value, n_gates=G,
                 n_vars=V, satisfied=(rc == 0))
     return arrs
+
+
+class Composer:
+    """RAII handle on the C oracle's composer with numpy export (rows >= gate_base, variables >= var_base)."""
+
+    def __init__(self, dummy: bool = True):
+        self.L = lib()
+        self.c = self.L.composer_new() if dummy else self.L.composer_new_without_dummy()
+
+    def __del__(self):
+        try:
+            self.L.composer_free(self.c)
+        except Exception:
+            pass
+
+    @property
+    def n(self):
+        return int(self.L.composer_circuit_size(self.c))
+
+    @property
+    def num_vars(self):
+        return int(self.L.composer_num_variables(self.c))
+
+    def add_input(self, limbs_) -> int:
+        return int(self.L.composer_add_input(self.c, fr(limbs_)))
+
+    def allocate(self, limbs_) -> AllocatedScalar:
+        return self.L.allocated_scalar_allocate(self.c, fr(limbs_))
+
+    def check(self) -> int:
+        return int(self.L.composer_check(self.c))
+
+    def export(self, gate_base: int = 0, var_base: int = 0) -> dict:
+        n, nv = self.n, self.num_vars
+        out = {}
+        for name, col in (("q_m", 0), ("q_l", 1), ("q_r", 2), ("q_o", 3), ("q_c", 4)):
+            p = self.L.composer_selector(self.c, col)
+            a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(n, 4)) if n else np.zeros((0, 4), np.uint64)
+            out[name] = a[gate_base:].copy()
+        for name, col in (("w_l", 0), ("w_r", 1), ("w_o", 2)):
+            p = self.L.composer_wire(self.c, col)
+            a = np.ctypeslib.as_array(p, shape=(n,)) if n else np.zeros((0,), np.uint64)
+            out[name] = a[gate_base:].copy()
+        vals = np.zeros((nv, 4), dtype=np.uint64)
+        self.L.composer_values_dense(self.c, vals.ctypes.data)
+        out["var_values"] = vals[var_base:].copy()
+        return out

@@ -56,6 +56,26 @@ SIGNATURES = {
     "pg_range_check_layout": (C.c_int, [_P(Scalar), _P(Scalar), C.c_uint64, _P(LayoutC)]),
     "pg_range_check_batch": (C.c_int, [C.c_void_p, _P(Scalar), _P(Scalar), C.c_void_p, C.c_uint64, C.c_uint64,
                                        C.c_uint64, _P(ColumnsC), C.c_void_p, C.c_void_p]),
+    "pg_max_bound_layout": (C.c_int, [_P(Scalar), C.c_uint64, _P(LayoutC)]),
+    "pg_max_bound_batch": (C.c_int, [C.c_void_p, _P(Scalar), C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
+                                     _P(ColumnsC), C.c_void_p, C.c_void_p]),
+    "pg_max_bound_ragged_plan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           _P(LayoutC), C.c_void_p]),
+    "pg_max_bound_ragged_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_uint64, C.c_uint64, _P(ColumnsC), C.c_void_p, C.c_void_p]),
+    "pg_conditionally_select_zero_batch": (C.c_int, [C.c_void_p] * 5 + [C.c_uint64] * 3 + [_P(ColumnsC), C.c_void_p,
+                                                                                            C.c_void_p]),
+    "pg_conditionally_select_one_batch": (C.c_int, [C.c_void_p] * 5 + [C.c_uint64] * 3 + [_P(ColumnsC), C.c_void_p,
+                                                                                           C.c_void_p]),
+    "pg_maybe_equal_batch": (C.c_int, [C.c_void_p] * 5 + [C.c_uint64] * 3 + [_P(ColumnsC), C.c_void_p, C.c_void_p]),
+    "pg_is_non_zero_plan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      _P(LayoutC), _P(C.c_uint64), C.c_void_p]),
+    "pg_is_non_zero_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                       C.c_uint64, C.c_uint64, C.c_uint64, _P(ColumnsC), C.c_void_p]),
+    "pg_scalar_mix_plan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     _P(LayoutC), _P(C.c_uint64), C.c_void_p]),
+    "pg_scalar_mix_batch": (C.c_int, [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                                          C.c_uint64, _P(ColumnsC), C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

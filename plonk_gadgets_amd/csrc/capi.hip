@@ -11,8 +11,10 @@
 #include <new>
 #include <string>
 
+#include "emit.hpp"
 #include "fr.hpp"
-#include "range_check.hpp"
+#include "range_gadgets.hpp"
+#include "scalar_gadgets.hpp"
 
 namespace {
 
@@ -23,11 +25,17 @@ pg_status fail(pg_status s, const std::string &msg) {
     return s;
 }
 
-#define PG_HIP_TRY(expr)                                                                          \
-    do {                                                                                          \
-        hipError_t _e = (expr);                                                                   \
-        if (_e != hipSuccess)                                                                     \
-            return fail(PG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
+#define PG_HIP_TRY(expr)                                                                \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess)                                                           \
+            return fail(PG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+#define PG_TRY(expr)                   \
+    do {                               \
+        pg_status _s = (expr);         \
+        if (_s != PG_OK) return _s;    \
     } while (0)
 
 inline pg::Fr to_fr(const pg_scalar *s) {
@@ -60,13 +68,143 @@ pg_status check_columns(const pg_columns *c) {
     return PG_OK;
 }
 
+pg_status check_scalars(const void *p, const char *what) {
+    if (!p || !aligned(p, 16)) return fail(PG_ERR_INVALID_ARGUMENT, std::string(what) + " NULL or not 16-byte aligned");
+    return PG_OK;
+}
+pg_status check_u64s(const void *p, const char *what, bool nullable = false) {
+    if (!p && nullable) return PG_OK;
+    if (!p || !aligned(p, 8)) return fail(PG_ERR_INVALID_ARGUMENT, std::string(what) + " NULL or not 8-byte aligned");
+    return PG_OK;
+}
+
 }  // namespace
 
 struct pg_engine {
     int device = -1;
     int num_cus = 0;
     uint4 *d_pow2 = nullptr;  // mont(2^i), i < 256
+    // scratch of the ragged plans (grow-only): per-item counts, block sums, error counter
+    uint32_t *d_rows = nullptr, *d_vars = nullptr;
+    uint64_t *d_blk_rows = nullptr, *d_blk_vars = nullptr;
+    uint32_t *d_err_count = nullptr;
+    uint64_t scratch_items = 0;
 };
+
+namespace {
+
+pg_status ensure_scratch(pg_engine *e, uint64_t batch) {
+    if (batch <= e->scratch_items && e->d_err_count) return PG_OK;
+    PG_HIP_TRY(hipSetDevice(e->device));
+    if (e->d_rows) { (void)hipFree(e->d_rows); e->d_rows = nullptr; }
+    if (e->d_vars) { (void)hipFree(e->d_vars); e->d_vars = nullptr; }
+    if (e->d_blk_rows) { (void)hipFree(e->d_blk_rows); e->d_blk_rows = nullptr; }
+    if (e->d_blk_vars) { (void)hipFree(e->d_blk_vars); e->d_blk_vars = nullptr; }
+    e->scratch_items = 0;
+    const uint64_t items = batch < 1024 ? 1024 : batch;
+    const uint64_t nblk = (items + pg::kScanBlock - 1) / pg::kScanBlock;
+    PG_HIP_TRY(hipMalloc(&e->d_rows, items * sizeof(uint32_t)));
+    PG_HIP_TRY(hipMalloc(&e->d_vars, items * sizeof(uint32_t)));
+    PG_HIP_TRY(hipMalloc(&e->d_blk_rows, nblk * sizeof(uint64_t)));
+    PG_HIP_TRY(hipMalloc(&e->d_blk_vars, nblk * sizeof(uint64_t)));
+    if (!e->d_err_count) PG_HIP_TRY(hipMalloc(&e->d_err_count, sizeof(uint32_t)));
+    e->scratch_items = items;
+    return PG_OK;
+}
+
+// counts in e->d_rows / e->d_vars -> exclusive prefix sums; totals copied back (synchronises the stream)
+pg_status scan_counts(pg_engine *e, uint64_t batch, uint64_t *d_row_off, uint64_t *d_var_off, uint64_t *n_rows,
+                      uint64_t *n_vars, hipStream_t st) {
+    const uint32_t nblk = (uint32_t)((batch + pg::kScanBlock - 1) / pg::kScanBlock);
+    hipLaunchKernelGGL(pg::scan_block_sums_kernel, dim3(nblk), dim3(pg::kThreads), 0, st, e->d_rows, e->d_vars, batch,
+                       e->d_blk_rows, e->d_blk_vars);
+    hipLaunchKernelGGL(pg::scan_top_kernel, dim3(1), dim3(pg::kThreads), 0, st, e->d_blk_rows, e->d_blk_vars, nblk);
+    hipLaunchKernelGGL(pg::scan_final_kernel, dim3(nblk), dim3(pg::kThreads), 0, st, e->d_rows, e->d_vars, batch,
+                       e->d_blk_rows, e->d_blk_vars, d_row_off, d_var_off);
+    PG_HIP_TRY(hipGetLastError());
+    PG_HIP_TRY(hipMemcpyAsync(n_rows, d_row_off + batch, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    PG_HIP_TRY(hipMemcpyAsync(n_vars, d_var_off + batch, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    PG_HIP_TRY(hipStreamSynchronize(st));
+    return PG_OK;
+}
+
+pg::EmitOut make_out(const pg_columns *c, uint64_t batch, int W, uint64_t gate_base, uint64_t var_base, uint64_t zero_var,
+                     const uint64_t *row_off, const uint64_t *var_off) {
+    pg::EmitOut O;
+    O.q[0] = reinterpret_cast<uint4 *>(c->q_m);
+    O.q[1] = reinterpret_cast<uint4 *>(c->q_l);
+    O.q[2] = reinterpret_cast<uint4 *>(c->q_r);
+    O.q[3] = reinterpret_cast<uint4 *>(c->q_o);
+    O.q[4] = reinterpret_cast<uint4 *>(c->q_c);
+    O.w[0] = c->w_l;
+    O.w[1] = c->w_r;
+    O.w[2] = c->w_o;
+    O.vars = reinterpret_cast<uint4 *>(c->var_values);
+    O.gate_base = gate_base;
+    O.var_base = var_base;
+    O.zero_var = zero_var;
+    O.row_off = row_off;
+    O.var_off = var_off;
+    O.batch = batch;
+    O.tiles = (uint32_t)((batch + W - 1) / W);
+    return O;
+}
+
+template <class GD>
+pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, uint64_t batch, uint64_t gate_base,
+                 uint64_t var_base, uint64_t zero_var, const uint64_t *row_off, const uint64_t *var_off, void *stream) {
+    if ((batch + GD::W - 1) / GD::W > 0xffffffffull) return fail(PG_ERR_INVALID_ARGUMENT, "batch too large for one call");
+    PG_HIP_TRY(hipSetDevice(e->device));
+    const pg::EmitOut O = make_out(c, batch, GD::W, gate_base, var_base, zero_var, row_off, var_off);
+    const uint32_t max_blocks = (uint32_t)e->num_cus * 8;
+    const uint32_t grid = O.tiles < max_blocks ? O.tiles : max_blocks;
+    hipLaunchKernelGGL(pg::emit_kernel<GD>, dim3(grid), dim3(pg::kThreads), 0, static_cast<hipStream_t>(stream), A, O);
+    PG_HIP_TRY(hipGetLastError());
+    return PG_OK;
+}
+
+pg_status scalar_args(const pg_variable *a_var, const pg_scalar *a_val, const pg_variable *b_var,
+                             const pg_scalar *b_val, pg_variable *res, pg::ScalarArgs *A) {
+    PG_TRY(check_u64s(a_var, "first Variable array"));
+    PG_TRY(check_u64s(b_var, "second Variable array"));
+    PG_TRY(check_scalars(a_val, "first value array"));
+    PG_TRY(check_scalars(b_val, "second value array"));
+    PG_TRY(check_u64s(res, "d_result_vars", true));
+    A->a_var = a_var;
+    A->b_var = b_var;
+    A->a_val = reinterpret_cast<const uint4 *>(a_val);
+    A->b_val = reinterpret_cast<const uint4 *>(b_val);
+    A->result_vars = res;
+    A->err_mask = nullptr;
+    return PG_OK;
+}
+
+template <class PlanKernel>
+pg_status error_plan(pg_engine *e, PlanKernel kernel, const pg_scalar *d_value, uint64_t batch, uint64_t *d_row_off,
+                            uint64_t *d_var_off, uint8_t *d_err_mask, pg_layout *out, uint64_t *err_count, void *stream) {
+    if (!e || !out) return fail(PG_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::memset(out, 0, sizeof *out);
+    if (err_count) *err_count = 0;
+    if (batch == 0) return PG_OK;
+    PG_TRY(check_scalars(d_value, "value array"));
+    PG_TRY(check_u64s(d_row_off, "d_row_off"));
+    PG_TRY(check_u64s(d_var_off, "d_var_off"));
+    PG_TRY(ensure_scratch(e, batch));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    PG_HIP_TRY(hipMemsetAsync(e->d_err_count, 0, sizeof(uint32_t), st));
+    const uint32_t grid = (uint32_t)((batch + pg::kThreads - 1) / pg::kThreads);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(pg::kThreads), 0, st, reinterpret_cast<const uint4 *>(d_value), batch,
+                       e->d_rows, e->d_vars, d_err_mask, e->d_err_count);
+    PG_HIP_TRY(hipGetLastError());
+    uint32_t errs = 0;
+    PG_HIP_TRY(hipMemcpyAsync(&errs, e->d_err_count, sizeof errs, hipMemcpyDeviceToHost, st));
+    PG_TRY(scan_counts(e, batch, d_row_off, d_var_off, &out->n_gates, &out->n_vars, st));
+    if (err_count) *err_count = errs;
+    if (errs) return fail(PG_ERR_NON_EXISTING_INVERSE, std::to_string(errs) + " item(s) have no inverse (value = 0)");
+    return PG_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -108,7 +246,7 @@ pg_status pg_engine_create(int device, pg_engine **out) {
     hipLaunchKernelGGL(pg::pow2_table_kernel, dim3(1), dim3(64), 0, nullptr, e->d_pow2);
     hipError_t err = hipDeviceSynchronize();
     if (err != hipSuccess) {
-        hipFree(e->d_pow2);
+        (void)hipFree(e->d_pow2);
         delete e;
         return fail(PG_ERR_HIP, std::string("pow2 table kernel: ") + hipGetErrorString(err));
     }
@@ -118,8 +256,13 @@ pg_status pg_engine_create(int device, pg_engine **out) {
 
 void pg_engine_destroy(pg_engine *e) {
     if (!e) return;
-    hipSetDevice(e->device);
-    hipFree(e->d_pow2);
+    (void)hipSetDevice(e->device);
+    (void)hipFree(e->d_pow2);
+    if (e->d_rows) (void)hipFree(e->d_rows);
+    if (e->d_vars) (void)hipFree(e->d_vars);
+    if (e->d_blk_rows) (void)hipFree(e->d_blk_rows);
+    if (e->d_blk_vars) (void)hipFree(e->d_blk_vars);
+    if (e->d_err_count) (void)hipFree(e->d_err_count);
     delete e;
 }
 
@@ -165,45 +308,179 @@ pg_status pg_range_check_batch(pg_engine *e, const pg_scalar *min_range, const p
                                const pg_columns *out, pg_variable *d_result_vars, void *stream) {
     if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
     pg_layout lay;
-    pg_status st = pg_range_check_layout(min_range, max_range, batch, &lay);
-    if (st != PG_OK) return st;
+    PG_TRY(pg_range_check_layout(min_range, max_range, batch, &lay));
     if (batch == 0) return PG_OK;
-    if (!d_witness || !aligned(d_witness, 16)) return fail(PG_ERR_INVALID_ARGUMENT, "d_witness NULL or not 16-byte aligned");
-    if (d_result_vars && !aligned(d_result_vars, 8)) return fail(PG_ERR_INVALID_ARGUMENT, "d_result_vars misaligned");
-    if ((st = check_columns(out)) != PG_OK) return st;
+    PG_TRY(check_scalars(d_witness, "d_witness"));
+    PG_TRY(check_u64s(d_result_vars, "d_result_vars", true));
+    PG_TRY(check_columns(out));
     if (lay.num_bits < 2 || lay.num_bits > 255) return fail(PG_ERR_INVALID_ARGUMENT, "ladder length out of range");
-
-    constexpr int W = 16;
-    const uint64_t tiles = (batch + W - 1) / W;
-    if (tiles > 0xffffffffull || lay.n_gates > (1ull << 40)) return fail(PG_ERR_INVALID_ARGUMENT, "batch too large for one call");
-
-    pg::RangeCheckArgs A;
+    pg::RangeCheckGD::Args A;
     A.min_range = to_fr(min_range);
     A.max_range = to_fr(max_range);
     A.n = (uint32_t)lay.num_bits;
-    A.tiles = (uint32_t)tiles;
-    A.batch = batch;
-    A.gate_base = gate_base;
-    A.var_base = var_base;
-    A.q[0] = reinterpret_cast<uint4 *>(out->q_m);
-    A.q[1] = reinterpret_cast<uint4 *>(out->q_l);
-    A.q[2] = reinterpret_cast<uint4 *>(out->q_r);
-    A.q[3] = reinterpret_cast<uint4 *>(out->q_o);
-    A.q[4] = reinterpret_cast<uint4 *>(out->q_c);
-    A.w[0] = out->w_l;
-    A.w[1] = out->w_r;
-    A.w[2] = out->w_o;
-    A.vars = reinterpret_cast<uint4 *>(out->var_values);
     A.witness = reinterpret_cast<const uint4 *>(d_witness);
     A.result_vars = d_result_vars;
     A.pow2 = e->d_pow2;
+    return launch<pg::RangeCheckGD>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream);
+}
 
-    PG_HIP_TRY(hipSetDevice(e->device));
-    const uint32_t max_blocks = (uint32_t)e->num_cus * 8;
-    const uint32_t grid = tiles < max_blocks ? (uint32_t)tiles : max_blocks;
-    hipLaunchKernelGGL(pg::range_check_kernel<W>, dim3(grid), dim3(pg::kThreads), 0, static_cast<hipStream_t>(stream), A);
-    PG_HIP_TRY(hipGetLastError());
+/* ---- max_bound ------------------------------------------------------------ */
+pg_status pg_max_bound_layout(const pg_scalar *max_range, uint64_t batch, pg_layout *out) {
+    if (!max_range || !out) return fail(PG_ERR_INVALID_ARGUMENT, "NULL argument");
+    pg::Fr mx = to_fr(max_range);
+    if (!is_reduced(mx)) return fail(PG_ERR_INVALID_ARGUMENT, "bound is not a reduced BlsScalar");
+    uint64_t n = pg::num_bits_closest_power_of_two(pg::fr_sub(mx, pg::fr_one()));
+    out->num_bits = n;
+    out->gates_per_item = 2 * n + 5;
+    out->vars_per_item = n + 262;  // n+261 of max_bound + 1 of allocate
+    out->n_gates = out->gates_per_item * batch;
+    out->n_vars = out->vars_per_item * batch;
     return PG_OK;
+}
+
+pg_status pg_max_bound_batch(pg_engine *e, const pg_scalar *max_range, const pg_scalar *d_witness, uint64_t batch,
+                             uint64_t gate_base, uint64_t var_base, const pg_columns *out, pg_variable *d_result_vars,
+                             void *stream) {
+    if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
+    pg_layout lay;
+    PG_TRY(pg_max_bound_layout(max_range, batch, &lay));
+    if (batch == 0) return PG_OK;
+    PG_TRY(check_scalars(d_witness, "d_witness"));
+    PG_TRY(check_u64s(d_result_vars, "d_result_vars", true));
+    PG_TRY(check_columns(out));
+    pg::MaxBoundGD<false>::Args A{};
+    A.max_range = to_fr(max_range);
+    A.n = (uint32_t)lay.num_bits;
+    A.witness = reinterpret_cast<const uint4 *>(d_witness);
+    A.result_vars = d_result_vars;
+    A.pow2 = e->d_pow2;
+    return launch<pg::MaxBoundGD<false>>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream);
+}
+
+pg_status pg_max_bound_ragged_plan(pg_engine *e, const pg_scalar *d_max_range, uint64_t batch, uint32_t *d_num_bits,
+                                   uint64_t *d_row_off, uint64_t *d_var_off, pg_layout *out, void *stream) {
+    if (!e || !out) return fail(PG_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::memset(out, 0, sizeof *out);
+    if (batch == 0) return PG_OK;
+    PG_TRY(check_scalars(d_max_range, "d_max_range"));
+    if (!d_num_bits || !aligned(d_num_bits, 4)) return fail(PG_ERR_INVALID_ARGUMENT, "d_num_bits NULL or misaligned");
+    PG_TRY(check_u64s(d_row_off, "d_row_off"));
+    PG_TRY(check_u64s(d_var_off, "d_var_off"));
+    PG_TRY(ensure_scratch(e, batch));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint32_t grid = (uint32_t)((batch + pg::kThreads - 1) / pg::kThreads);
+    hipLaunchKernelGGL(pg::max_bound_plan_kernel, dim3(grid), dim3(pg::kThreads), 0, st,
+                       reinterpret_cast<const uint4 *>(d_max_range), batch, e->d_pow2, d_num_bits, e->d_rows, e->d_vars);
+    PG_HIP_TRY(hipGetLastError());
+    PG_TRY(scan_counts(e, batch, d_row_off, d_var_off, &out->n_gates, &out->n_vars, st));
+    return PG_OK;
+}
+
+pg_status pg_max_bound_ragged_batch(pg_engine *e, const pg_scalar *d_max_range, const pg_scalar *d_witness, uint64_t batch,
+                                    const uint32_t *d_num_bits, const uint64_t *d_row_off, const uint64_t *d_var_off,
+                                    uint64_t gate_base, uint64_t var_base, const pg_columns *out,
+                                    pg_variable *d_result_vars, void *stream) {
+    if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
+    if (batch == 0) return PG_OK;
+    PG_TRY(check_scalars(d_max_range, "d_max_range"));
+    PG_TRY(check_scalars(d_witness, "d_witness"));
+    if (!d_num_bits) return fail(PG_ERR_INVALID_ARGUMENT, "d_num_bits is NULL");
+    PG_TRY(check_u64s(d_row_off, "d_row_off"));
+    PG_TRY(check_u64s(d_var_off, "d_var_off"));
+    PG_TRY(check_u64s(d_result_vars, "d_result_vars", true));
+    PG_TRY(check_columns(out));
+    pg::MaxBoundGD<true>::Args A{};
+    A.max_range_v = reinterpret_cast<const uint4 *>(d_max_range);
+    A.num_bits_v = d_num_bits;
+    A.witness = reinterpret_cast<const uint4 *>(d_witness);
+    A.result_vars = d_result_vars;
+    A.pow2 = e->d_pow2;
+    return launch<pg::MaxBoundGD<true>>(e, A, out, batch, gate_base, var_base, 0, d_row_off, d_var_off, stream);
+}
+
+/* ---- scalar gadgets ------------------------------------------------------- */
+pg_status pg_conditionally_select_zero_batch(pg_engine *e, const pg_variable *d_x_var, const pg_scalar *d_x_val,
+                                             const pg_variable *d_select_var, const pg_scalar *d_select_val, uint64_t batch,
+                                             uint64_t gate_base, uint64_t var_base, const pg_columns *out,
+                                             pg_variable *d_result_vars, void *stream) {
+    if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
+    if (batch == 0) return PG_OK;
+    pg::ScalarArgs A;
+    PG_TRY(scalar_args(d_x_var, d_x_val, d_select_var, d_select_val, d_result_vars, &A));
+    PG_TRY(check_columns(out));
+    return launch<pg::SelectZeroGD>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream);
+}
+
+pg_status pg_conditionally_select_one_batch(pg_engine *e, const pg_variable *d_y_var, const pg_scalar *d_y_val,
+                                            const pg_variable *d_selector_var, const pg_scalar *d_selector_val,
+                                            uint64_t batch, uint64_t gate_base, uint64_t var_base, const pg_columns *out,
+                                            pg_variable *d_result_vars, void *stream) {
+    if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
+    if (batch == 0) return PG_OK;
+    pg::ScalarArgs A;
+    PG_TRY(scalar_args(d_y_var, d_y_val, d_selector_var, d_selector_val, d_result_vars, &A));
+    PG_TRY(check_columns(out));
+    return launch<pg::SelectOneGD>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream);
+}
+
+pg_status pg_maybe_equal_batch(pg_engine *e, const pg_variable *d_a_var, const pg_scalar *d_a_val, const pg_variable *d_b_var,
+                               const pg_scalar *d_b_val, uint64_t batch, uint64_t gate_base, uint64_t var_base,
+                               const pg_columns *out, pg_variable *d_result_vars, void *stream) {
+    if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
+    if (batch == 0) return PG_OK;
+    pg::ScalarArgs A;
+    PG_TRY(scalar_args(d_a_var, d_a_val, d_b_var, d_b_val, d_result_vars, &A));
+    PG_TRY(check_columns(out));
+    return launch<pg::MaybeEqualGD>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream);
+}
+
+pg_status pg_is_non_zero_plan(pg_engine *e, const pg_scalar *d_value_assigned, uint64_t batch, uint64_t *d_row_off,
+                              uint64_t *d_var_off, uint8_t *d_err_mask, pg_layout *out, uint64_t *err_count, void *stream) {
+    return error_plan(e, pg::is_non_zero_plan_kernel, d_value_assigned, batch, d_row_off, d_var_off, d_err_mask, out,
+                      err_count, stream);
+}
+
+pg_status pg_is_non_zero_batch(pg_engine *e, const pg_variable *d_var, const pg_scalar *d_value_assigned, uint64_t batch,
+                               const uint64_t *d_row_off, const uint64_t *d_var_off, uint64_t gate_base, uint64_t var_base,
+                               pg_variable zero_var, const pg_columns *out, void *stream) {
+    if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
+    if (batch == 0) return PG_OK;
+    PG_TRY(check_u64s(d_var, "d_var"));
+    PG_TRY(check_scalars(d_value_assigned, "d_value_assigned"));
+    PG_TRY(check_u64s(d_row_off, "d_row_off"));
+    PG_TRY(check_u64s(d_var_off, "d_var_off"));
+    PG_TRY(check_columns(out));
+    pg::ScalarArgs A{};
+    A.a_var = d_var;
+    A.b_val = reinterpret_cast<const uint4 *>(d_value_assigned);
+    return launch<pg::IsNonZeroGD>(e, A, out, batch, gate_base, var_base, zero_var, d_row_off, d_var_off, stream);
+}
+
+pg_status pg_scalar_mix_plan(pg_engine *e, const pg_scalar *d_v, uint64_t batch, uint64_t *d_row_off, uint64_t *d_var_off,
+                             uint8_t *d_err_mask, pg_layout *out, uint64_t *err_count, void *stream) {
+    return error_plan(e, pg::scalar_mix_plan_kernel, d_v, batch, d_row_off, d_var_off, d_err_mask, out, err_count, stream);
+}
+
+pg_status pg_scalar_mix_batch(pg_engine *e, const pg_scalar *d_v, const pg_scalar *d_y, const pg_scalar *d_s,
+                              const pg_scalar *d_a, const pg_scalar *d_b, uint64_t batch, const uint64_t *d_row_off,
+                              const uint64_t *d_var_off, uint64_t gate_base, uint64_t var_base, pg_variable zero_var,
+                              const pg_columns *out, pg_variable *d_result_vars, void *stream) {
+    if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
+    if (batch == 0) return PG_OK;
+    const pg_scalar *in[5] = {d_v, d_y, d_s, d_a, d_b};
+    for (const pg_scalar *p : in) PG_TRY(check_scalars(p, "input array"));
+    PG_TRY(check_u64s(d_row_off, "d_row_off"));
+    PG_TRY(check_u64s(d_var_off, "d_var_off"));
+    PG_TRY(check_u64s(d_result_vars, "d_result_vars", true));
+    PG_TRY(check_columns(out));
+    pg::ScalarMixArgs A;
+    A.v = reinterpret_cast<const uint4 *>(d_v);
+    A.y = reinterpret_cast<const uint4 *>(d_y);
+    A.s = reinterpret_cast<const uint4 *>(d_s);
+    A.a = reinterpret_cast<const uint4 *>(d_a);
+    A.b = reinterpret_cast<const uint4 *>(d_b);
+    A.result_vars = d_result_vars;
+    return launch<pg::ScalarMixGD>(e, A, out, batch, gate_base, var_base, zero_var, d_row_off, d_var_off, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,328 @@
+// range_gadgets.hpp -- range_check / max_bound as policies of the streaming
+// writer (emit.hpp).
+//
+// One "bound block" is what max_bound (/root/reference/src/range.rs:82-113)
+// or min_bound (:53-76) appends: one add row producing T (= max-1-x or x-min)
+// followed by scalar_decomposition_gadget (:119-158) on T, which ends in
+// maybe_equal (/root/reference/src/scalar.rs:105-140).  With n ladder bits a
+// block has L = 2n+5 rows and VB = n+261 variables:
+//     row 0        bound add   (x, x, T ; 0, -1|+1, 0, -1, mont(max-1) | mont(-min))
+//     row 1        A0 const    (A0,A0,A0 ; 0, 1, 0, 0, 0)
+//     row 2+2i     boolean     (b_i,b_i,b_i ; 1, 0, 0, -1, 0)
+//     row 3+2i     ladder add  (b_i, A_i, A_{i+1} ; 0, mont(2^i), 1, -1, 0)
+//     row 2n+2     u = A_n - T (A_n, T, U ; 0, 1, -1, -1, 0)
+//     row 2n+3     y = 1 - u z (Z, U, Y ; -1, 0, 0, -1, 1)
+//     row 2n+4     y u = 0     (Y, U, U ; 1, 0, 0, 0, 0)
+//     var 0 = T, 1..256 = the 256 bits of canonical(T) (all allocated, range.rs:128-131),
+//     257+i = A_i (i = 0..n), 258+n = U, 259+n = Z, 260+n = Y
+//
+// range_check (range.rs:27-43), preceded by AllocatedScalar::allocate
+// (allocated_scalar.rs:27): variables [x | max block | min block | R], rows
+// [max block | min block | (Y1, Y2, R ; 1, 0, 0, -1, 0)].
+// max_bound alone: variables [x | block], rows [block].
+#pragma once
+
+#include "emit.hpp"
+
+namespace pg {
+
+struct alignas(16) BoundRec {
+    Fr Tm;  // T in Montgomery form (the block's first variable)
+    Fr Tc;  // canonical integer of T
+    Fr U;   // A_n - T
+    Fr Z;   // U^-1 or 0
+};
+
+// per-item arithmetic of one bound block
+__device__ __forceinline__ uint32_t bound_item(const Fr &Tm, uint32_t n, BoundRec &b) {
+    const Fr Tc = fr_from_mont(Tm);            // scalar_to_bits -> to_bytes, range.rs:163
+    const bool hi = raw_has_high_bits(Tc, n);  // T does not fit n bits
+    Fr U = fr_zero(), Z = fr_zero();
+    if (hi) {
+        U = fr_sub(fr_to_mont(raw_low_bits(Tc, n)), Tm);  // accumulator - witness, scalar.rs:121
+        Z = fr_invert_or_zero(U);                         // scalar.rs:122
+    }
+    b.Tm = Tm;
+    b.Tc = Tc;
+    b.U = U;
+    b.Z = Z;
+    return hi ? 0u : 1u;  // y = 1 - u z
+}
+
+// selector table ids of block row jj; is_min selects the min_bound flavour of row 0
+__device__ __forceinline__ void bound_selector_ids(uint32_t jj, uint32_t n, bool is_min, uint32_t id[5]) {
+    uint32_t qm = T_ZERO, ql = T_ZERO, qr = T_ZERO, qo = T_NEG1, qc = T_ZERO;
+    if (jj >= 2 && jj < 2 * n + 2) {
+        if (jj & 1) {  // ladder add, range.rs:147-151
+            ql = T_POW + ((jj - 3) >> 1);
+            qr = T_ONE;
+        } else {  // boolean_gate, range.rs:144
+            qm = T_ONE;
+        }
+    } else if (jj == 0) {  // range.rs:93-99 / :60-66
+        ql = is_min ? T_ONE : T_NEG1;
+        qc = is_min ? T_QC_B : T_QC_A;
+    } else if (jj == 1) {  // add_witness_to_circuit_description(0), range.rs:139
+        ql = T_ONE;
+        qo = T_ZERO;
+    } else if (jj == 2 * n + 2) {  // scalar.rs:111-117
+        ql = T_ONE;
+        qr = T_NEG1;
+    } else if (jj == 2 * n + 3) {  // scalar.rs:126
+        qm = T_NEG1;
+        qc = T_ONE;
+    } else {  // scalar.rs:129-138
+        qm = T_ONE;
+        qo = T_ZERO;
+    }
+    id[0] = qm; id[1] = ql; id[2] = qr; id[3] = qo; id[4] = qc;
+}
+
+// wire variable offsets of block row jj; vb = offset of the block's first variable, x = offset of the witness
+__device__ __forceinline__ void bound_wire_offsets(uint32_t jj, uint32_t n, uint32_t vb, uint32_t x, uint32_t off[3]) {
+    uint32_t a, b, c;
+    if (jj >= 2 && jj < 2 * n + 2) {
+        const uint32_t i = (jj - 2) >> 1;
+        a = vb + 1 + i;  // b_i
+        if (jj & 1) { b = vb + 257 + i; c = vb + 258 + i; }
+        else { b = a; c = a; }
+    } else if (jj == 0) {
+        a = x; b = x; c = vb;  // w_r = x with q_r = 0 (not zero_var), range.rs:62,95
+    } else if (jj == 1) {
+        a = b = c = vb + 257;
+    } else if (jj == 2 * n + 2) {
+        a = vb + 257 + n; b = vb; c = vb + 258 + n;
+    } else if (jj == 2 * n + 3) {
+        a = vb + 259 + n; b = vb + 258 + n; c = vb + 260 + n;
+    } else {
+        a = vb + 260 + n; b = vb + 258 + n; c = b;
+    }
+    off[0] = a; off[1] = b; off[2] = c;
+}
+
+// value of block variable kk
+__device__ __forceinline__ Fr bound_var_value(const BoundRec &B, uint32_t y, uint32_t kk, uint32_t n) {
+    if (kk == 0) return B.Tm;
+    if (kk <= 256) return raw_bit(B.Tc, kk - 1) ? fr_one() : fr_zero();  // range.rs:128-131
+    if (kk <= 257 + n) {                                                  // A_i = mont(T mod 2^i), range.rs:152
+        const uint32_t i = kk - 257;
+        return i ? fr_to_mont(raw_low_bits(B.Tc, i)) : fr_zero();
+    }
+    if (kk == 258 + n) return B.U;
+    if (kk == 259 + n) return B.Z;
+    return y ? fr_one() : fr_zero();  // scalar.rs:126
+}
+
+__device__ __forceinline__ void ids_to_values(const uint32_t id[5], const uint4 *table, uint32_t h, uint4 out[5]) {
+#pragma unroll
+    for (int c = 0; c < 5; c++) out[c] = table[2 * id[c] + h];
+}
+
+// ---- range_check ------------------------------------------------------------
+struct RangeCheckGD {
+    struct Args {
+        Fr min_range, max_range;  // Montgomery form (public inputs)
+        uint32_t n;               // ladder bits
+        const uint4 *witness;
+        uint64_t *result_vars;
+        const uint4 *pow2;
+    };
+    struct alignas(16) ItemRec {
+        Fr x;
+        BoundRec b[2];
+        uint32_t y[2];
+        uint32_t pad[2];
+    };
+    static constexpr int W = 16;
+    static constexpr bool kRagged = false, kRecInRows = false, kUsePow2 = true;
+
+    __device__ static const uint4 *pow2(const Args &A) { return A.pow2; }
+    __device__ static uint32_t rows_per_item(const Args &A) { return 4 * A.n + 11; }
+    __device__ static uint32_t vars_per_item(const Args &A) { return 2 * A.n + 524; }
+
+    __device__ static void fill_table(const Args &A, uint4 *table, uint32_t tid) {
+        if (tid == T_QC_A || tid == T_QC_B) {
+            FrVec t;
+            t.f = tid == T_QC_A ? fr_sub(A.max_range, fr_one())  // range.rs:87
+                                : fr_neg(A.min_range);           // range.rs:63
+            table[2 * tid] = t.v[0];
+            table[2 * tid + 1] = t.v[1];
+        }
+    }
+
+    __device__ static void item(const Args &A, const EmitOut &O, uint64_t item, const uint4 *table, ItemRec &R) {
+        FrVec x;
+        x.v[0] = A.witness[item * 2];
+        x.v[1] = A.witness[item * 2 + 1];
+        R.x = x.f;
+        // T = (max-1) - x  (range.rs:102)   |   T = x - min  (range.rs:69)
+        R.y[0] = bound_item(fr_sub(lds_fr(table, T_QC_A), x.f), A.n, R.b[0]);
+        R.y[1] = bound_item(fr_add(x.f, lds_fr(table, T_QC_B)), A.n, R.b[1]);
+        const uint64_t V = vars_per_item(A);
+        if (A.result_vars) A.result_vars[item] = O.var_base + item * V + (V - 1);
+    }
+
+    __device__ static void selectors(const Args &A, const ItemRec &, uint32_t j, const uint4 *table, uint32_t h, uint4 out[5]) {
+        const uint32_t L = 2 * A.n + 5;
+        uint32_t id[5];
+        if (j == 2 * L) {  // y1 * y2, range.rs:42
+            id[0] = T_ONE; id[1] = T_ZERO; id[2] = T_ZERO; id[3] = T_NEG1; id[4] = T_ZERO;
+        } else {
+            const bool is_min = j >= L;
+            bound_selector_ids(is_min ? j - L : j, A.n, is_min, id);
+        }
+        ids_to_values(id, table, h, out);
+    }
+
+    __device__ static void wires(const Args &A, const EmitOut &, const ItemRec &, uint64_t, uint64_t vbase, uint32_t j,
+                                 uint64_t out[3]) {
+        const uint32_t n = A.n, L = 2 * n + 5, VB = n + 261;
+        uint32_t off[3];
+        if (j == 2 * L) {
+            off[0] = 1 + 260 + n;       // Y1
+            off[1] = 1 + VB + 260 + n;  // Y2
+            off[2] = 1 + 2 * VB;        // R
+        } else {
+            const bool is_min = j >= L;
+            bound_wire_offsets(is_min ? j - L : j, n, is_min ? 1 + VB : 1, 0, off);
+        }
+        out[0] = vbase + off[0];
+        out[1] = vbase + off[1];
+        out[2] = vbase + off[2];
+    }
+
+    __device__ static Fr var_value(const Args &A, const ItemRec &R, const uint4 *, uint32_t k) {
+        const uint32_t n = A.n, VB = n + 261;
+        if (k == 0) return R.x;
+        if (k == 2 * VB + 1) return (R.y[0] & R.y[1]) ? fr_one() : fr_zero();  // range.rs:42
+        uint32_t kk = k - 1, blk = 0;
+        if (kk >= VB) { kk -= VB; blk = 1; }
+        return bound_var_value(R.b[blk], R.y[blk], kk, n);
+    }
+};
+
+// ---- max_bound: one public bound for the whole batch, or one bound per item ----
+template <bool RAGGED>
+struct MaxBoundGD {
+    struct Args {
+        Fr max_range;               // uniform: the bound (Montgomery form)
+        uint32_t n;                 // uniform: ladder bits
+        const uint4 *max_range_v;   // ragged: per-item bounds
+        const uint32_t *num_bits_v; // ragged: per-item ladder bits (from the plan)
+        const uint4 *witness;
+        uint64_t *result_vars;
+        const uint4 *pow2;
+    };
+    struct alignas(16) ItemRec {
+        Fr x;
+        Fr qc;  // mont(max - 1) of this item (ragged: a per-item selector constant)
+        BoundRec b;
+        uint32_t y, n;
+        uint32_t pad[2];
+    };
+    static constexpr int W = 16;
+    static constexpr bool kRagged = RAGGED, kRecInRows = RAGGED, kUsePow2 = true;
+
+    __device__ static const uint4 *pow2(const Args &A) { return A.pow2; }
+    __device__ static uint32_t rows_per_item(const Args &A) { return 2 * A.n + 5; }
+    __device__ static uint32_t vars_per_item(const Args &A) { return A.n + 262; }
+
+    __device__ static void fill_table(const Args &A, uint4 *table, uint32_t tid) {
+        if (tid == T_QC_A) {
+            FrVec t;
+            t.f = RAGGED ? fr_zero() : fr_sub(A.max_range, fr_one());  // range.rs:87
+            table[2 * tid] = t.v[0];
+            table[2 * tid + 1] = t.v[1];
+        } else if (tid == T_QC_B) {
+            table[2 * tid] = make_uint4(0, 0, 0, 0);
+            table[2 * tid + 1] = make_uint4(0, 0, 0, 0);
+        }
+    }
+
+    __device__ static void item(const Args &A, const EmitOut &O, uint64_t item, const uint4 *table, ItemRec &R) {
+        FrVec x;
+        x.v[0] = A.witness[item * 2];
+        x.v[1] = A.witness[item * 2 + 1];
+        R.x = x.f;
+        uint32_t n = A.n;
+        Fr qc;
+        if constexpr (RAGGED) {
+            FrVec m;
+            m.v[0] = A.max_range_v[item * 2];
+            m.v[1] = A.max_range_v[item * 2 + 1];
+            qc = fr_sub(m.f, fr_one());
+            n = A.num_bits_v[item];
+        } else {
+            qc = lds_fr(table, T_QC_A);
+        }
+        R.qc = qc;
+        R.n = n;
+        R.y = bound_item(fr_sub(qc, x.f), n, R.b);  // range.rs:102
+        if (A.result_vars) {
+            const uint64_t first = RAGGED ? O.var_off[item] : item * (uint64_t)(n + 262);
+            A.result_vars[item] = O.var_base + first + (n + 261);  // Y is the item's last variable
+        }
+    }
+
+    __device__ static void selectors(const Args &A, const ItemRec &R, uint32_t j, const uint4 *table, uint32_t h, uint4 out[5]) {
+        uint32_t id[5];
+        bound_selector_ids(j, RAGGED ? R.n : A.n, false, id);
+        ids_to_values(id, table, h, out);
+        if constexpr (RAGGED) {
+            if (j == 0) {  // the only data-dependent selector: q_c = mont(max_i - 1)
+                FrVec q;
+                q.f = R.qc;
+                out[4] = q.v[h];
+            }
+        }
+    }
+
+    __device__ static void wires(const Args &A, const EmitOut &, const ItemRec &R, uint64_t, uint64_t vbase, uint32_t j,
+                                 uint64_t out[3]) {
+        uint32_t off[3];
+        bound_wire_offsets(j, RAGGED ? R.n : A.n, 1, 0, off);
+        out[0] = vbase + off[0];
+        out[1] = vbase + off[1];
+        out[2] = vbase + off[2];
+    }
+
+    __device__ static Fr var_value(const Args &A, const ItemRec &R, const uint4 *, uint32_t k) {
+        if (k == 0) return R.x;
+        return bound_var_value(R.b, R.y, k - 1, RAGGED ? R.n : A.n);
+    }
+};
+
+// plan of a ragged max_bound batch: ladder bits and row/variable counts per item (range.rs:87-90)
+__global__ __launch_bounds__(kThreads) void max_bound_plan_kernel(const uint4 *max_range, uint64_t batch, const uint4 *pow2,
+                                                                 uint32_t *num_bits, uint32_t *rows, uint32_t *vars) {
+    const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= batch) return;
+    FrVec m, p;
+    m.v[0] = max_range[i * 2];
+    m.v[1] = max_range[i * 2 + 1];
+    const Fr mm1 = fr_sub(m.f, fr_one());
+    uint32_t nb = raw_bit_length(fr_from_mont(mm1));  // bits_count, range.rs:173-181
+    if (nb < 1) nb = 1;
+    // bits_count(BlsScalar::pow_of_2(nb)), range.rs:187-188 (nb <= 255)
+    p.v[0] = pow2[nb * 2];
+    p.v[1] = pow2[nb * 2 + 1];
+    uint32_t n = raw_bit_length(fr_from_mont(p.f));
+    if (n < 1) n = 1;
+    num_bits[i] = n;
+    rows[i] = 2 * n + 5;
+    vars[i] = n + 262;
+}
+
+// engine table: mont(2^i) by repeated doubling (one thread; runs once per engine)
+__global__ void pow2_table_kernel(uint4 *out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    FrVec p;
+    p.f = fr_one();
+    for (int i = 0; i < 256; i++) {
+        out[2 * i] = p.v[0];
+        out[2 * i + 1] = p.v[1];
+        p.f = fr_add(p.f, p.f);
+    }
+}
+
+}  // namespace pg

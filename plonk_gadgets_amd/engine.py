@@ -129,3 +129,142 @@ class Engine:
         if st != 0:
             raise PgError(st, "pg_range_check_batch")
         return out, result_vars
+
+    # ---- helpers -------------------------------------------------------------
+    def _layout(self, lay: "_lib.LayoutC") -> Layout:
+        return Layout(*[int(getattr(lay, f)) for f in ("num_bits", "gates_per_item", "vars_per_item", "n_gates", "n_vars")])
+
+    @staticmethod
+    def _check_scalars(t: torch.Tensor, batch: int | None = None):
+        assert t.is_cuda and t.dtype == torch.int64 and t.dim() == 2 and t.shape[1] == 4 and t.is_contiguous()
+        assert batch is None or t.shape[0] == batch
+
+    @staticmethod
+    def _check_vars(t: torch.Tensor, batch: int):
+        assert t.is_cuda and t.dtype == torch.int64 and t.dim() == 1 and t.shape[0] == batch and t.is_contiguous()
+
+    def _out(self, out, n_gates, n_vars, gate_base, var_base):
+        return out if out is not None else Columns.allocate(n_gates, n_vars, self.device, gate_base, var_base)
+
+    # ---- max_bound -------------------------------------------------------------
+    def max_bound_layout(self, max_range: BlsScalar, batch: int) -> Layout:
+        lay = _lib.LayoutC()
+        st = self._lib.pg_max_bound_layout(C.byref(max_range.c), batch, C.byref(lay))
+        if st != 0:
+            raise PgError(st, "pg_max_bound_layout")
+        return self._layout(lay)
+
+    def max_bound_batch(self, max_range: BlsScalar, witness: torch.Tensor, gate_base: int = 0, var_base: int = 0,
+                        out: Columns | None = None):
+        """for each witness: allocate + max_bound(composer, max_range, w) (/root/reference/src/range.rs:82-113).
+        Returns (Columns, result_vars, num_bits)."""
+        self._check_scalars(witness)
+        batch = witness.shape[0]
+        lay = self.max_bound_layout(max_range, batch)
+        out = self._out(out, lay.n_gates, lay.n_vars, gate_base, var_base)
+        res = torch.empty((batch,), dtype=torch.int64, device=self.device)
+        cols = out.as_c()
+        st = self._lib.pg_max_bound_batch(self._h, C.byref(max_range.c), witness.data_ptr(), batch, gate_base, var_base,
+                                          C.byref(cols), res.data_ptr(), self._stream())
+        if st != 0:
+            raise PgError(st, "pg_max_bound_batch")
+        return out, res, lay.num_bits
+
+    def max_bound_ragged_batch(self, max_range: torch.Tensor, witness: torch.Tensor, gate_base: int = 0,
+                               var_base: int = 0):
+        """one public bound PER ITEM (device tensor): plan (ladder bits + prefix sums on the device) then emit.
+        Returns (Columns, result_vars, num_bits[int32 tensor], layout)."""
+        self._check_scalars(witness)
+        batch = witness.shape[0]
+        self._check_scalars(max_range, batch)
+        nb = torch.empty((batch,), dtype=torch.int32, device=self.device)
+        roff = torch.empty((batch + 1,), dtype=torch.int64, device=self.device)
+        voff = torch.empty((batch + 1,), dtype=torch.int64, device=self.device)
+        lay = _lib.LayoutC()
+        st = self._lib.pg_max_bound_ragged_plan(self._h, max_range.data_ptr(), batch, nb.data_ptr(), roff.data_ptr(),
+                                                voff.data_ptr(), C.byref(lay), self._stream())
+        if st != 0:
+            raise PgError(st, "pg_max_bound_ragged_plan")
+        lay = self._layout(lay)
+        out = Columns.allocate(lay.n_gates, lay.n_vars, self.device, gate_base, var_base)
+        res = torch.empty((batch,), dtype=torch.int64, device=self.device)
+        cols = out.as_c()
+        st = self._lib.pg_max_bound_ragged_batch(self._h, max_range.data_ptr(), witness.data_ptr(), batch, nb.data_ptr(),
+                                                 roff.data_ptr(), voff.data_ptr(), gate_base, var_base, C.byref(cols),
+                                                 res.data_ptr(), self._stream())
+        if st != 0:
+            raise PgError(st, "pg_max_bound_ragged_batch")
+        return out, res, nb, lay
+
+    # ---- scalar gadgets ----------------------------------------------------------
+    def _scalar2(self, fn_name, per_item, a_var, a_val, b_var, b_val, gate_base, var_base, out):
+        batch = a_var.shape[0]
+        self._check_vars(a_var, batch)
+        self._check_vars(b_var, batch)
+        self._check_scalars(a_val, batch)
+        self._check_scalars(b_val, batch)
+        out = self._out(out, per_item * batch, per_item * batch, gate_base, var_base)
+        res = torch.empty((batch,), dtype=torch.int64, device=self.device)
+        cols = out.as_c()
+        st = getattr(self._lib, fn_name)(self._h, a_var.data_ptr(), a_val.data_ptr(), b_var.data_ptr(), b_val.data_ptr(),
+                                         batch, gate_base, var_base, C.byref(cols), res.data_ptr(), self._stream())
+        if st != 0:
+            raise PgError(st, fn_name)
+        return out, res
+
+    def conditionally_select_zero_batch(self, x_var, x_val, select_var, select_val, gate_base=0, var_base=0, out=None):
+        """/root/reference/src/scalar.rs:21-27, per item"""
+        return self._scalar2("pg_conditionally_select_zero_batch", 1, x_var, x_val, select_var, select_val, gate_base,
+                             var_base, out)
+
+    def conditionally_select_one_batch(self, y_var, y_val, selector_var, selector_val, gate_base=0, var_base=0, out=None):
+        """/root/reference/src/scalar.rs:36-59, per item"""
+        return self._scalar2("pg_conditionally_select_one_batch", 4, y_var, y_val, selector_var, selector_val, gate_base,
+                             var_base, out)
+
+    def maybe_equal_batch(self, a_var, a_val, b_var, b_val, gate_base=0, var_base=0, out=None):
+        """/root/reference/src/scalar.rs:105-140, per item"""
+        return self._scalar2("pg_maybe_equal_batch", 3, a_var, a_val, b_var, b_val, gate_base, var_base, out)
+
+    def _error_plan(self, fn_name, values, batch):
+        roff = torch.empty((batch + 1,), dtype=torch.int64, device=self.device)
+        voff = torch.empty((batch + 1,), dtype=torch.int64, device=self.device)
+        err = torch.zeros((max(batch, 1),), dtype=torch.uint8, device=self.device)
+        lay, nerr = _lib.LayoutC(), C.c_uint64()
+        st = getattr(self._lib, fn_name)(self._h, values.data_ptr(), batch, roff.data_ptr(), voff.data_ptr(),
+                                         err.data_ptr(), C.byref(lay), C.byref(nerr), self._stream())
+        if st not in (0, 1):
+            raise PgError(st, fn_name)
+        return roff, voff, err[:batch], self._layout(lay), int(nerr.value)
+
+    def is_non_zero_batch(self, var, value_assigned, gate_base=0, var_base=0, zero_var=0):
+        """/root/reference/src/scalar.rs:63-97, per item.  Returns (Columns, err_mask[uint8], err_count): items whose
+        value is 0 (Err(NonExistingInverse)) keep their partial emission (1 row, 1 variable)."""
+        batch = var.shape[0]
+        self._check_vars(var, batch)
+        self._check_scalars(value_assigned, batch)
+        roff, voff, err, lay, nerr = self._error_plan("pg_is_non_zero_plan", value_assigned, batch)
+        out = Columns.allocate(lay.n_gates, lay.n_vars, self.device, gate_base, var_base)
+        cols = out.as_c()
+        st = self._lib.pg_is_non_zero_batch(self._h, var.data_ptr(), value_assigned.data_ptr(), batch, roff.data_ptr(),
+                                            voff.data_ptr(), gate_base, var_base, zero_var, C.byref(cols), self._stream())
+        if st != 0:
+            raise PgError(st, "pg_is_non_zero_batch")
+        return out, err, nerr
+
+    def scalar_mix_batch(self, v, y, s, a, b, gate_base=0, var_base=0, zero_var=0):
+        """BASELINE config 3, one launch: per item 5 x add_input, is_non_zero(v), conditionally_select_one(y, s),
+        maybe_equal(a, b).  Returns (Columns, result_vars[batch,2], err_mask, err_count, layout)."""
+        batch = v.shape[0]
+        for t in (v, y, s, a, b):
+            self._check_scalars(t, batch)
+        roff, voff, err, lay, nerr = self._error_plan("pg_scalar_mix_plan", v, batch)
+        out = Columns.allocate(lay.n_gates, lay.n_vars, self.device, gate_base, var_base)
+        res = torch.empty((batch, 2), dtype=torch.int64, device=self.device)
+        cols = out.as_c()
+        st = self._lib.pg_scalar_mix_batch(self._h, v.data_ptr(), y.data_ptr(), s.data_ptr(), a.data_ptr(), b.data_ptr(),
+                                           batch, roff.data_ptr(), voff.data_ptr(), gate_base, var_base, zero_var,
+                                           C.byref(cols), res.data_ptr(), self._stream())
+        if st != 0:
+            raise PgError(st, "pg_scalar_mix_batch")
+        return out, res, err, nerr, lay

@@ -1,0 +1,66 @@
+"""CPU: the C-ABI library loads and exports every symbol include/plonk_gadgets_hip.h declares (no compute)."""
+import ctypes as C
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "plonk_gadgets_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from plonk_gadgets_amd import _lib
+    lib = _lib.load()
+    names = declared_functions()
+    assert len(names) >= 28
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    # and the Python binding table covers the header exactly
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_host_scalar_helpers_and_layouts():
+    """host-only entry points: no GPU needed"""
+    import plonk_gadgets_amd as pg
+    from plonk_gadgets_amd import _lib
+    from oracle.model import Q, mont_limbs, num_bits_closest_power_of_two
+    lib = _lib.load()
+    assert lib.pg_build_arch() == b"gfx950"
+    for x in (0, 1, 2, 2**64, 2**254 - 1, Q - 1):
+        assert pg.BlsScalar.from_int(x).limbs() == mont_limbs(x)
+        assert pg.BlsScalar.from_int(x).to_int() == x
+        assert pg.num_bits_closest_power_of_two(pg.BlsScalar.from_int(x)) == num_bits_closest_power_of_two(x)
+    a, b = pg.BlsScalar.from_int(12345), pg.BlsScalar.from_int(Q - 7)
+    assert (a + b).to_int() == 12338 and (a - b).to_int() == 12352 and (a * b).to_int() == (12345 * (Q - 7)) % Q
+    assert (-a).to_int() == Q - 12345
+    # the reference's only pure KAT (src/range.rs:196-203) through the product's own host code
+    assert pg.bits_count(pg.BlsScalar.zero()) == 1 and pg.bits_count(pg.BlsScalar.one()) == 1
+    assert pg.bits_count(pg.BlsScalar.from_u64(3)) == 2 and pg.bits_count(pg.BlsScalar.pow_of_2(128)) == 129
+    lay = _lib.LayoutC()
+    mn, mx = pg.BlsScalar.from_int(0), pg.BlsScalar.from_int(2**254)
+    assert lib.pg_range_check_layout(C.byref(mn.c), C.byref(mx.c), 1 << 20, C.byref(lay)) == 0
+    assert (lay.num_bits, lay.gates_per_item, lay.vars_per_item) == (255, 1031, 1034)
+    assert lay.n_gates == 1031 << 20 and lay.n_vars == 1034 << 20
+    assert lib.pg_max_bound_layout(C.byref(pg.BlsScalar.from_int(200).c), 3, C.byref(lay)) == 0
+    assert (lay.num_bits, lay.gates_per_item, lay.vars_per_item, lay.n_gates) == (9, 23, 271, 69)
+    # a non-reduced "scalar" is rejected, not computed with
+    bad = _lib.Scalar.of([2**64 - 1] * 4)
+    assert lib.pg_range_check_layout(C.byref(mn.c), C.byref(bad), 1, C.byref(lay)) == 2
+    assert b"reduced" in lib.pg_last_error()
+
+
+def test_engine_fails_loudly_without_gpu():
+    import pytest
+    import torch
+    import plonk_gadgets_amd as pg
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        pg.Engine(0)
+    from plonk_gadgets_amd import _lib
+    h = C.c_void_p()
+    assert _lib.load().pg_engine_create(0, C.byref(h)) == 3  # PG_ERR_NO_DEVICE

@@ -1,0 +1,216 @@
+"""GPU parity: max_bound (uniform + ragged), the scalar gadgets and the fused mix vs the CPU oracle, limb for limb."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from plonk_gadgets_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+COLS = ("q_m", "q_l", "q_r", "q_o", "q_c", "w_l", "w_r", "w_o", "var_values")
+Q = synth.Q
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import plonk_gadgets_amd as pg
+    e = pg.Engine(0)
+    yield e
+    e.close()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:0")
+
+
+def assert_cols(got, exp):
+    for k in COLS:
+        a, b = got[k], exp[k]
+        assert a.shape == b.shape, (k, a.shape, b.shape)
+        if not np.array_equal(a, b):
+            bad = np.argwhere(a != b)[0]
+            raise AssertionError(f"{k} differs first at {bad.tolist()}: gpu={a[tuple(bad)]:#x} oracle={b[tuple(bad)]:#x}")
+
+
+def u64(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+# ---- max_bound ------------------------------------------------------------------
+
+@pytest.mark.parametrize("mx,count", [(200, 20), (2**128 - 1, 9), (2**253 + 5, 7), (2, 5), (1, 3), (0, 3)])
+def test_max_bound_uniform(engine, mx, count):
+    import plonk_gadgets_amd as pg
+    from oracle import pyoracle as po
+    inside = [int(v) % max(mx, 1) for v in synth.splitmix64(count, mx % 9973 + 1)]
+    wit = np.concatenate([synth.scalars_from_ints(inside), synth.random_scalars(count, 5),
+                          synth.scalars_from_ints([0, (mx - 1) % Q, mx % Q, Q - 1])])
+    ora = po.max_bound_batch(np.repeat(synth.scalars_from_ints([mx]), len(wit), axis=0), wit)
+    assert ora["satisfied"]
+    cols, res, n = engine.max_bound_batch(pg.BlsScalar.from_int(mx), dev(wit), 3, 5)
+    torch.cuda.synchronize()
+    assert_cols(cols.to_numpy(), ora)
+    assert np.array_equal(u64(res), ora["result_vars"]) and (ora["num_bits"] == n).all()
+
+
+def test_max_bound_ragged_and_golden(engine):
+    from oracle import pyoracle as po
+    g = dict(np.load(os.path.join(GOLD, "max_bound_ref.npz")))
+    cols, res, nb, lay = engine.max_bound_ragged_batch(dev(g["max_range"]), dev(g["witness"]), 3, 5)
+    torch.cuda.synchronize()
+    assert_cols(cols.to_numpy(), g)
+    assert np.array_equal(u64(res), g["result_vars"]) and nb.cpu().numpy().tolist() == g["num_bits"].tolist()
+    # random 253-bit bounds (BASELINE config C4 shape) + the edge bounds 0, 1, 2, q-1 and tile-boundary batch sizes
+    for batch in (1, 15, 16, 17, 70):
+        bounds = [int.from_bytes(synth.splitmix64(4, 100 + i).tobytes(), "little") % 2**253 for i in range(batch)]
+        bounds[:4] = [0, 1, 2, Q - 1][:min(4, batch)]
+        wits = []
+        for i, b in enumerate(bounds):
+            r = int.from_bytes(synth.splitmix64(4, 900 + i).tobytes(), "little")
+            wits.append(r % b if (i % 2 == 0 and b > 0) else r % Q)
+        mr, wt = synth.scalars_from_ints(bounds), synth.scalars_from_ints(wits)
+        ora = po.max_bound_batch(mr, wt)
+        assert ora["satisfied"]
+        cols, res, nb, lay = engine.max_bound_ragged_batch(dev(mr), dev(wt), 3, 5)
+        torch.cuda.synchronize()
+        assert (lay.n_gates, lay.n_vars) == (ora["n_gates"], ora["n_vars"])
+        assert_cols(cols.to_numpy(), ora)
+        assert np.array_equal(u64(res), ora["result_vars"])
+        assert nb.cpu().numpy().astype(np.uint64).tolist() == ora["num_bits"].tolist()
+
+
+# ---- stand-alone scalar gadgets -------------------------------------------------------
+
+def oracle_two_input(fn_name, a_vals, b_vals, allocated: bool):
+    """oracle: add_input all a's, then all b's (existing Variables), then the gadget per item"""
+    from oracle import pyoracle as po
+    c = po.Composer()
+    batch = len(a_vals)
+    a_vars = [c.add_input(x) for x in a_vals]
+    b_vars = [c.add_input(x) for x in b_vals]
+    g0, v0 = c.n, c.num_vars
+    res = []
+    for i in range(batch):
+        if allocated:
+            a = po.AllocatedScalar(a_vars[i], po.fr(a_vals[i]))
+            b = po.AllocatedScalar(b_vars[i], po.fr(b_vals[i]))
+            res.append(int(getattr(c.L, fn_name)(c.c, a, b)))
+        else:
+            res.append(int(getattr(c.L, fn_name)(c.c, a_vars[i], b_vars[i])))
+    assert c.check() == -1
+    return c.export(g0, v0), np.array(res, dtype=np.uint64), g0, v0, a_vars, b_vars
+
+
+def pair_inputs(batch, seed, equal_every=0, bits=False):
+    a = synth.random_scalars(batch, seed)
+    b = synth.random_scalars(batch, seed + 1)
+    if bits:
+        b = synth.scalars_from_ints([int(x) & 1 for x in synth.splitmix64(batch, seed + 2)])
+    if equal_every:
+        b[::equal_every] = a[::equal_every]
+    return a, b
+
+
+@pytest.mark.parametrize("batch", [1, 5, 256, 300])
+def test_maybe_equal_batch(engine, batch):
+    a, b = pair_inputs(batch, 11, equal_every=2)
+    exp, res, g0, v0, av, bv = oracle_two_input("maybe_equal", a, b, True)
+    cols, got = engine.maybe_equal_batch(dev(np.array(av, np.uint64)), dev(a), dev(np.array(bv, np.uint64)), dev(b), g0, v0)
+    torch.cuda.synchronize()
+    assert_cols(cols.to_numpy(), exp)
+    assert np.array_equal(u64(got), res)
+
+
+def test_maybe_equal_reference_cases_golden(engine):
+    g = dict(np.load(os.path.join(GOLD, "maybe_equal_ref.npz")))
+    n = len(g["a"])
+    # golden numbering: allocate(a_i), allocate(b_i), maybe_equal, per item -> inputs interleaved with outputs;
+    # compare per item against a single-item call placed at the same indices
+    for i in range(n):
+        vb = 5 + 5 * i
+        cols, got = engine.maybe_equal_batch(dev(np.array([vb], np.uint64)), dev(g["a"][i:i + 1]),
+                                             dev(np.array([vb + 1], np.uint64)), dev(g["b"][i:i + 1]), 3 + 3 * i, vb + 2)
+        torch.cuda.synchronize()
+        out = cols.to_numpy()
+        for k in ("q_m", "q_l", "q_r", "q_o", "q_c", "w_l", "w_r", "w_o"):
+            assert np.array_equal(out[k], g[k][3 * i:3 * i + 3]), k
+        assert np.array_equal(out["var_values"], g["var_values"][5 * i + 2:5 * i + 5])
+        assert int(u64(got)[0]) == int(g["result_vars"][i])
+        assert synth.to_int(out["var_values"][2]) == int(g["expected"][i])
+
+
+@pytest.mark.parametrize("batch", [1, 7, 256, 513])
+def test_select_one_and_zero_batch(engine, batch):
+    y, s = pair_inputs(batch, 21, bits=True)
+    exp, res, g0, v0, yv, sv = oracle_two_input("conditionally_select_one", y, s, False)
+    cols, got = engine.conditionally_select_one_batch(dev(np.array(yv, np.uint64)), dev(y), dev(np.array(sv, np.uint64)),
+                                                      dev(s), g0, v0)
+    torch.cuda.synchronize()
+    out = cols.to_numpy()
+    assert_cols(out, exp)
+    assert np.array_equal(u64(got), res)
+    # semantics: selector 1 -> y, selector 0 -> 1 (tests/scalar_gadgets_tests.rs:142-177)
+    for i in (0, batch - 1):
+        sel = synth.to_int(s[i])
+        assert out["var_values"][4 * i + 3].tolist() == (y[i].tolist() if sel else synth.mont(1))
+    exp, res, g0, v0, xv, sv = oracle_two_input("conditionally_select_zero", y, s, False)
+    cols, got = engine.conditionally_select_zero_batch(dev(np.array(xv, np.uint64)), dev(y), dev(np.array(sv, np.uint64)),
+                                                       dev(s), g0, v0)
+    torch.cuda.synchronize()
+    assert_cols(cols.to_numpy(), exp)
+    assert np.array_equal(u64(got), res)
+
+
+@pytest.mark.parametrize("batch,zeros", [(1, []), (1, [0]), (9, [3]), (300, [0, 1, 255, 256, 299]), (64, list(range(64)))])
+def test_is_non_zero_batch(engine, batch, zeros):
+    from oracle import pyoracle as po
+    vals = synth.random_scalars(batch, 31)
+    vals[zeros] = 0
+    c = po.Composer()
+    vars_ = [c.add_input(v) for v in vals]
+    g0, v0 = c.n, c.num_vars
+    errs = [int(c.L.is_non_zero(c.c, vars_[i], po.fr(vals[i]))) for i in range(batch)]
+    assert c.check() == -1
+    exp = c.export(g0, v0)
+    cols, err, nerr = engine.is_non_zero_batch(dev(np.array(vars_, np.uint64)), dev(vals), g0, v0, zero_var=0)
+    torch.cuda.synchronize()
+    assert_cols(cols.to_numpy(), exp)
+    assert err.cpu().numpy().tolist() == errs and nerr == len(zeros)
+
+
+# ---- the fused mix (BASELINE config C3) -------------------------------------------------
+
+def mix_inputs(batch, seed, zeros=()):
+    v = synth.random_scalars(batch, seed)
+    v[list(zeros)] = 0
+    y = synth.random_scalars(batch, seed + 1)
+    s = synth.scalars_from_ints([int(x) & 1 for x in synth.splitmix64(batch, seed + 2)])
+    a = synth.random_scalars(batch, seed + 3)
+    b = synth.random_scalars(batch, seed + 4)
+    b[::2] = a[::2]
+    return v, y, s, a, b
+
+
+@pytest.mark.parametrize("batch,zeros", [(1, ()), (4, (2,)), (128, ()), (129, (0, 127, 128)), (1000, (5, 500, 999))])
+def test_scalar_mix_batch(engine, batch, zeros):
+    from oracle import pyoracle as po
+    v, y, s, a, b = mix_inputs(batch, 41, zeros)
+    ora = po.scalar_mix_batch(v, y, s, a, b)
+    assert ora["satisfied"]
+    cols, res, err, nerr, lay = engine.scalar_mix_batch(dev(v), dev(y), dev(s), dev(a), dev(b), 3, 5, zero_var=0)
+    torch.cuda.synchronize()
+    assert (lay.n_gates, lay.n_vars) == (ora["n_gates"], ora["n_vars"])
+    assert_cols(cols.to_numpy(), ora)
+    assert np.array_equal(u64(res), ora["result_vars"])
+    assert err.cpu().numpy().tolist() == ora["err_mask"].tolist() and nerr == len(zeros)
+
+
+def test_scalar_mix_golden(engine):
+    g = dict(np.load(os.path.join(GOLD, "scalar_mix.npz")))
+    cols, res, err, nerr, lay = engine.scalar_mix_batch(*(dev(g[k]) for k in "vysab"), 3, 5, zero_var=0)
+    torch.cuda.synchronize()
+    assert_cols(cols.to_numpy(), g)
+    assert np.array_equal(u64(res), g["result_vars"]) and err.cpu().numpy().tolist() == g["err_mask"].tolist()
