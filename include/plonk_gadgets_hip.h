@@ -180,6 +180,12 @@ pg_status pg_scalar_mix_batch(pg_engine *e, const pg_scalar *d_v, const pg_scala
                               const uint64_t *d_var_off, uint64_t gate_base, uint64_t var_base, pg_variable zero_var,
                               const pg_columns *out, pg_variable *d_result_vars /* may be NULL */, void *stream);
 
+/* ---- diagnostics ----------------------------------------------------------
+ * pg_fill_bytes: a bare streaming fill (16 B per lane, same store form and grid shape as the emitters) used by
+ * bench.py to measure the practical HBM write ceiling on the same box. */
+pg_status pg_fill_bytes(pg_engine *e, void *d_dst /* 16-byte aligned */, uint64_t bytes /* multiple of 16 */,
+                        uint64_t pattern, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,7 @@ SIGNATURES = {
                                        C.c_uint64, C.c_uint64, C.c_uint64, _P(ColumnsC), C.c_void_p]),
     "pg_scalar_mix_plan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      _P(LayoutC), _P(C.c_uint64), C.c_void_p]),
+    "pg_fill_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "pg_scalar_mix_batch": (C.c_int, [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                                           C.c_uint64, _P(ColumnsC), C.c_void_p, C.c_void_p]),
 }

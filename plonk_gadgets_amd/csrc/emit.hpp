@@ -222,6 +222,15 @@ __global__ __launch_bounds__(kThreads) void emit_kernel(const typename GD::Args 
     }
 }
 
+// bare streaming fill: the practical write ceiling the emitters are compared with
+__global__ __launch_bounds__(kThreads) void fill_kernel(uint4 *dst, uint64_t n16, uint64_t pattern) {
+    const uint4 v = make_uint4((uint32_t)pattern, (uint32_t)(pattern >> 32), (uint32_t)~pattern, (uint32_t)(~pattern >> 32));
+    // each workgroup walks contiguous 64 KiB pieces, grid-strided
+    constexpr uint64_t kPiece = 4096;  // uint4 per piece
+    for (uint64_t base = (uint64_t)blockIdx.x * kPiece; base < n16; base += (uint64_t)gridDim.x * kPiece)
+        for (uint64_t i = base + threadIdx.x; i < base + kPiece && i < n16; i += kThreads) store16(dst + i, v);
+}
+
 // ---- exclusive prefix sums for ragged batches ---------------------------
 // counts[i] (rows, vars of item i) -> off[i], off[batch] = total.  Three small
 // kernels: per-block sums, scan of the block sums (one block), final scan.

@@ -268,3 +268,11 @@ class Engine:
         if st != 0:
             raise PgError(st, "pg_scalar_mix_batch")
         return out, res, err, nerr, lay
+
+    # ---- diagnostics -----------------------------------------------------------------
+    def fill_bytes(self, dst: torch.Tensor, pattern: int = 0x0123456789ABCDEF):
+        """bare 16-B-per-lane streaming fill of `dst` (the write ceiling bench.py quotes beside the emitters)"""
+        nbytes = dst.numel() * dst.element_size()
+        st = self._lib.pg_fill_bytes(self._h, dst.data_ptr(), nbytes, pattern, self._stream())
+        if st != 0:
+            raise PgError(st, "pg_fill_bytes")

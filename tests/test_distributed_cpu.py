@@ -1,0 +1,158 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercise the sharding arithmetic, the per-column all-gather and
+the packed-chunk GatherPipeline.  The HIP engine cannot run here (no GPU), so a stand-in engine that answers with
+the CPU oracle's rows takes its place -- what is under test is plonk_gadgets_amd.distributed, not the kernels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from plonk_gadgets_amd import synth
+
+COLS = ("q_m", "q_l", "q_r", "q_o", "q_c", "w_l", "w_r", "w_o", "var_values")
+MN, MX = 50_000, 250_000
+
+
+class OracleEngine:
+    """test stand-in with Engine's range_check interface, rows from the oracle (relocated to the requested bases)"""
+    device = torch.device("cpu")
+
+    def range_check_layout(self, mn, mx, batch):
+        import plonk_gadgets_amd as pg
+        from plonk_gadgets_amd import _lib
+        import ctypes as C
+        lay = _lib.LayoutC()
+        assert _lib.load().pg_range_check_layout(C.byref(mn.c), C.byref(mx.c), batch, C.byref(lay)) == 0
+        return pg.Layout(lay.num_bits, lay.gates_per_item, lay.vars_per_item, lay.n_gates, lay.n_vars)
+
+    def range_check_batch(self, mn, mx, witness, gate_base=0, var_base=0, out=None, result_vars=None):
+        import plonk_gadgets_amd as pg
+        from oracle import pyoracle as po
+        ora = po.range_check_batch(mn.limbs(), mx.limbs(), witness.numpy().view(np.uint64))
+        if out is None:
+            out = pg.Columns.allocate(ora["n_gates"], ora["n_vars"], "cpu", gate_base, var_base)
+        shift = np.uint64((var_base - 5) % 2**64)
+        for k in COLS:
+            a = ora[k] + shift if k.startswith("w_") else ora[k]
+            getattr(out, k).copy_(torch.from_numpy(a.view(np.int64)))
+        res = torch.from_numpy((ora["result_vars"] + shift).view(np.int64))
+        if result_vars is not None:
+            result_vars.copy_(res)
+            res = result_vars
+        return out, res
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def witnesses(total):
+    inside = synth.scalars_from_ints([MN + int(v) % (MX - MN) for v in synth.splitmix64(total // 2, 3)])
+    return np.ascontiguousarray(np.concatenate([inside, synth.random_scalars(total - total // 2, 4)]))
+
+
+def worker(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import plonk_gadgets_amd as pg
+        from plonk_gadgets_amd import distributed as pd
+        eng = OracleEngine()
+        mn, mx = pg.BlsScalar.from_int(MN), pg.BlsScalar.from_int(MX)
+        wit = witnesses(total)
+        lo, hi = pd.shard_range(total, rank, world)
+        local = torch.from_numpy(wit[lo:hi].view(np.int64))
+        cols, res, info = pd.range_check_sharded(eng, mn, mx, local, total, gate_base=3, var_base=5)
+        lay = eng.range_check_layout(mn, mx, 1)
+        assert (info.lo, info.hi) == (lo, hi)
+        assert info.gate_base == 3 + lo * lay.gates_per_item and info.var_base == 5 + lo * lay.vars_per_item
+        ranges = [pd.shard_range(total, r, world) for r in range(world)]
+        full, full_res = pd.gather_columns(cols, res, [(b - a) * lay.gates_per_item for a, b in ranges],
+                                           [(b - a) * lay.vars_per_item for a, b in ranges])
+        out = {k: getattr(full, k).numpy().view(np.uint64).copy() for k in COLS}
+        out["result_vars"] = full_res.numpy().view(np.uint64).copy()
+        # packed pipeline: equal shards of 4 items per rank, chunk 2 -> 2 chunks, one collective each
+        per_rank, chunk = 4, 2
+        wl = torch.from_numpy(wit[rank * per_rank:(rank + 1) * per_rank].view(np.int64))
+        pipe = pd.GatherPipeline(eng, mn, mx, chunk)
+        seen = []
+        pipe.run(wl, per_rank, 3, 5, consume=lambda g, k: seen.append((k, g.clone())))
+        out["pipe"] = [(k, g.numpy().view(np.uint64).copy()) for k, g in seen]
+        out["pipe_lay"] = (pipe.lay.n_gates, pipe.lay.n_vars)
+        q.put((rank, out))
+    except Exception as e:  # surface the failure instead of leaving the parent waiting on the queue
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [8, 9])
+def test_sharded_gather_matches_single_process(total):
+    from oracle import pyoracle as po
+    from plonk_gadgets_amd import distributed as pd
+    world, port = 2, free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for r in got:
+        assert "error" not in got[r], got[r]["error"]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    wit = witnesses(total)
+    ora = po.range_check_batch(synth.mont(MN), synth.mont(MX), wit)
+    for r in range(world):
+        for k in COLS + ("result_vars",):
+            assert np.array_equal(got[r][k], ora[k]), (r, k)
+    # packed chunks: gathered[src] of chunk k == the oracle rows of items src*4 + 2k .. +2, at global numbering
+    G, V = 4 * ora["num_bits"] + 11, 2 * ora["num_bits"] + 524
+    ng, nv = got[0]["pipe_lay"]
+    off, sizes, words = pd.packed_layout(ng, nv)
+    for r in range(world):
+        assert [k for k, _ in got[r]["pipe"]] == [0, 1]
+        for k, g in got[r]["pipe"]:
+            assert g.shape == (world, words)
+            for src in range(world):
+                first = src * 4 + k * 2
+                for name in COLS:
+                    sec = g[src, off[name]:off[name] + sizes[name]]
+                    if name == "var_values":
+                        exp = ora[name][first * V:(first + 2) * V].reshape(-1)
+                    elif name.startswith("w_"):
+                        exp = ora[name][first * G:(first + 2) * G]
+                    else:
+                        exp = ora[name][first * G:(first + 2) * G].reshape(-1)
+                    assert np.array_equal(sec, exp), (r, k, src, name)
+
+
+def test_shard_range_partitions():
+    from plonk_gadgets_amd import distributed as pd
+    for total in (0, 1, 7, 8, 1 << 20, (1 << 23) + 5):
+        for world in (1, 2, 3, 8):
+            rs = [pd.shard_range(total, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == total
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in rs) - min(b - a for a, b in rs) <= 1
+
+
+def test_packed_layout_alignment():
+    from plonk_gadgets_amd import distributed as pd
+    for ng, nv in ((87, 562), (1031, 1034), (2, 3)):
+        off, sizes, total = pd.packed_layout(ng, nv)
+        assert all(o % 2 == 0 for o in off.values()) and total % 2 == 0  # 16-byte aligned sections (int64 words)
+        flat = torch.zeros(total, dtype=torch.int64)
+        cols = pd.columns_in(flat, ng, nv)
+        assert cols.q_m.shape == (ng, 4) and cols.w_o.shape == (ng,) and cols.var_values.shape == (nv, 4)
+        assert cols.var_values.data_ptr() - flat.data_ptr() == off["var_values"] * 8
