@@ -89,6 +89,9 @@ struct pg_engine {
     uint64_t *d_blk_rows = nullptr, *d_blk_vars = nullptr;
     uint32_t *d_err_count = nullptr;
     uint64_t scratch_items = 0;
+    // scratch of the inversion pre-pass (grow-only): inverses and running products, 32 B per element each
+    uint4 *d_inv = nullptr, *d_prefix = nullptr;
+    uint64_t inv_elems = 0;
 };
 
 namespace {
@@ -150,11 +153,39 @@ pg::EmitOut make_out(const pg_columns *c, uint64_t batch, int W, uint64_t gate_b
     return O;
 }
 
+pg_status ensure_inv_scratch(pg_engine *e, uint64_t elems) {
+    if (elems <= e->inv_elems) return PG_OK;
+    PG_HIP_TRY(hipSetDevice(e->device));
+    if (e->d_inv) { (void)hipFree(e->d_inv); e->d_inv = nullptr; }
+    if (e->d_prefix) { (void)hipFree(e->d_prefix); e->d_prefix = nullptr; }
+    e->inv_elems = 0;
+    PG_HIP_TRY(hipMalloc(&e->d_inv, elems * 2 * sizeof(uint4)));
+    PG_HIP_TRY(hipMalloc(&e->d_prefix, elems * 2 * sizeof(uint4)));
+    e->inv_elems = elems;
+    return PG_OK;
+}
+
 template <class GD>
-pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, uint64_t batch, uint64_t gate_base,
+pg_status launch(pg_engine *e, const typename GD::Args &A_in, const pg_columns *c, uint64_t batch, uint64_t gate_base,
                  uint64_t var_base, uint64_t zero_var, const uint64_t *row_off, const uint64_t *var_off, void *stream) {
     if ((batch + GD::W - 1) / GD::W > 0xffffffffull) return fail(PG_ERR_INVALID_ARGUMENT, "batch too large for one call");
     PG_HIP_TRY(hipSetDevice(e->device));
+    typename GD::Args A = A_in;
+    if constexpr (GD::kInv > 0) {
+        // inversion pre-pass: all of the call's inverses by Montgomery's trick (invert.hpp)
+        const uint64_t elems = batch * GD::kInv;
+        PG_TRY(ensure_inv_scratch(e, elems));
+        const uint64_t lanes_wanted = (uint64_t)e->num_cus * 4 * 64;  // one wave per SIMD
+        uint64_t per_lane = (elems + lanes_wanted - 1) / lanes_wanted;
+        if (per_lane < 1) per_lane = 1;
+        if (per_lane > 32) per_lane = 32;
+        const uint64_t lanes = (elems + per_lane - 1) / per_lane;
+        const uint32_t blocks = (uint32_t)((lanes + pg::kThreads - 1) / pg::kThreads);
+        hipLaunchKernelGGL(pg::batch_invert_kernel<GD>, dim3(blocks), dim3(pg::kThreads), 0,
+                           static_cast<hipStream_t>(stream), A, elems, (uint32_t)per_lane, e->d_inv, e->d_prefix);
+        PG_HIP_TRY(hipGetLastError());
+        A.inv = e->d_inv;
+    }
     const pg::EmitOut O = make_out(c, batch, GD::W, gate_base, var_base, zero_var, row_off, var_off);
     const uint32_t max_blocks = (uint32_t)e->num_cus * 8;
     const uint32_t grid = O.tiles < max_blocks ? O.tiles : max_blocks;
@@ -176,6 +207,7 @@ pg_status scalar_args(const pg_variable *a_var, const pg_scalar *a_val, const pg
     A->b_val = reinterpret_cast<const uint4 *>(b_val);
     A->result_vars = res;
     A->err_mask = nullptr;
+    A->inv = nullptr;
     return PG_OK;
 }
 
@@ -263,6 +295,8 @@ void pg_engine_destroy(pg_engine *e) {
     if (e->d_blk_rows) (void)hipFree(e->d_blk_rows);
     if (e->d_blk_vars) (void)hipFree(e->d_blk_vars);
     if (e->d_err_count) (void)hipFree(e->d_err_count);
+    if (e->d_inv) (void)hipFree(e->d_inv);
+    if (e->d_prefix) (void)hipFree(e->d_prefix);
     delete e;
 }
 
@@ -314,7 +348,7 @@ pg_status pg_range_check_batch(pg_engine *e, const pg_scalar *min_range, const p
     PG_TRY(check_u64s(d_result_vars, "d_result_vars", true));
     PG_TRY(check_columns(out));
     if (lay.num_bits < 2 || lay.num_bits > 255) return fail(PG_ERR_INVALID_ARGUMENT, "ladder length out of range");
-    pg::RangeCheckGD::Args A;
+    pg::RangeCheckGD::Args A{};
     A.min_range = to_fr(min_range);
     A.max_range = to_fr(max_range);
     A.n = (uint32_t)lay.num_bits;
@@ -473,7 +507,7 @@ pg_status pg_scalar_mix_batch(pg_engine *e, const pg_scalar *d_v, const pg_scala
     PG_TRY(check_u64s(d_var_off, "d_var_off"));
     PG_TRY(check_u64s(d_result_vars, "d_result_vars", true));
     PG_TRY(check_columns(out));
-    pg::ScalarMixArgs A;
+    pg::ScalarMixArgs A{};
     A.v = reinterpret_cast<const uint4 *>(d_v);
     A.y = reinterpret_cast<const uint4 *>(d_y);
     A.s = reinterpret_cast<const uint4 *>(d_s);

@@ -23,6 +23,7 @@
 #pragma once
 
 #include "emit.hpp"
+#include "invert.hpp"
 
 namespace pg {
 
@@ -33,20 +34,20 @@ struct alignas(16) BoundRec {
     Fr Z;   // U^-1 or 0
 };
 
-// per-item arithmetic of one bound block
-__device__ __forceinline__ uint32_t bound_item(const Fr &Tm, uint32_t n, BoundRec &b) {
-    const Fr Tc = fr_from_mont(Tm);            // scalar_to_bits -> to_bytes, range.rs:163
-    const bool hi = raw_has_high_bits(Tc, n);  // T does not fit n bits
-    Fr U = fr_zero(), Z = fr_zero();
-    if (hi) {
-        U = fr_sub(fr_to_mont(raw_low_bits(Tc, n)), Tm);  // accumulator - witness, scalar.rs:121
-        Z = fr_invert_or_zero(U);                         // scalar.rs:122
-    }
+// u = accumulator - witness (scalar.rs:121) of a bound block: A_n - T with A_n = mont(T mod 2^n); 0 when T fits n bits
+__device__ __forceinline__ Fr bound_u(const Fr &Tm, const Fr &Tc, uint32_t n) {
+    if (!raw_has_high_bits(Tc, n)) return fr_zero();
+    return fr_sub(fr_to_mont(raw_low_bits(Tc, n)), Tm);
+}
+
+// per-item arithmetic of one bound block; Z = u^-1 or 0 comes from the inversion pre-pass (invert.hpp)
+__device__ __forceinline__ uint32_t bound_item(const Fr &Tm, uint32_t n, const Fr &Z, BoundRec &b) {
+    const Fr Tc = fr_from_mont(Tm);  // scalar_to_bits -> to_bytes, range.rs:163
     b.Tm = Tm;
     b.Tc = Tc;
-    b.U = U;
-    b.Z = Z;
-    return hi ? 0u : 1u;  // y = 1 - u z
+    b.U = bound_u(Tm, Tc, n);
+    b.Z = Z;                         // scalar.rs:122
+    return fr_is_zero(b.U) ? 1u : 0u;  // y = 1 - u z
 }
 
 // selector table ids of block row jj; is_min selects the min_bound flavour of row 0
@@ -126,7 +127,17 @@ struct RangeCheckGD {
         const uint4 *witness;
         uint64_t *result_vars;
         const uint4 *pow2;
+        const uint4 *inv;  // [batch][2] from the inversion pre-pass
     };
+    static constexpr int kInv = 2;
+    // element e of item: u of the max block (e = 0) / min block (e = 1)
+    __device__ static Fr inv_element(const Args &A, uint64_t item, uint32_t e) {
+        FrVec x;
+        x.v[0] = A.witness[item * 2];
+        x.v[1] = A.witness[item * 2 + 1];
+        const Fr Tm = e == 0 ? fr_sub(fr_sub(A.max_range, fr_one()), x.f) : fr_sub(x.f, A.min_range);
+        return bound_u(Tm, fr_from_mont(Tm), A.n);
+    }
     struct alignas(16) ItemRec {
         Fr x;
         BoundRec b[2];
@@ -156,8 +167,11 @@ struct RangeCheckGD {
         x.v[1] = A.witness[item * 2 + 1];
         R.x = x.f;
         // T = (max-1) - x  (range.rs:102)   |   T = x - min  (range.rs:69)
-        R.y[0] = bound_item(fr_sub(lds_fr(table, T_QC_A), x.f), A.n, R.b[0]);
-        R.y[1] = bound_item(fr_add(x.f, lds_fr(table, T_QC_B)), A.n, R.b[1]);
+        FrVec z0, z1;
+        z0.v[0] = A.inv[item * 4]; z0.v[1] = A.inv[item * 4 + 1];
+        z1.v[0] = A.inv[item * 4 + 2]; z1.v[1] = A.inv[item * 4 + 3];
+        R.y[0] = bound_item(fr_sub(lds_fr(table, T_QC_A), x.f), A.n, z0.f, R.b[0]);
+        R.y[1] = bound_item(fr_add(x.f, lds_fr(table, T_QC_B)), A.n, z1.f, R.b[1]);
         const uint64_t V = vars_per_item(A);
         if (A.result_vars) A.result_vars[item] = O.var_base + item * V + (V - 1);
     }
@@ -212,7 +226,23 @@ struct MaxBoundGD {
         const uint4 *witness;
         uint64_t *result_vars;
         const uint4 *pow2;
+        const uint4 *inv;  // [batch] from the inversion pre-pass
     };
+    static constexpr int kInv = 1;
+    __device__ static Fr inv_element(const Args &A, uint64_t item, uint32_t) {
+        FrVec x, m;
+        x.v[0] = A.witness[item * 2];
+        x.v[1] = A.witness[item * 2 + 1];
+        uint32_t n = A.n;
+        m.f = A.max_range;
+        if constexpr (RAGGED) {
+            m.v[0] = A.max_range_v[item * 2];
+            m.v[1] = A.max_range_v[item * 2 + 1];
+            n = A.num_bits_v[item];
+        }
+        const Fr Tm = fr_sub(fr_sub(m.f, fr_one()), x.f);
+        return bound_u(Tm, fr_from_mont(Tm), n);
+    }
     struct alignas(16) ItemRec {
         Fr x;
         Fr qc;  // mont(max - 1) of this item (ragged: a per-item selector constant)
@@ -257,7 +287,10 @@ struct MaxBoundGD {
         }
         R.qc = qc;
         R.n = n;
-        R.y = bound_item(fr_sub(qc, x.f), n, R.b);  // range.rs:102
+        FrVec z;
+        z.v[0] = A.inv[item * 2];
+        z.v[1] = A.inv[item * 2 + 1];
+        R.y = bound_item(fr_sub(qc, x.f), n, z.f, R.b);  // range.rs:102
         if (A.result_vars) {
             const uint64_t first = RAGGED ? O.var_off[item] : item * (uint64_t)(n + 262);
             A.result_vars[item] = O.var_base + first + (n + 261);  // Y is the item's last variable

@@ -23,6 +23,7 @@
 #pragma once
 
 #include "emit.hpp"
+#include "invert.hpp"
 
 namespace pg {
 
@@ -82,6 +83,7 @@ struct ScalarArgs {
     const uint4 *a_val, *b_val;
     uint64_t *result_vars;
     uint8_t *err_mask;  // is_non_zero only
+    const uint4 *inv;   // [batch] from the inversion pre-pass (maybe_equal, is_non_zero)
 };
 
 // ---- conditionally_select_zero ------------------------------------------------
@@ -89,6 +91,7 @@ struct SelectZeroGD {
     using Args = ScalarArgs;
     struct alignas(16) ItemRec { Fr out; };
     static constexpr int W = 256;
+    static constexpr int kInv = 0;
     static constexpr bool kRagged = false, kRecInRows = false, kUsePow2 = false;
     __device__ static uint32_t rows_per_item(const Args &) { return 1; }
     __device__ static uint32_t vars_per_item(const Args &) { return 1; }
@@ -116,6 +119,7 @@ struct SelectOneGD {
     using Args = ScalarArgs;
     struct alignas(16) ItemRec { Fr sy, oms; };
     static constexpr int W = 256;
+    static constexpr int kInv = 0;
     static constexpr bool kRagged = false, kRecInRows = false, kUsePow2 = false;
     __device__ static uint32_t rows_per_item(const Args &) { return 4; }
     __device__ static uint32_t vars_per_item(const Args &) { return 4; }
@@ -150,13 +154,17 @@ struct MaybeEqualGD {
     using Args = ScalarArgs;
     struct alignas(16) ItemRec { Fr u, z; };
     static constexpr int W = 256;
+    static constexpr int kInv = 1;
+    __device__ static Fr inv_element(const Args &A, uint64_t item, uint32_t) {
+        return fr_sub(load_fr(A.a_val, item), load_fr(A.b_val, item));  // scalar.rs:121
+    }
     static constexpr bool kRagged = false, kRecInRows = false, kUsePow2 = false;
     __device__ static uint32_t rows_per_item(const Args &) { return 3; }
     __device__ static uint32_t vars_per_item(const Args &) { return 3; }
     __device__ static void fill_table(const Args &, uint4 *, uint32_t) {}
     __device__ static void item(const Args &A, const EmitOut &O, uint64_t item, const uint4 *, ItemRec &R) {
         R.u = fr_sub(load_fr(A.a_val, item), load_fr(A.b_val, item));
-        R.z = fr_is_zero(R.u) ? fr_zero() : fr_invert_or_zero(R.u);
+        R.z = load_fr(A.inv, item);  // scalar.rs:122
         if (A.result_vars) A.result_vars[item] = O.var_base + item * 3 + 2;
     }
     __device__ static void selectors(const Args &, const ItemRec &, uint32_t j, const uint4 *table, uint32_t h, uint4 out[5]) {
@@ -182,11 +190,13 @@ struct IsNonZeroGD {
     using Args = ScalarArgs;
     struct alignas(16) ItemRec { Fr value, inv; };
     static constexpr int W = 256;
+    static constexpr int kInv = 1;
+    __device__ static Fr inv_element(const Args &A, uint64_t item, uint32_t) { return load_fr(A.b_val, item); }  // scalar.rs:73
     static constexpr bool kRagged = true, kRecInRows = false, kUsePow2 = false;
     __device__ static void fill_table(const Args &, uint4 *, uint32_t) {}
     __device__ static void item(const Args &A, const EmitOut &, uint64_t item, const uint4 *, ItemRec &R) {
         R.value = load_fr(A.b_val, item);
-        R.inv = fr_invert_or_zero(R.value);
+        R.inv = load_fr(A.inv, item);
     }
     __device__ static void selectors(const Args &, const ItemRec &, uint32_t j, const uint4 *table, uint32_t h, uint4 out[5]) {
         RowOut r;
@@ -224,6 +234,7 @@ __global__ __launch_bounds__(kThreads) void is_non_zero_plan_kernel(const uint4 
 struct ScalarMixArgs {
     const uint4 *v, *y, *s, *a, *b;
     uint64_t *result_vars;  // [batch][2]: select_one's output, maybe_equal's output
+    const uint4 *inv;       // [batch][2] from the inversion pre-pass: v^-1, (a-b)^-1
 };
 
 struct ScalarMixGD {
@@ -233,6 +244,10 @@ struct ScalarMixGD {
         uint32_t err, pad[3];
     };
     static constexpr int W = 128;
+    static constexpr int kInv = 2;
+    __device__ static Fr inv_element(const Args &A, uint64_t item, uint32_t e) {
+        return e == 0 ? load_fr(A.v, item) : fr_sub(load_fr(A.a, item), load_fr(A.b, item));
+    }
     static constexpr bool kRagged = true, kRecInRows = true, kUsePow2 = false;
     __device__ static void fill_table(const Args &, uint4 *, uint32_t) {}
     __device__ static void item(const Args &A, const EmitOut &O, uint64_t item, const uint4 *, ItemRec &R) {
@@ -242,9 +257,8 @@ struct ScalarMixGD {
         R.a = load_fr(A.a, item);
         R.b = load_fr(A.b, item);
         R.err = fr_is_zero(R.v) ? 1u : 0u;
-        R.inv = fr_invert_or_zero(R.v);
-        const Fr u = fr_sub(R.a, R.b);
-        R.z = fr_is_zero(u) ? fr_zero() : fr_invert_or_zero(u);
+        R.inv = load_fr(A.inv, 2 * item);
+        R.z = load_fr(A.inv, 2 * item + 1);
         if (A.result_vars) {
             const uint64_t vb = O.var_base + O.var_off[item];
             const uint64_t nz = R.err ? 1 : 3;
