@@ -180,6 +180,82 @@ pg_status pg_scalar_mix_batch(pg_engine *e, const pg_scalar *d_v, const pg_scala
                               const uint64_t *d_var_off, uint64_t gate_base, uint64_t var_base, pg_variable zero_var,
                               const pg_columns *out, pg_variable *d_result_vars /* may be NULL */, void *stream);
 
+/* ---- pg_composer: the composer-gate API surface, device resident ----------------------------
+ * The counterpart of the slice of dusk-plonk's `StandardComposer` the reference's gadgets call.  Columns and the
+ * variable table live in HBM with fixed capacities chosen at creation (PG_ERR_CAPACITY when an append does not fit);
+ * every call appends on the composer's stream and returns immediately -- Variables are numbered on the host, their
+ * values exist only on the device.  With the single-gadget entry points below (the reference's exact signatures,
+ * argument order and error behaviour) host code written against the reference reads the same:
+ *
+ *     reference (tests/range_gadgets_tests.rs:36-43)                 this library
+ *     let w = AllocatedScalar::allocate(composer, witness);          pg_allocated_scalar_allocate(c, &witness, &w);
+ *     let r = range_check(composer, min, max, w);                    pg_range_check(c, &min, &max, &w, &r);
+ *     composer.constrain_to_constant(r, outcome, None);              pg_composer_constrain_to_constant(c, r, &outcome, NULL);
+ */
+typedef struct pg_composer pg_composer;
+
+/* StandardComposer::new() [with_dummy = 1]: zero_var = Variable(0) + its constant row, then the two dummy
+ * constraints (variables 1..4 = 6, 1, 7, -20): 3 rows, 5 variables.  with_dummy = 0 stops after zero_var. */
+pg_status pg_composer_create(pg_engine *e, uint64_t gate_capacity, uint64_t var_capacity, int with_dummy, void *stream,
+                             pg_composer **out);
+void pg_composer_destroy(pg_composer *c);
+uint64_t pg_composer_circuit_size(const pg_composer *c);  /* StandardComposer::circuit_size(): rows so far */
+uint64_t pg_composer_num_variables(const pg_composer *c);
+pg_variable pg_composer_zero_var(const pg_composer *c);
+/* device pointers to the live columns (row 0 = gate 0, var_values[0] = Variable(0)) */
+pg_status pg_composer_columns(const pg_composer *c, pg_columns *out);
+pg_status pg_composer_sync(pg_composer *c);
+
+/* composer calls used by the gadgets (same argument order as dusk-plonk 0.8; `pi` may be NULL = None) */
+pg_status pg_composer_add_input(pg_composer *c, const pg_scalar *s, pg_variable *out);
+pg_status pg_composer_add_witness_to_circuit_description(pg_composer *c, const pg_scalar *value, pg_variable *out);
+pg_status pg_composer_constrain_to_constant(pg_composer *c, pg_variable a, const pg_scalar *constant, const pg_scalar *pi);
+pg_status pg_composer_assert_equal(pg_composer *c, pg_variable a, pg_variable b);
+pg_status pg_composer_poly_gate(pg_composer *c, pg_variable a, pg_variable b, pg_variable o, const pg_scalar *q_m,
+                                const pg_scalar *q_l, const pg_scalar *q_r, const pg_scalar *q_o, const pg_scalar *q_c,
+                                const pg_scalar *pi);
+pg_status pg_composer_add(pg_composer *c, const pg_scalar *q_l, pg_variable a, const pg_scalar *q_r, pg_variable b,
+                          const pg_scalar *q_c, const pg_scalar *pi, pg_variable *out);
+pg_status pg_composer_mul(pg_composer *c, const pg_scalar *q_m, pg_variable a, pg_variable b, const pg_scalar *q_c,
+                          const pg_scalar *pi, pg_variable *out);
+pg_status pg_composer_mul_gate(pg_composer *c, pg_variable a, pg_variable b, pg_variable o, const pg_scalar *q_m,
+                               const pg_scalar *q_o, const pg_scalar *q_c, const pg_scalar *pi);
+pg_status pg_composer_boolean_gate(pg_composer *c, pg_variable a);
+
+/* the reference's public API, one call = one gadget (src/lib.rs:42-45) */
+pg_status pg_allocated_scalar_allocate(pg_composer *c, const pg_scalar *scalar, pg_allocated_scalar *out); /* src/allocated_scalar.rs:27 */
+pg_status pg_range_check(pg_composer *c, const pg_scalar *min_range, const pg_scalar *max_range,
+                         const pg_allocated_scalar *witness, pg_variable *out);                           /* src/range.rs:27-43 */
+pg_status pg_max_bound(pg_composer *c, const pg_scalar *max_range, const pg_allocated_scalar *witness, pg_variable *out,
+                       uint64_t *num_bits);                                                               /* src/range.rs:82-113 */
+pg_status pg_conditionally_select_zero(pg_composer *c, pg_variable x, pg_variable select, pg_variable *out); /* src/scalar.rs:21-27 */
+pg_status pg_conditionally_select_one(pg_composer *c, pg_variable y, pg_variable selector, pg_variable *out); /* src/scalar.rs:36-59 */
+/* PG_ERR_NON_EXISTING_INVERSE after the first variable + row were appended, like the reference (src/scalar.rs:69-79) */
+pg_status pg_is_non_zero(pg_composer *c, pg_variable var, const pg_scalar *value_assigned);              /* src/scalar.rs:63-97 */
+pg_status pg_maybe_equal(pg_composer *c, const pg_allocated_scalar *a, const pg_allocated_scalar *b, pg_variable *out); /* src/scalar.rs:105-140 */
+
+/* batched appends: the loop  for w in d_witness { allocate; range_check }  emitted at the composer's end */
+pg_status pg_composer_range_check_batch(pg_composer *c, const pg_scalar *min_range, const pg_scalar *max_range,
+                                        const pg_scalar *d_witness, uint64_t batch, pg_variable *d_result_vars);
+
+/* read-back and checks */
+pg_status pg_composer_read_value(pg_composer *c, pg_variable v, pg_scalar *out); /* synchronises */
+/* every row satisfies q_m a b + q_l a + q_r b + q_o c + q_4 d + q_c + PI = 0?  *first_bad = -1 or the first failing row */
+pg_status pg_composer_check(pg_composer *c, int64_t *first_bad);
+/* construct_dense_pi_vec (tests/scalar_gadgets_tests.rs:151): d_out[circuit_size] */
+pg_status pg_composer_dense_pi(pg_composer *c, pg_scalar *d_out);
+
+/* everything else a prover-ready row holds.  Constant selector columns (q_4, q_arith = 1,
+ * q_range = q_logic = q_fixed_group_add = q_variable_group_add = 0), w_4 (zero_var except on the dummy rows) and
+ * the wire VALUE columns (variables[w_x[i]]).  Any pointer may be NULL (skipped); all are device arrays of
+ * circuit_size entries. */
+typedef struct pg_full_columns {
+    pg_scalar *q_4, *q_arith, *q_range, *q_logic, *q_fixed_group_add, *q_variable_group_add;
+    uint64_t *w_4;
+    pg_scalar *w_l_value, *w_r_value, *w_o_value, *w_4_value;
+} pg_full_columns;
+pg_status pg_composer_materialize(pg_composer *c, const pg_full_columns *out);
+
 /* ---- diagnostics ----------------------------------------------------------
  * pg_fill_bytes: a bare streaming fill (16 B per lane, same store form and grid shape as the emitters) used by
  * bench.py to measure the practical HBM write ceiling on the same box. */

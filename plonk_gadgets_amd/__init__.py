@@ -5,3 +5,5 @@ The compute path is libplonk_gadgets_hip.so (hand-written HIP behind a C ABI, in
 this package is the thin host side: scalar helpers, buffer plumbing on torch device tensors, and sharding."""
 from .scalar import BlsScalar, bits_count, num_bits_closest_power_of_two  # noqa: F401
 from .engine import Columns, Engine, Layout, NonExistingInverse, PgError  # noqa: F401
+from .composer import (AllocatedScalar, StandardComposer, Variable, conditionally_select_one,  # noqa: F401
+                       conditionally_select_zero, is_non_zero, max_bound, maybe_equal, range_check)

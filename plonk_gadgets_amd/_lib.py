@@ -31,6 +31,12 @@ class ColumnsC(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("q_m", "q_l", "q_r", "q_o", "q_c", "w_l", "w_r", "w_o", "var_values")]
 
 
+class FullColumnsC(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("q_4", "q_arith", "q_range", "q_logic", "q_fixed_group_add",
+                                          "q_variable_group_add", "w_4", "w_l_value", "w_r_value", "w_o_value",
+                                          "w_4_value")]
+
+
 class LayoutC(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("num_bits", "gates_per_item", "vars_per_item", "n_gates", "n_vars")]
 
@@ -74,6 +80,35 @@ SIGNATURES = {
                                        C.c_uint64, C.c_uint64, C.c_uint64, _P(ColumnsC), C.c_void_p]),
     "pg_scalar_mix_plan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      _P(LayoutC), _P(C.c_uint64), C.c_void_p]),
+    "pg_composer_create": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, _P(C.c_void_p)]),
+    "pg_composer_destroy": (None, [C.c_void_p]),
+    "pg_composer_circuit_size": (C.c_uint64, [C.c_void_p]),
+    "pg_composer_num_variables": (C.c_uint64, [C.c_void_p]),
+    "pg_composer_zero_var": (C.c_uint64, [C.c_void_p]),
+    "pg_composer_columns": (C.c_int, [C.c_void_p, _P(ColumnsC)]),
+    "pg_composer_sync": (C.c_int, [C.c_void_p]),
+    "pg_composer_add_input": (C.c_int, [C.c_void_p, _P(Scalar), _P(C.c_uint64)]),
+    "pg_composer_add_witness_to_circuit_description": (C.c_int, [C.c_void_p, _P(Scalar), _P(C.c_uint64)]),
+    "pg_composer_constrain_to_constant": (C.c_int, [C.c_void_p, C.c_uint64, _P(Scalar), _P(Scalar)]),
+    "pg_composer_assert_equal": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
+    "pg_composer_poly_gate": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64] + [_P(Scalar)] * 6),
+    "pg_composer_add": (C.c_int, [C.c_void_p, _P(Scalar), C.c_uint64, _P(Scalar), C.c_uint64, _P(Scalar), _P(Scalar),
+                                  _P(C.c_uint64)]),
+    "pg_composer_mul": (C.c_int, [C.c_void_p, _P(Scalar), C.c_uint64, C.c_uint64, _P(Scalar), _P(Scalar), _P(C.c_uint64)]),
+    "pg_composer_mul_gate": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64] + [_P(Scalar)] * 4),
+    "pg_composer_boolean_gate": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "pg_allocated_scalar_allocate": (C.c_int, [C.c_void_p, _P(Scalar), _P(AllocatedScalarC)]),
+    "pg_range_check": (C.c_int, [C.c_void_p, _P(Scalar), _P(Scalar), _P(AllocatedScalarC), _P(C.c_uint64)]),
+    "pg_max_bound": (C.c_int, [C.c_void_p, _P(Scalar), _P(AllocatedScalarC), _P(C.c_uint64), _P(C.c_uint64)]),
+    "pg_conditionally_select_zero": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, _P(C.c_uint64)]),
+    "pg_conditionally_select_one": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, _P(C.c_uint64)]),
+    "pg_is_non_zero": (C.c_int, [C.c_void_p, C.c_uint64, _P(Scalar)]),
+    "pg_maybe_equal": (C.c_int, [C.c_void_p, _P(AllocatedScalarC), _P(AllocatedScalarC), _P(C.c_uint64)]),
+    "pg_composer_range_check_batch": (C.c_int, [C.c_void_p, _P(Scalar), _P(Scalar), C.c_void_p, C.c_uint64, C.c_void_p]),
+    "pg_composer_read_value": (C.c_int, [C.c_void_p, C.c_uint64, _P(Scalar)]),
+    "pg_composer_check": (C.c_int, [C.c_void_p, _P(C.c_int64)]),
+    "pg_composer_dense_pi": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pg_composer_materialize": (C.c_int, [C.c_void_p, _P(FullColumnsC)]),
     "pg_fill_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "pg_scalar_mix_batch": (C.c_int, [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                                           C.c_uint64, _P(ColumnsC), C.c_void_p, C.c_void_p]),

@@ -1,0 +1,240 @@
+"""Host mirror of the reference's public interface on a device-resident composer.
+
+Same names, argument order and error behaviour as /root/reference/src/lib.rs:42-45 re-exports, so circuits written
+against the reference read the same:
+
+    reference (tests/range_gadgets_tests.rs:36-43)                 here
+    let w = AllocatedScalar::allocate(composer, witness);          w = AllocatedScalar.allocate(composer, witness)
+    let r = range_check(composer, min, max, w);                    r = range_check(composer, mn, mx, w)
+    composer.constrain_to_constant(r, outcome, None);              composer.constrain_to_constant(r, outcome, None)
+
+Every call appends on the GPU through the C ABI (pg_composer_*, pg_range_check, ...); nothing is computed here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from .engine import Columns, Engine, NonExistingInverse, PgError
+from .scalar import BlsScalar
+
+Variable = int
+
+
+def _chk(st: int, where: str):
+    if st == 1:
+        raise NonExistingInverse(st, where)
+    if st != 0:
+        raise PgError(st, where)
+
+
+def _opt(pi: BlsScalar | None):
+    return C.byref(pi.c) if pi is not None else None
+
+
+class StandardComposer:
+    """pg_composer: dusk-plonk's StandardComposer slice used by the gadgets, columns resident in HBM."""
+
+    def __init__(self, engine: Engine, gate_capacity: int = 1 << 16, var_capacity: int = 1 << 16, with_dummy: bool = True):
+        self.engine = engine
+        self._lib = engine._lib
+        h = C.c_void_p()
+        _chk(self._lib.pg_composer_create(engine._h, gate_capacity, var_capacity, int(with_dummy), engine._stream(),
+                                          C.byref(h)), "pg_composer_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pg_composer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state ------------------------------------------------------------------------------
+    def circuit_size(self) -> int:
+        return int(self._lib.pg_composer_circuit_size(self._h))
+
+    def num_variables(self) -> int:
+        return int(self._lib.pg_composer_num_variables(self._h))
+
+    @property
+    def zero_var(self) -> Variable:
+        return int(self._lib.pg_composer_zero_var(self._h))
+
+    # -- composer calls (dusk-plonk 0.8 argument order) ---------------------------------------------
+    def add_input(self, s: BlsScalar) -> Variable:
+        out = C.c_uint64()
+        _chk(self._lib.pg_composer_add_input(self._h, C.byref(s.c), C.byref(out)), "add_input")
+        return out.value
+
+    def add_witness_to_circuit_description(self, value: BlsScalar) -> Variable:
+        out = C.c_uint64()
+        _chk(self._lib.pg_composer_add_witness_to_circuit_description(self._h, C.byref(value.c), C.byref(out)),
+             "add_witness_to_circuit_description")
+        return out.value
+
+    def constrain_to_constant(self, a: Variable, constant: BlsScalar, pi: BlsScalar | None = None):
+        _chk(self._lib.pg_composer_constrain_to_constant(self._h, a, C.byref(constant.c), _opt(pi)), "constrain_to_constant")
+
+    def assert_equal(self, a: Variable, b: Variable):
+        _chk(self._lib.pg_composer_assert_equal(self._h, a, b), "assert_equal")
+
+    def poly_gate(self, a, b, c, q_m, q_l, q_r, q_o, q_c, pi=None):
+        _chk(self._lib.pg_composer_poly_gate(self._h, a, b, c, C.byref(q_m.c), C.byref(q_l.c), C.byref(q_r.c),
+                                             C.byref(q_o.c), C.byref(q_c.c), _opt(pi)), "poly_gate")
+
+    def add(self, q_l_a, q_r_b, q_c: BlsScalar, pi=None) -> Variable:
+        (q_l, a), (q_r, b) = q_l_a, q_r_b
+        out = C.c_uint64()
+        _chk(self._lib.pg_composer_add(self._h, C.byref(q_l.c), a, C.byref(q_r.c), b, C.byref(q_c.c), _opt(pi),
+                                       C.byref(out)), "add")
+        return out.value
+
+    def mul(self, q_m: BlsScalar, a: Variable, b: Variable, q_c: BlsScalar, pi=None) -> Variable:
+        out = C.c_uint64()
+        _chk(self._lib.pg_composer_mul(self._h, C.byref(q_m.c), a, b, C.byref(q_c.c), _opt(pi), C.byref(out)), "mul")
+        return out.value
+
+    def mul_gate(self, a, b, c, q_m, q_o, q_c, pi=None):
+        _chk(self._lib.pg_composer_mul_gate(self._h, a, b, c, C.byref(q_m.c), C.byref(q_o.c), C.byref(q_c.c), _opt(pi)),
+             "mul_gate")
+
+    def boolean_gate(self, a: Variable) -> Variable:
+        _chk(self._lib.pg_composer_boolean_gate(self._h, a), "boolean_gate")
+        return a
+
+    # -- batched append -------------------------------------------------------------------------------
+    def range_check_batch(self, min_range: BlsScalar, max_range: BlsScalar, witness: torch.Tensor) -> torch.Tensor:
+        """for w in witness: allocate(w); range_check(min, max, w) -- appended at the composer's end"""
+        assert witness.is_cuda and witness.dtype == torch.int64 and witness.dim() == 2 and witness.is_contiguous()
+        res = torch.empty((witness.shape[0],), dtype=torch.int64, device=witness.device)
+        _chk(self._lib.pg_composer_range_check_batch(self._h, C.byref(min_range.c), C.byref(max_range.c),
+                                                     witness.data_ptr(), witness.shape[0], res.data_ptr()),
+             "pg_composer_range_check_batch")
+        return res
+
+    # -- read-back ----------------------------------------------------------------------------------------
+    def value(self, v: Variable) -> BlsScalar:
+        out = _lib.Scalar()
+        _chk(self._lib.pg_composer_read_value(self._h, v, C.byref(out)), "read_value")
+        return BlsScalar(out)
+
+    def check(self) -> int:
+        """-1 when every row is satisfied, else the first failing row"""
+        bad = C.c_int64()
+        _chk(self._lib.pg_composer_check(self._h, C.byref(bad)), "check")
+        return bad.value
+
+    def construct_dense_pi_vec(self) -> torch.Tensor:
+        out = torch.empty((self.circuit_size(), 4), dtype=torch.int64, device=self.engine.device)
+        _chk(self._lib.pg_composer_dense_pi(self._h, out.data_ptr()), "dense_pi")
+        return out
+
+    def export(self, gate_base: int = 0, var_base: int = 0) -> dict:
+        """numpy copy of the live columns (rows >= gate_base, variables >= var_base)"""
+        import numpy as np
+        cc = _lib.ColumnsC()
+        _chk(self._lib.pg_composer_columns(self._h, C.byref(cc)), "columns")
+        _chk(self._lib.pg_composer_sync(self._h), "sync")
+        n, nv = self.circuit_size(), self.num_variables()
+        out = {}
+        for name in Columns.SCALAR_COLS:
+            t = torch.empty((n, 4), dtype=torch.int64, device=self.engine.device)
+            if n:
+                _memcpy_d2d(t, getattr(cc, name), n * 32)
+            out[name] = t.cpu().numpy().view(np.uint64)[gate_base:]
+        for name in Columns.WIRE_COLS:
+            t = torch.empty((n,), dtype=torch.int64, device=self.engine.device)
+            if n:
+                _memcpy_d2d(t, getattr(cc, name), n * 8)
+            out[name] = t.cpu().numpy().view(np.uint64)[gate_base:]
+        t = torch.empty((nv, 4), dtype=torch.int64, device=self.engine.device)
+        _memcpy_d2d(t, cc.var_values, nv * 32)
+        out["var_values"] = t.cpu().numpy().view(np.uint64)[var_base:]
+        return out
+
+    def materialize(self) -> dict:
+        """constant columns, w_4 and the wire-value columns as device tensors"""
+        n, dev = self.circuit_size(), self.engine.device
+        names = ("q_4", "q_arith", "q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add")
+        vals = ("w_l_value", "w_r_value", "w_o_value", "w_4_value")
+        t = {k: torch.empty((n, 4), dtype=torch.int64, device=dev) for k in names + vals}
+        t["w_4"] = torch.empty((n,), dtype=torch.int64, device=dev)
+        fc = _lib.FullColumnsC(**{k: v.data_ptr() for k, v in t.items()})
+        _chk(self._lib.pg_composer_materialize(self._h, C.byref(fc)), "materialize")
+        return t
+
+
+def _memcpy_d2d(dst: torch.Tensor, src_ptr: int, nbytes: int):
+    """copy nbytes from a raw device pointer into a torch tensor (hipMemcpy through torch's runtime)"""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rc = hip.hipMemcpy(dst.data_ptr(), src_ptr, nbytes, 3)  # hipMemcpyDeviceToDevice
+    if rc != 0:
+        raise RuntimeError(f"hipMemcpy failed: {rc}")
+
+
+@dataclass
+class AllocatedScalar:
+    """/root/reference/src/allocated_scalar.rs:17-30"""
+    var: Variable
+    scalar: BlsScalar
+
+    @staticmethod
+    def allocate(composer: StandardComposer, scalar: BlsScalar) -> "AllocatedScalar":
+        out = _lib.AllocatedScalarC()
+        _chk(composer._lib.pg_allocated_scalar_allocate(composer._h, C.byref(scalar.c), C.byref(out)), "allocate")
+        return AllocatedScalar(int(out.var), scalar)
+
+    def _c(self) -> _lib.AllocatedScalarC:
+        return _lib.AllocatedScalarC(self.var, self.scalar.c)
+
+
+# ---- RangeGadgets (/root/reference/src/range.rs) ---------------------------------------------------------
+def range_check(composer: StandardComposer, min_range: BlsScalar, max_range: BlsScalar, witness: AllocatedScalar) -> Variable:
+    """src/range.rs:27-43"""
+    out, w = C.c_uint64(), witness._c()
+    _chk(composer._lib.pg_range_check(composer._h, C.byref(min_range.c), C.byref(max_range.c), C.byref(w), C.byref(out)),
+         "range_check")
+    return out.value
+
+
+def max_bound(composer: StandardComposer, max_range: BlsScalar, witness: AllocatedScalar):
+    """src/range.rs:82-113 -> (Variable, num_bits)"""
+    out, nb, w = C.c_uint64(), C.c_uint64(), witness._c()
+    _chk(composer._lib.pg_max_bound(composer._h, C.byref(max_range.c), C.byref(w), C.byref(out), C.byref(nb)), "max_bound")
+    return out.value, nb.value
+
+
+# ---- ScalarGadgets (/root/reference/src/scalar.rs) --------------------------------------------------------
+def conditionally_select_zero(composer: StandardComposer, x: Variable, select: Variable) -> Variable:
+    """src/scalar.rs:21-27"""
+    out = C.c_uint64()
+    _chk(composer._lib.pg_conditionally_select_zero(composer._h, x, select, C.byref(out)), "conditionally_select_zero")
+    return out.value
+
+
+def conditionally_select_one(composer: StandardComposer, y: Variable, selector: Variable) -> Variable:
+    """src/scalar.rs:36-59"""
+    out = C.c_uint64()
+    _chk(composer._lib.pg_conditionally_select_one(composer._h, y, selector, C.byref(out)), "conditionally_select_one")
+    return out.value
+
+
+def is_non_zero(composer: StandardComposer, var: Variable, value_assigned: BlsScalar) -> None:
+    """src/scalar.rs:63-97: raises NonExistingInverse (after the partial emission) when value_assigned is zero"""
+    _chk(composer._lib.pg_is_non_zero(composer._h, var, C.byref(value_assigned.c)), "is_non_zero")
+
+
+def maybe_equal(composer: StandardComposer, a: AllocatedScalar, b: AllocatedScalar) -> Variable:
+    """src/scalar.rs:105-140"""
+    out, ca, cb = C.c_uint64(), a._c(), b._c()
+    _chk(composer._lib.pg_maybe_equal(composer._h, C.byref(ca), C.byref(cb), C.byref(out)), "maybe_equal")
+    return out.value

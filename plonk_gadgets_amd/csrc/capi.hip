@@ -10,11 +10,13 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "emit.hpp"
 #include "fr.hpp"
 #include "range_gadgets.hpp"
 #include "scalar_gadgets.hpp"
+#include "composer.hpp"
 
 namespace {
 
@@ -529,3 +531,5 @@ pg_status pg_fill_bytes(pg_engine *e, void *d_dst, uint64_t bytes, uint64_t patt
 }
 
 }  // extern "C"
+
+#include "capi_composer.inc"

@@ -1,0 +1,141 @@
+// composer.hpp -- device side of pg_composer, the device-resident counterpart of the slice of dusk-plonk's
+// StandardComposer the reference's gadgets call (call sites: /root/reference/src/range.rs:42,
+// 65,98,130,139,144,151 and src/scalar.rs:26,41-58,69-94,111-137; tests use constrain_to_constant and
+// construct_dense_pi_vec).  The columns live in HBM and only ever grow; a single composer call is one tiny launch
+// that appends one row and/or one variable, the gadgets append through the batched emitters (emit.hpp).
+#pragma once
+
+#include "emit.hpp"
+
+namespace pg {
+
+struct ComposerCols {
+    uint4 *q[5];
+    uint64_t *w[3];
+    uint4 *vars;
+};
+
+enum GateOp : uint32_t { OP_ADD_INPUT = 0, OP_ROW = 1, OP_ADD = 2, OP_MUL = 3 };
+
+// one composer call, passed by value as the kernel argument
+struct GateCmd {
+    uint32_t op;
+    uint32_t pad;
+    uint64_t gate;     // row to write (OP_ROW, OP_ADD, OP_MUL)
+    uint64_t var;      // variable to create (OP_ADD_INPUT, OP_ADD, OP_MUL)
+    uint64_t a, b, c;  // wires; for OP_ADD / OP_MUL the output wire is `var`
+    Fr q_m, q_l, q_r, q_o, q_c;
+    Fr pi;     // public input of the row (0 if none): enters the value of OP_ADD / OP_MUL outputs
+    Fr value;  // OP_ADD_INPUT
+};
+
+__device__ __forceinline__ void put_fr(uint4 *col, uint64_t i, const Fr &f) {
+    FrVec t;
+    t.f = f;
+    col[2 * i] = t.v[0];
+    col[2 * i + 1] = t.v[1];
+}
+__device__ __forceinline__ Fr get_fr(const uint4 *col, uint64_t i) {
+    FrVec t;
+    t.v[0] = col[2 * i];
+    t.v[1] = col[2 * i + 1];
+    return t.f;
+}
+
+__global__ void gate_kernel(const GateCmd cmd, const ComposerCols C) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (cmd.op == OP_ADD_INPUT) {
+        put_fr(C.vars, cmd.var, cmd.value);
+        return;
+    }
+    uint64_t out = cmd.c;
+    if (cmd.op == OP_ADD || cmd.op == OP_MUL) {
+        const Fr a = get_fr(C.vars, cmd.a), b = get_fr(C.vars, cmd.b);
+        // big_add / big_mul with no fourth wire: c = q_l a + q_r b + q_c + pi   |   c = q_m a b + q_c + pi
+        Fr v = cmd.op == OP_ADD ? fr_add(fr_mul(cmd.q_l, a), fr_mul(cmd.q_r, b)) : fr_mul(fr_mul(cmd.q_m, a), b);
+        v = fr_add(fr_add(v, cmd.q_c), cmd.pi);
+        put_fr(C.vars, cmd.var, v);
+        out = cmd.var;
+    }
+    put_fr(C.q[0], cmd.gate, cmd.q_m);
+    put_fr(C.q[1], cmd.gate, cmd.q_l);
+    put_fr(C.q[2], cmd.gate, cmd.q_r);
+    put_fr(C.q[3], cmd.gate, cmd.q_o);
+    put_fr(C.q[4], cmd.gate, cmd.q_c);
+    C.w[0][cmd.gate] = cmd.a;
+    C.w[1][cmd.gate] = cmd.b;
+    C.w[2][cmd.gate] = out;
+}
+
+// small host blob -> device staging buffer (inputs of single-gadget calls: scalars, Variables, offsets)
+struct StageBlob {
+    uint64_t w[40];
+};
+__global__ void stage_kernel(const StageBlob blob, uint64_t *dst, uint32_t n) {
+    if (threadIdx.x < n) dst[threadIdx.x] = blob.w[threadIdx.x];
+}
+
+// rows whose fourth wire is live (q_4 != 0 or w_4 != zero_var): only the initial dummy constraints on this path
+struct FourthWire {
+    uint64_t gate, w_4;
+    Fr q_4;
+};
+
+// q_m a b + q_l a + q_r b + q_o c + q_4 d + q_c + PI == 0 on every row; first unsatisfied row -> *first_bad
+__global__ __launch_bounds__(kThreads) void check_kernel(const ComposerCols C, uint64_t n, const uint64_t *pi_gate,
+                                                        const uint4 *pi_val, uint32_t n_pi, const FourthWire *fw,
+                                                        uint32_t n_fw, unsigned long long *first_bad) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kThreads) {
+        const Fr a = get_fr(C.vars, C.w[0][i]), b = get_fr(C.vars, C.w[1][i]), c = get_fr(C.vars, C.w[2][i]);
+        Fr t = fr_mul(fr_mul(get_fr(C.q[0], i), a), b);
+        t = fr_add(t, fr_mul(get_fr(C.q[1], i), a));
+        t = fr_add(t, fr_mul(get_fr(C.q[2], i), b));
+        t = fr_add(t, fr_mul(get_fr(C.q[3], i), c));
+        t = fr_add(t, get_fr(C.q[4], i));
+        // sparse public inputs, sorted by gate (rows are appended in order): binary search
+        uint32_t lo = 0, hi = n_pi;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (pi_gate[mid] < i) lo = mid + 1; else hi = mid;
+        }
+        if (lo < n_pi && pi_gate[lo] == i) t = fr_add(t, get_fr(pi_val, lo));
+        for (uint32_t k = 0; k < n_fw; k++)
+            if (fw[k].gate == i) t = fr_add(t, fr_mul(fw[k].q_4, get_fr(C.vars, fw[k].w_4)));
+        if (!fr_is_zero(t)) atomicMin(first_bad, (unsigned long long)i);
+    }
+}
+
+// ---- the rest of a prover-ready row ------------------------------------
+// constant selector column: the same scalar on every row
+__global__ __launch_bounds__(kThreads) void fill_scalar_kernel(uint4 *dst, uint64_t n_rows, const Fr value) {
+    FrVec t;
+    t.f = value;
+    const uint4 v = t.v[threadIdx.x & 1];
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < 2 * n_rows; i += (uint64_t)gridDim.x * kThreads)
+        store16(dst + i, v);
+}
+__global__ __launch_bounds__(kThreads) void fill_u64_kernel(uint64_t *dst, uint64_t n, uint64_t value) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kThreads) dst[i] = value;
+}
+__global__ void patch_fourth_kernel(uint4 *q_4, uint64_t *w_4, const FourthWire *fw, uint32_t n_fw) {
+    if (threadIdx.x < n_fw) {
+        put_fr(q_4, fw[threadIdx.x].gate, fw[threadIdx.x].q_4);
+        w_4[fw[threadIdx.x].gate] = fw[threadIdx.x].w_4;
+    }
+}
+// wire VALUE column: out[i] = variables[w[i]] (what the prover interpolates); 16 B per lane
+__global__ __launch_bounds__(kThreads) void gather_wire_values_kernel(const uint64_t *w, const uint4 *vars, uint64_t n_rows,
+                                                                     uint4 *out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < 2 * n_rows; i += (uint64_t)gridDim.x * kThreads)
+        store16(out + i, vars[2 * w[i >> 1] + (i & 1)]);
+}
+// dense public-input vector from the sparse store (construct_dense_pi_vec)
+__global__ void scatter_pi_kernel(uint4 *dense, const uint64_t *pi_gate, const uint4 *pi_val, uint32_t n_pi) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_pi) {
+        dense[2 * pi_gate[k]] = pi_val[2 * k];
+        dense[2 * pi_gate[k] + 1] = pi_val[2 * k + 1];
+    }
+}
+
+}  // namespace pg

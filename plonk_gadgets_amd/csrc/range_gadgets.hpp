@@ -79,7 +79,9 @@ __device__ __forceinline__ void bound_selector_ids(uint32_t jj, uint32_t n, bool
     id[0] = qm; id[1] = ql; id[2] = qr; id[3] = qo; id[4] = qc;
 }
 
-// wire variable offsets of block row jj; vb = offset of the block's first variable, x = offset of the witness
+constexpr uint32_t kWitnessWire = 0xffffffffu;  // "the witness Variable" (allocated by the item, or an existing one)
+
+// wire variable offsets of block row jj; vb = offset of the block's first variable, x = kWitnessWire
 __device__ __forceinline__ void bound_wire_offsets(uint32_t jj, uint32_t n, uint32_t vb, uint32_t x, uint32_t off[3]) {
     uint32_t a, b, c;
     if (jj >= 2 && jj < 2 * n + 2) {
@@ -125,6 +127,8 @@ struct RangeCheckGD {
         Fr min_range, max_range;  // Montgomery form (public inputs)
         uint32_t n;               // ladder bits
         const uint4 *witness;
+        const uint64_t *witness_vars;  // NULL: every item allocates its witness (AllocatedScalar::allocate) as its
+                                       // first variable; else: the existing Variables the items range-check
         uint64_t *result_vars;
         const uint4 *pow2;
         const uint4 *inv;  // [batch][2] from the inversion pre-pass
@@ -149,7 +153,8 @@ struct RangeCheckGD {
 
     __device__ static const uint4 *pow2(const Args &A) { return A.pow2; }
     __device__ static uint32_t rows_per_item(const Args &A) { return 4 * A.n + 11; }
-    __device__ static uint32_t vars_per_item(const Args &A) { return 2 * A.n + 524; }
+    __device__ static uint32_t xo(const Args &A) { return A.witness_vars ? 0u : 1u; }  // variables the witness takes
+    __device__ static uint32_t vars_per_item(const Args &A) { return 2 * A.n + 523 + xo(A); }
 
     __device__ static void fill_table(const Args &A, uint4 *table, uint32_t tid) {
         if (tid == T_QC_A || tid == T_QC_B) {
@@ -188,28 +193,31 @@ struct RangeCheckGD {
         ids_to_values(id, table, h, out);
     }
 
-    __device__ static void wires(const Args &A, const EmitOut &, const ItemRec &, uint64_t, uint64_t vbase, uint32_t j,
+    __device__ static void wires(const Args &A, const EmitOut &, const ItemRec &, uint64_t item, uint64_t vbase, uint32_t j,
                                  uint64_t out[3]) {
-        const uint32_t n = A.n, L = 2 * n + 5, VB = n + 261;
+        const uint32_t n = A.n, L = 2 * n + 5, VB = n + 261, x0 = xo(A);
         uint32_t off[3];
         if (j == 2 * L) {
-            off[0] = 1 + 260 + n;       // Y1
-            off[1] = 1 + VB + 260 + n;  // Y2
-            off[2] = 1 + 2 * VB;        // R
+            off[0] = x0 + 260 + n;       // Y1
+            off[1] = x0 + VB + 260 + n;  // Y2
+            off[2] = x0 + 2 * VB;        // R
         } else {
             const bool is_min = j >= L;
-            bound_wire_offsets(is_min ? j - L : j, n, is_min ? 1 + VB : 1, 0, off);
+            bound_wire_offsets(is_min ? j - L : j, n, is_min ? x0 + VB : x0, kWitnessWire, off);
         }
-        out[0] = vbase + off[0];
-        out[1] = vbase + off[1];
-        out[2] = vbase + off[2];
+        const uint64_t xvar = A.witness_vars ? A.witness_vars[item] : vbase;
+#pragma unroll
+        for (int c = 0; c < 3; c++) out[c] = off[c] == kWitnessWire ? xvar : vbase + off[c];
     }
 
     __device__ static Fr var_value(const Args &A, const ItemRec &R, const uint4 *, uint32_t k) {
         const uint32_t n = A.n, VB = n + 261;
-        if (k == 0) return R.x;
-        if (k == 2 * VB + 1) return (R.y[0] & R.y[1]) ? fr_one() : fr_zero();  // range.rs:42
-        uint32_t kk = k - 1, blk = 0;
+        if (!A.witness_vars) {
+            if (k == 0) return R.x;
+            k -= 1;
+        }
+        if (k == 2 * VB) return (R.y[0] & R.y[1]) ? fr_one() : fr_zero();  // range.rs:42
+        uint32_t kk = k, blk = 0;
         if (kk >= VB) { kk -= VB; blk = 1; }
         return bound_var_value(R.b[blk], R.y[blk], kk, n);
     }
@@ -224,6 +232,7 @@ struct MaxBoundGD {
         const uint4 *max_range_v;   // ragged: per-item bounds
         const uint32_t *num_bits_v; // ragged: per-item ladder bits (from the plan)
         const uint4 *witness;
+        const uint64_t *witness_vars;  // NULL: items allocate their witness; else existing Variables (uniform only)
         uint64_t *result_vars;
         const uint4 *pow2;
         const uint4 *inv;  // [batch] from the inversion pre-pass
@@ -255,7 +264,8 @@ struct MaxBoundGD {
 
     __device__ static const uint4 *pow2(const Args &A) { return A.pow2; }
     __device__ static uint32_t rows_per_item(const Args &A) { return 2 * A.n + 5; }
-    __device__ static uint32_t vars_per_item(const Args &A) { return A.n + 262; }
+    __device__ static uint32_t xo(const Args &A) { return (!RAGGED && A.witness_vars) ? 0u : 1u; }
+    __device__ static uint32_t vars_per_item(const Args &A) { return A.n + 261 + xo(A); }
 
     __device__ static void fill_table(const Args &A, uint4 *table, uint32_t tid) {
         if (tid == T_QC_A) {
@@ -292,8 +302,8 @@ struct MaxBoundGD {
         z.v[1] = A.inv[item * 2 + 1];
         R.y = bound_item(fr_sub(qc, x.f), n, z.f, R.b);  // range.rs:102
         if (A.result_vars) {
-            const uint64_t first = RAGGED ? O.var_off[item] : item * (uint64_t)(n + 262);
-            A.result_vars[item] = O.var_base + first + (n + 261);  // Y is the item's last variable
+            const uint64_t first = RAGGED ? O.var_off[item] : item * (uint64_t)(n + 261 + xo(A));
+            A.result_vars[item] = O.var_base + first + (n + 260 + xo(A));  // Y is the item's last variable
         }
     }
 
@@ -310,18 +320,21 @@ struct MaxBoundGD {
         }
     }
 
-    __device__ static void wires(const Args &A, const EmitOut &, const ItemRec &R, uint64_t, uint64_t vbase, uint32_t j,
+    __device__ static void wires(const Args &A, const EmitOut &, const ItemRec &R, uint64_t item, uint64_t vbase, uint32_t j,
                                  uint64_t out[3]) {
         uint32_t off[3];
-        bound_wire_offsets(j, RAGGED ? R.n : A.n, 1, 0, off);
-        out[0] = vbase + off[0];
-        out[1] = vbase + off[1];
-        out[2] = vbase + off[2];
+        bound_wire_offsets(j, RAGGED ? R.n : A.n, xo(A), kWitnessWire, off);
+        const uint64_t xvar = xo(A) ? vbase : A.witness_vars[item];
+#pragma unroll
+        for (int c = 0; c < 3; c++) out[c] = off[c] == kWitnessWire ? xvar : vbase + off[c];
     }
 
     __device__ static Fr var_value(const Args &A, const ItemRec &R, const uint4 *, uint32_t k) {
-        if (k == 0) return R.x;
-        return bound_var_value(R.b, R.y, k - 1, RAGGED ? R.n : A.n);
+        if (xo(A)) {
+            if (k == 0) return R.x;
+            k -= 1;
+        }
+        return bound_var_value(R.b, R.y, k, RAGGED ? R.n : A.n);
     }
 };
 

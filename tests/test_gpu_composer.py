@@ -1,0 +1,234 @@
+"""GPU: the reference's own test circuits expressed on the device-resident composer through the reference-named
+host API (plonk_gadgets_amd.composer), compared limb for limb with the same calls on the CPU oracle's composer."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import plonk_gadgets_amd as pg
+from plonk_gadgets_amd import synth
+from tests.refcases import MAX_BOUND_CASES, MAYBE_EQUAL_CASES, RANGE_CHECK_CASES
+
+pytestmark = pytest.mark.gpu
+
+COLS = ("q_m", "q_l", "q_r", "q_o", "q_c", "w_l", "w_r", "w_o", "var_values")
+Q = synth.Q
+S = pg.BlsScalar.from_int
+
+
+@pytest.fixture(scope="module")
+def engine():
+    e = pg.Engine(0)
+    yield e
+    e.close()
+
+
+def same(dev: pg.StandardComposer, ora):
+    got, exp = dev.export(), ora.export()
+    assert dev.circuit_size() == ora.n and dev.num_variables() == ora.num_vars
+    for k in COLS:
+        assert got[k].shape == exp[k].shape, k
+        assert np.array_equal(got[k], exp[k]), k
+
+
+def test_initial_state(engine):
+    from oracle import pyoracle as po
+    dev, ora = pg.StandardComposer(engine), po.Composer()
+    assert (dev.circuit_size(), dev.num_variables(), dev.zero_var) == (3, 5, 0)
+    same(dev, ora)
+    assert dev.check() == -1
+    bare = pg.StandardComposer(engine, with_dummy=False)
+    assert (bare.circuit_size(), bare.num_variables()) == (1, 1)
+    same(bare, po.Composer(dummy=False))
+    # the fourth wire of the dummy rows lives in the materialised columns (q_4 = 1 on w_4 = Variable(2) in row 1)
+    m = dev.materialize()
+    assert m["w_4"].cpu().tolist() == [0, 2, 0]
+    assert m["q_4"].cpu().numpy().view(np.uint64).tolist() == [[0] * 4, synth.mont(1), [0] * 4]
+    assert (m["q_arith"].cpu().numpy().view(np.uint64) == np.array(synth.mont(1), dtype=np.uint64)).all()
+    for k in ("q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add"):
+        assert int(m[k].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("min_range,max_range,witness,expected", RANGE_CHECK_CASES)
+def test_range_check_reference_circuit(engine, min_range, max_range, witness, expected):
+    """tests/range_gadgets_tests.rs:29-44: allocate, range_check, constrain_to_constant(res, outcome)"""
+    from oracle import pyoracle as po
+    dev, ora = pg.StandardComposer(engine), po.Composer()
+    w = pg.AllocatedScalar.allocate(dev, S(witness))
+    res = pg.range_check(dev, S(min_range), S(max_range), w)
+    dev.constrain_to_constant(res, S(int(expected)), None)
+    ow = ora.allocate(synth.mont(witness))
+    ores = int(ora.L.range_check(ora.c, po.fr(synth.mont(min_range)), po.fr(synth.mont(max_range)), ow))
+    ora.L.composer_constrain_to_constant(ora.c, ores, po.fr(synth.mont(int(expected))), None)
+    assert res == ores and w.var == ow.var
+    same(dev, ora)
+    assert dev.value(res).to_int() == int(expected)
+    assert dev.check() == -1
+    dev.constrain_to_constant(res, S(1 - int(expected)), None)  # the wrong outcome must not verify
+    assert dev.check() == dev.circuit_size() - 1
+
+
+@pytest.mark.parametrize("max_range,witness,expected", MAX_BOUND_CASES)
+def test_max_bound_reference_circuit(engine, max_range, witness, expected):
+    """tests/range_gadgets_tests.rs:13-27"""
+    from oracle import pyoracle as po
+    dev, ora = pg.StandardComposer(engine), po.Composer()
+    res, nbits = pg.max_bound(dev, S(max_range), pg.AllocatedScalar.allocate(dev, S(witness)))
+    dev.constrain_to_constant(res, S(int(expected)), None)
+    onb = C.c_uint64()
+    ores = int(ora.L.max_bound(ora.c, po.fr(synth.mont(max_range)), ora.allocate(synth.mont(witness)), C.byref(onb)))
+    ora.L.composer_constrain_to_constant(ora.c, ores, po.fr(synth.mont(int(expected))), None)
+    assert (res, nbits) == (ores, onb.value)
+    same(dev, ora)
+    assert dev.check() == -1 and dev.value(res).to_int() == int(expected)
+
+
+@pytest.mark.parametrize("a,b,expected", MAYBE_EQUAL_CASES)
+def test_maybe_equal_reference_circuit(engine, a, b, expected):
+    """tests/scalar_gadgets_tests.rs:19-31"""
+    from oracle import pyoracle as po
+    dev, ora = pg.StandardComposer(engine), po.Composer()
+    bit = pg.maybe_equal(dev, pg.AllocatedScalar.allocate(dev, S(a)), pg.AllocatedScalar.allocate(dev, S(b)))
+    dev.constrain_to_constant(bit, S(int(expected)), None)
+    obit = int(ora.L.maybe_equal(ora.c, ora.allocate(synth.mont(a)), ora.allocate(synth.mont(b))))
+    ora.L.composer_constrain_to_constant(ora.c, obit, po.fr(synth.mont(int(expected))), None)
+    assert bit == obit
+    same(dev, ora)
+    assert dev.check() == -1
+
+
+def test_select_zero_reference_circuit(engine):
+    """tests/scalar_gadgets_tests.rs:70-122: selector 0 -> result 0 verifies; selector 1 -> constraining to 0 fails"""
+    from oracle import pyoracle as po
+    for sel in (0, 1):
+        value = 123456789 + sel
+        dev, ora = pg.StandardComposer(engine), po.Composer()
+        v, s = dev.add_input(S(value)), dev.add_input(S(sel))
+        res = pg.conditionally_select_zero(dev, v, s)
+        dev.constrain_to_constant(res, S(0), None)
+        ov, os_ = ora.add_input(synth.mont(value)), ora.add_input(synth.mont(sel))
+        ores = int(ora.L.conditionally_select_zero(ora.c, ov, os_))
+        ora.L.composer_constrain_to_constant(ora.c, ores, po.fr(synth.mont(0)), None)
+        assert res == ores
+        same(dev, ora)
+        assert (dev.check() == -1) == (sel == 0)
+
+
+def test_select_one_reference_circuit_with_public_input(engine):
+    """tests/scalar_gadgets_tests.rs:124-178: expected value injected as public input, dense PI vector"""
+    from oracle import pyoracle as po
+    for sel in (0, 1):
+        value = Q - 12345
+        expected = value if sel else 1
+        dev, ora = pg.StandardComposer(engine), po.Composer()
+        v, s = dev.add_input(S(value)), dev.add_input(S(sel))
+        res = pg.conditionally_select_one(dev, v, s)
+        dev.constrain_to_constant(res, S(0), S(-expected))
+        ov, os_ = ora.add_input(synth.mont(value)), ora.add_input(synth.mont(sel))
+        ores = int(ora.L.conditionally_select_one(ora.c, ov, os_))
+        pi = po.fr(synth.mont(-expected))
+        ora.L.composer_constrain_to_constant(ora.c, ores, po.fr(synth.mont(0)), C.byref(pi))
+        assert res == ores
+        same(dev, ora)
+        assert dev.check() == -1 and dev.value(res).to_int() == expected
+        dense = dev.construct_dense_pi_vec().cpu().numpy().view(np.uint64)
+        odense = np.zeros((ora.n, 4), dtype=np.uint64)
+        ora.L.composer_dense_pi(ora.c, odense.ctypes.data)
+        assert np.array_equal(dense, odense) and dense[-1].tolist() == synth.mont(-expected)
+
+
+def test_is_non_zero_reference_circuit(engine):
+    """tests/scalar_gadgets_tests.rs:180-236"""
+    from oracle import pyoracle as po
+    # (0, 0): Err after the partial emission
+    dev, ora = pg.StandardComposer(engine), po.Composer()
+    v = dev.add_input(S(0))
+    with pytest.raises(pg.NonExistingInverse):
+        pg.is_non_zero(dev, v, S(0))
+    assert ora.L.is_non_zero(ora.c, ora.add_input(synth.mont(0)), po.fr(synth.mont(0))) == 1
+    same(dev, ora)
+    # mismatching var / value_assigned: Ok but unsatisfied (:224)
+    dev, ora = pg.StandardComposer(engine), po.Composer()
+    pg.is_non_zero(dev, dev.add_input(S(777)), S(778))
+    assert ora.L.is_non_zero(ora.c, ora.add_input(synth.mont(777)), po.fr(synth.mont(778))) == 0
+    same(dev, ora)
+    assert dev.check() >= 0 and ora.check() == dev.check()
+    # equal and non-zero: satisfied (:235)
+    dev, ora = pg.StandardComposer(engine), po.Composer()
+    r = 2**200 + 17
+    pg.is_non_zero(dev, dev.add_input(S(r)), S(r))
+    assert ora.L.is_non_zero(ora.c, ora.add_input(synth.mont(r)), po.fr(synth.mont(r))) == 0
+    same(dev, ora)
+    assert dev.check() == -1
+
+
+def test_composer_gate_calls(engine):
+    """every composer call of SURVEY 3.4, with and without public inputs"""
+    from oracle import pyoracle as po
+    dev, ora = pg.StandardComposer(engine), po.Composer()
+    L = ora.L
+    f = lambda x: po.fr(synth.mont(x))
+    a, b = dev.add_input(S(11)), dev.add_input(S(Q - 3))
+    oa, ob = ora.add_input(synth.mont(11)), ora.add_input(synth.mont(Q - 3))
+    one = dev.add_witness_to_circuit_description(S(1))
+    assert one == L.composer_add_witness_to_circuit_description(ora.c, f(1))
+    c1 = dev.add((S(5), a), (S(-7), b), S(9), None)
+    assert c1 == L.composer_add(ora.c, f(5), oa, f(-7), ob, f(9), None)
+    pi = f(1000)
+    c2 = dev.add((S(2), a), (S(3), c1), S(0), S(1000))
+    assert c2 == L.composer_add(ora.c, f(2), oa, f(3), c1, f(0), C.byref(pi))
+    c3 = dev.mul(S(-1), c2, b, S(4), None)
+    assert c3 == L.composer_mul(ora.c, f(-1), c2, ob, f(4), None)
+    c4 = dev.mul(S(6), c3, c3, S(1), S(1000))
+    assert c4 == L.composer_mul(ora.c, f(6), c3, c3, f(1), C.byref(pi))
+    dev.boolean_gate(one)
+    L.composer_boolean_gate(ora.c, one)
+    dev.assert_equal(a, a)
+    L.composer_assert_equal(ora.c, oa, oa)
+    dev.mul_gate(a, one, a, S(1), S(-1), S(0), None)
+    L.composer_mul_gate(ora.c, oa, one, oa, f(1), f(-1), f(0), None)
+    dev.poly_gate(a, b, one, S(0), S(1), S(1), S(0), S(-8), None)  # 11 + (q-3) - 8 = 0
+    L.composer_poly_gate(ora.c, oa, ob, one, f(0), f(1), f(1), f(0), f(-8), None)
+    same(dev, ora)
+    assert dev.check() == -1 and ora.check() == -1
+    assert dev.value(c1).to_int() == (5 * 11 - 7 * (Q - 3) + 9) % Q
+    # wire-value columns == variables gathered by wire index
+    m = dev.materialize()
+    exp = dev.export()
+    for wname, vname in (("w_l", "w_l_value"), ("w_r", "w_r_value"), ("w_o", "w_o_value")):
+        assert np.array_equal(m[vname].cpu().numpy().view(np.uint64), exp["var_values"][exp[wname].astype(np.int64)])
+    w4 = m["w_4"].cpu().numpy()
+    assert np.array_equal(m["w_4_value"].cpu().numpy().view(np.uint64), exp["var_values"][w4])
+
+
+def test_batched_append_interleaved_with_single_calls(engine):
+    """a circuit that mixes composer calls, a batched range_check append and single gadgets"""
+    from oracle import pyoracle as po
+    mn, mx = 50_000, 250_000
+    wit = synth.scalars_from_ints([50_001, 250_000, 49_999, 123_456, 0])
+    dev, ora = pg.StandardComposer(engine, 1 << 12, 1 << 13), po.Composer()
+    x = dev.add_input(S(5))
+    ox = ora.add_input(synth.mont(5))
+    res = dev.range_check_batch(S(mn), S(mx), torch.from_numpy(wit.view(np.int64)).to("cuda:0"))
+    ores = []
+    for w in wit:
+        ores.append(int(ora.L.range_check(ora.c, po.fr(synth.mont(mn)), po.fr(synth.mont(mx)), ora.allocate(w))))
+    assert res.cpu().numpy().view(np.uint64).tolist() == ores
+    y = pg.conditionally_select_zero(dev, x, ores[0])
+    assert y == int(ora.L.conditionally_select_zero(ora.c, ox, ores[0]))
+    r2 = pg.range_check(dev, S(0), S(2**64), pg.AllocatedScalar(x, S(5)))
+    assert r2 == int(ora.L.range_check(ora.c, po.fr(synth.mont(0)), po.fr(synth.mont(2**64)),
+                                       po.AllocatedScalar(ox, po.fr(synth.mont(5)))))
+    same(dev, ora)
+    assert dev.check() == -1
+    assert [dev.value(r).to_int() for r in ores] == [1, 0, 0, 1, 0]
+
+
+def test_errors_do_not_crash(engine):
+    dev = pg.StandardComposer(engine, gate_capacity=8, var_capacity=8)
+    with pytest.raises(pg.PgError, match="capacity"):
+        pg.range_check(dev, S(0), S(2**64), pg.AllocatedScalar.allocate(dev, S(1)))
+    with pytest.raises(pg.PgError, match="unknown Variable"):
+        dev.boolean_gate(999)
+    assert dev.circuit_size() == 3  # nothing was appended by the failed calls
