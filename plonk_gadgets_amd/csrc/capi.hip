@@ -189,7 +189,12 @@ pg_status launch(pg_engine *e, const typename GD::Args &A_in, const pg_columns *
         A.inv = e->d_inv;
     }
     const pg::EmitOut O = make_out(c, batch, GD::W, gate_base, var_base, zero_var, row_off, var_off);
-    const uint32_t max_blocks = (uint32_t)e->num_cus * 8;
+#ifndef PG_GRID_BLOCKS_PER_CU
+// more workgroups than can be resident: the dispatcher back-fills CUs as tiles finish (+6 % over a persistent
+// 8-per-CU grid on the C2 shape, tools/ab_emit.py)
+#define PG_GRID_BLOCKS_PER_CU 64
+#endif
+    const uint32_t max_blocks = (uint32_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
     const uint32_t grid = O.tiles < max_blocks ? O.tiles : max_blocks;
     hipLaunchKernelGGL(pg::emit_kernel<GD>, dim3(grid), dim3(pg::kThreads), 0, static_cast<hipStream_t>(stream), A, O);
     PG_HIP_TRY(hipGetLastError());

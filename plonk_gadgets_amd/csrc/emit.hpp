@@ -48,9 +48,12 @@ struct EmitOut {
 enum : uint32_t { T_ZERO = 0, T_ONE = 1, T_NEG1 = 2, T_QC_A = 3, T_QC_B = 4, T_POW = 8 };
 constexpr int kTableEntries = 8 + 256;
 
+typedef unsigned int pg_u32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ void store16(uint4 *p, uint4 v) {
 #if defined(PG_NT_STORES)
-    __builtin_nontemporal_store(v, p);
+    pg_u32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<pg_u32x4 *>(p));
 #else
     *p = v;
 #endif
@@ -89,8 +92,11 @@ __device__ __forceinline__ void fill_common_table(uint4 *table, const uint4 *pow
 //   void selectors(A, rec, j, table, h, uint4 out[5])
 //   void wires(A, O, rec, item, item_var_base, j, uint64_t out[3])
 //   Fr   var_value(A, rec, table, k)
+#ifndef PG_EMIT_WAVES_PER_SIMD
+#define PG_EMIT_WAVES_PER_SIMD 1  // __launch_bounds__ second argument (waves per SIMD the register allocator must allow)
+#endif
 template <class GD>
-__global__ __launch_bounds__(kThreads) void emit_kernel(const typename GD::Args A, const EmitOut O) {
+__global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(const typename GD::Args A, const EmitOut O) {
     constexpr int W = GD::W;
     __shared__ uint4 s_table[kTableEntries * 2];
     __shared__ typename GD::ItemRec s_item[W];

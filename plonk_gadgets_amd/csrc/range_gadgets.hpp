@@ -148,7 +148,10 @@ struct RangeCheckGD {
         uint32_t y[2];
         uint32_t pad[2];
     };
-    static constexpr int W = 16;
+#ifndef PG_RC_W
+#define PG_RC_W 32
+#endif
+    static constexpr int W = PG_RC_W;
     static constexpr bool kRagged = false, kRecInRows = false, kUsePow2 = true;
 
     __device__ static const uint4 *pow2(const Args &A) { return A.pow2; }
@@ -259,7 +262,7 @@ struct MaxBoundGD {
         uint32_t y, n;
         uint32_t pad[2];
     };
-    static constexpr int W = 16;
+    static constexpr int W = 32;
     static constexpr bool kRagged = RAGGED, kRecInRows = RAGGED, kUsePow2 = true;
 
     __device__ static const uint4 *pow2(const Args &A) { return A.pow2; }
