@@ -262,7 +262,10 @@ struct MaxBoundGD {
         uint32_t y, n;
         uint32_t pad[2];
     };
-    static constexpr int W = 32;
+#ifndef PG_MB_W
+#define PG_MB_W 16
+#endif
+    static constexpr int W = PG_MB_W;
     static constexpr bool kRagged = RAGGED, kRecInRows = RAGGED, kUsePow2 = true;
 
     __device__ static const uint4 *pow2(const Args &A) { return A.pow2; }

@@ -15,12 +15,10 @@ VDIR = os.path.join(ROOT, "tools", "variants")
 
 VARIANTS = {
     "base": [],
-    "w32_grid32": ["-DPG_RC_W=32", "-DPG_GRID_BLOCKS_PER_CU=32"],
-    "w32_grid64": ["-DPG_RC_W=32", "-DPG_GRID_BLOCKS_PER_CU=64"],
-    "w32_grid1024": ["-DPG_RC_W=32", "-DPG_GRID_BLOCKS_PER_CU=1024"],
-    "w16_grid1024": ["-DPG_RC_W=16", "-DPG_GRID_BLOCKS_PER_CU=1024"],
-    "w24_grid1024": ["-DPG_RC_W=24", "-DPG_GRID_BLOCKS_PER_CU=1024"],
-    "w48_grid1024": ["-DPG_RC_W=48", "-DPG_GRID_BLOCKS_PER_CU=1024"],
+    "mb16": ["-DPG_MB_W=16"],
+    "mb64": ["-DPG_MB_W=64"],
+    "mb16_grid8": ["-DPG_MB_W=16", "-DPG_GRID_BLOCKS_PER_CU=8"],
+    "mb32_grid8": ["-DPG_MB_W=32", "-DPG_GRID_BLOCKS_PER_CU=8"],
 }
 
 
@@ -31,6 +29,63 @@ def build():
         out = os.path.join(VDIR, f"lib_{name}.so")
         b.build(force=True, extra_flags=flags, out=out)
         print("built", out)
+
+
+def run_c4(log2_chunk=19, rounds=4):
+    """ragged max_bound (BASELINE config C4 shape): plan once, time invert pre-pass + emit"""
+    import numpy as np
+    import torch
+    from plonk_gadgets_amd import _lib
+    import plonk_gadgets_amd as pg
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda", 0)
+    chunk = 1 << log2_chunk
+    mr_np, wt_np = bench.c4_inputs(chunk)
+    mr = torch.from_numpy(mr_np.view(np.int64)).to(dev)
+    wt = torch.from_numpy(wt_np.view(np.int64)).to(dev)
+    nb = torch.empty((chunk,), dtype=torch.int32, device=dev)
+    roff = torch.empty((chunk + 1,), dtype=torch.int64, device=dev)
+    voff = torch.empty((chunk + 1,), dtype=torch.int64, device=dev)
+    res = torch.empty((chunk,), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    libs = {}
+    cols = None
+    for name in VARIANTS:
+        path = os.path.join(VDIR, f"lib_{name}.so")
+        if not os.path.exists(path):
+            continue
+        lib = C.CDLL(path)
+        for fn, (r, a) in _lib.SIGNATURES.items():
+            f = getattr(lib, fn)
+            f.restype, f.argtypes = r, a
+        h = C.c_void_p()
+        assert lib.pg_engine_create(0, C.byref(h)) == 0
+        lay = _lib.LayoutC()
+        assert lib.pg_max_bound_ragged_plan(h, mr.data_ptr(), chunk, nb.data_ptr(), roff.data_ptr(), voff.data_ptr(),
+                                            C.byref(lay), C.c_void_p(stream.cuda_stream)) == 0
+        if cols is None:
+            cols = pg.Columns.allocate(int(lay.n_gates), int(lay.n_vars), dev)
+            nbytes = int(lay.n_gates) * 184 + int(lay.n_vars) * 32
+        libs[name] = (lib, h)
+    cc = cols.as_c()
+    times = {n: [] for n in libs}
+    for r in range(rounds + 1):
+        for name, (lib, h) in libs.items():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            st = lib.pg_max_bound_ragged_batch(h, mr.data_ptr(), wt.data_ptr(), chunk, nb.data_ptr(), roff.data_ptr(),
+                                               voff.data_ptr(), 3, 5, C.byref(cc), res.data_ptr(),
+                                               C.c_void_p(stream.cuda_stream))
+            assert st == 0
+            e1.record(stream)
+            torch.cuda.synchronize()
+            if r:
+                times[name].append(e0.elapsed_time(e1))
+    for name, ts in times.items():
+        ts = sorted(ts)
+        print(json.dumps({"variant": name, "flags": VARIANTS[name], "median_ms": ts[len(ts) // 2], "min_ms": ts[0],
+                          "gbps_median": nbytes / ts[len(ts) // 2] / 1e6}))
 
 
 def run(log2_chunk=18, rounds=4):
@@ -81,5 +136,7 @@ def run(log2_chunk=18, rounds=4):
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build()
+    elif sys.argv[1] == "run_c4":
+        run_c4(*(int(x) for x in sys.argv[2:]))
     else:
         run(*(int(x) for x in sys.argv[2:]))
