@@ -185,3 +185,66 @@ def test_misaligned_wire_columns(engine):
     # guard elements around the odd-aligned columns untouched
     assert int(big.w_l[0]) == -1 and int(big.w_l[-1]) == -1 and int(big.w_o[0]) == -1 and int(big.w_o[-1]) == -1
     assert int(big.w_r[0]) == -1 and int(big.w_r[1]) == -1
+
+
+def test_config_c1_exact(engine):
+    """BASELINE config 1: 1 000 x range_check(v, "64-bit") -- min = 0, max = 2^64 (n = 65, 271 rows per witness),
+    witnesses uniform in [0, 2^64 + 2^60) (about 6 % out of range): every limb vs the CPU oracle."""
+    from oracle import pyoracle as po
+    mn, mx = 0, 2**64
+    wit = synth.uniform_below(1000, 2**64 + 2**60, seed=synth.SEED)
+    ora = po.range_check_batch(synth.mont(mn), synth.mont(mx), wit)
+    assert ora["satisfied"] and ora["n_gates"] == 271_000 and ora["n_vars"] == 654_000
+    gpu = run_gpu(engine, mn, mx, wit)
+    assert_same(gpu, ora)
+    outcomes = [synth.to_int(gpu["var_values"][int(r) - 5]) for r in gpu["result_vars"]]
+    assert outcomes == [int(synth.to_int(w) < 2**64) for w in wit] and 0 < sum(outcomes) < 1000
+
+
+def test_config_c2_full_size_properties(engine):
+    """BASELINE config 2 at its full size: 2^20 witnesses x n = 255 in ONE launch (233.6 GB of columns).
+    Size-independent properties on the device (periodic selectors, affine wires, witness = first variable,
+    result variables) + items sampled across the whole range vs the CPU oracle."""
+    import plonk_gadgets_amd as pg
+    from oracle import pyoracle as po
+    free, _ = torch.cuda.mem_get_info()
+    batch = 1 << 20
+    G, V = 1031, 1034
+    if free < batch * (G * 184 + V * 32) + (24 << 30):
+        pytest.skip("not enough free HBM for the full-size batch")
+    mn, mx = 0, 2**254
+    wit = synth.random_scalars(batch, seed=synth.SEED)
+    w = torch.from_numpy(wit.view(np.int64)).to("cuda:0")
+    cols, res = engine.range_check_batch(pg.BlsScalar.from_int(mn), pg.BlsScalar.from_int(mx), w, 3, 5)
+    torch.cuda.synchronize()
+    step = 1 << 14  # compare in slabs to bound temporary memory
+    for name in ("q_m", "q_l", "q_r", "q_o", "q_c"):
+        c = getattr(cols, name).view(batch, G, 4)
+        ref = c[0:1]
+        for s in range(0, batch, step):
+            assert bool((c[s:s + step] == ref).all()), (name, s)
+    for name in WIRE_COLS:
+        c = getattr(cols, name).view(batch, G)
+        ref = c[0:1]
+        for s in range(0, batch, step):
+            base = (torch.arange(s, min(s + step, batch), device="cuda:0", dtype=torch.int64) * V).view(-1, 1)
+            assert bool(((c[s:s + step] - base) == ref).all()), (name, s)
+    assert bool((res == 5 + torch.arange(batch, device="cuda:0", dtype=torch.int64) * V + (V - 1)).all())
+    vv = cols.var_values.view(batch, V, 4)
+    assert bool((vv[:, 0, :] == w).all())
+    # every result is 1 at n = 255 (every field element fits 255 bits): the last variable of each item is mont(1)
+    one = torch.tensor(np.array(synth.mont(1), dtype=np.uint64).view(np.int64), device="cuda:0")
+    assert bool((vv[:, V - 1, :] == one).all())
+    idx = [0, 31, 32, 33, batch // 2 - 1, batch // 2, batch - 33, batch - 1] + [int(x) % batch for x in synth.splitmix64(8, 9)]
+    ora = po.range_check_batch(synth.mont(mn), synth.mont(mx), np.ascontiguousarray(wit[idx]))
+    for s, i in enumerate(idx):
+        for name in ("q_m", "q_l", "q_r", "q_o", "q_c"):
+            got = getattr(cols, name)[i * G:(i + 1) * G].cpu().numpy().view(np.uint64)
+            assert np.array_equal(got, ora[name][s * G:(s + 1) * G]), (name, i)
+        got = cols.var_values[i * V:(i + 1) * V].cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, ora["var_values"][s * V:(s + 1) * V]), ("var_values", i)
+        for name in WIRE_COLS:
+            got = getattr(cols, name)[i * G:(i + 1) * G].cpu().numpy().view(np.uint64) - np.uint64(i * V)
+            assert np.array_equal(got, ora[name][s * G:(s + 1) * G] - np.uint64(s * V)), (name, i)
+    del cols, vv
+    torch.cuda.empty_cache()
