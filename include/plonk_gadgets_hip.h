@@ -256,6 +256,12 @@ typedef struct pg_full_columns {
 } pg_full_columns;
 pg_status pg_composer_materialize(pg_composer *c, const pg_full_columns *out);
 
+/* the copy permutation the composer's bookkeeping implies (dusk-plonk's
+ * Permutation::compute_sigma_permutations).  d_sigma[4 * padded_n] (device): sigma of position (wire, gate) at
+ * index wire * padded_n + gate, encoded the same way; wire 0..3 = left, right, output, fourth; rows >= circuit_size
+ * map to themselves.  padded_n >= circuit_size (the prover pads to a power of two). */
+pg_status pg_composer_permutation(pg_composer *c, uint64_t padded_n, uint64_t *d_sigma);
+
 /* ---- diagnostics ----------------------------------------------------------
  * pg_fill_bytes: a bare streaming fill (16 B per lane, same store form and grid shape as the emitters) used by
  * bench.py to measure the practical HBM write ceiling on the same box. */

@@ -263,6 +263,18 @@ void composer_free(composer_t *c) {
     free(c);
 }
 
+void composer_sigma(const composer_t *c, size_t padded_n, uint64_t *out) {
+    for (size_t w = 0; w < 4; w++)
+        for (size_t i = 0; i < padded_n; i++) out[w * padded_n + i] = w * padded_n + i;
+    for (size_t v = 0; v < c->next_var; v++) {
+        const slot_t *s = must_find(c, v);
+        for (uint32_t k = 0; k < s->perm.len; k++) {
+            const wire_data cur = s->perm.p[k], nxt = s->perm.p[(k + 1 == s->perm.len) ? 0 : k + 1];
+            out[(size_t)cur.wire * padded_n + cur.gate] = (uint64_t)nxt.wire * padded_n + nxt.gate;
+        }
+    }
+}
+
 long composer_check(const composer_t *c) {
     fr_t *pi = (fr_t *)malloc((c->n ? c->n : 1) * sizeof(fr_t));
     composer_dense_pi(c, pi);

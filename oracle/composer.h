@@ -75,6 +75,11 @@ const var_t *composer_wire(const composer_t *c, int col);
 void composer_values_dense(const composer_t *c, fr_t *out);
 /* number of wire positions recorded for a variable in the permutation map */
 size_t composer_perm_count(const composer_t *c, var_t v);
+/* Permutation::compute_sigma_permutations(n) [dusk-plonk 0.8, restated]: every Variable's wire positions, in the
+ * order they were recorded (gate by gate; left, right, output, fourth within a gate), form one cycle; sigma maps each
+ * position to the next one of its Variable.  Positions are encoded wire * padded_n + gate; rows >= circuit size map
+ * to themselves.  out has 4 * padded_n entries. */
+void composer_sigma(const composer_t *c, size_t padded_n, uint64_t *out);
 /* construct_dense_pi_vec (tests/scalar_gadgets_tests.rs:151,173,211,229) */
 void composer_dense_pi(const composer_t *c, fr_t *out /* n entries */);
 

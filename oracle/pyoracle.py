@@ -62,6 +62,7 @@ def lib():
         "composer_value": (Fr, [vp, u64]), "composer_selector": (P(Fr), [vp, C.c_int]),
         "composer_wire": (P(u64), [vp, C.c_int]), "composer_values_dense": (None, [vp, vp]),
         "composer_perm_count": (sz, [vp, u64]), "composer_dense_pi": (None, [vp, vp]), "composer_check": (C.c_long, [vp]),
+        "composer_sigma": (None, [vp, sz, vp]),
         "allocated_scalar_allocate": (AllocatedScalar, [vp, Fr]),
         "range_check": (u64, [vp, Fr, Fr, AllocatedScalar]), "max_bound": (u64, [vp, Fr, AllocatedScalar, P(u64)]),
         "min_bound": (u64, [vp, Fr, AllocatedScalar, u64]), "range_proof": (u64, [vp, AllocatedScalar, u64]),
@@ -213,6 +214,11 @@ class Composer:
 
     def check(self) -> int:
         return int(self.L.composer_check(self.c))
+
+    def sigma(self, padded_n: int) -> np.ndarray:
+        out = np.zeros(4 * padded_n, dtype=np.uint64)
+        self.L.composer_sigma(self.c, padded_n, out.ctypes.data)
+        return out.reshape(4, padded_n)
 
     def export(self, gate_base: int = 0, var_base: int = 0) -> dict:
         n, nv = self.n, self.num_vars

@@ -160,6 +160,14 @@ class StandardComposer:
         out["var_values"] = t.cpu().numpy().view(np.uint64)[var_base:]
         return out
 
+    def permutation(self, padded_n: int | None = None) -> torch.Tensor:
+        """sigma as int64[4, padded_n]; entry [w, i] = w' * padded_n + i' (next position of the Variable)"""
+        n = self.circuit_size()
+        padded_n = padded_n or n
+        out = torch.empty((4, padded_n), dtype=torch.int64, device=self.engine.device)
+        _chk(self._lib.pg_composer_permutation(self._h, padded_n, out.data_ptr()), "permutation")
+        return out
+
     def materialize(self) -> dict:
         """constant columns, w_4 and the wire-value columns as device tensors"""
         n, dev = self.circuit_size(), self.engine.device

@@ -17,6 +17,7 @@
 #include "range_gadgets.hpp"
 #include "scalar_gadgets.hpp"
 #include "composer.hpp"
+#include "permutation.hpp"
 
 namespace {
 

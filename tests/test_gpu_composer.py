@@ -232,3 +232,36 @@ def test_errors_do_not_crash(engine):
     with pytest.raises(pg.PgError, match="unknown Variable"):
         dev.boolean_gate(999)
     assert dev.circuit_size() == 3  # nothing was appended by the failed calls
+
+
+def test_permutation_matches_oracle_bookkeeping(engine):
+    """sigma from the device columns == the cycles of the oracle's per-gate Variable -> [WireData] map"""
+    from oracle import pyoracle as po
+    dev, ora = pg.StandardComposer(engine, 1 << 12, 1 << 13), po.Composer()
+    for padded in (3, 4, 8):
+        assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded))
+    mn, mx = 50_000, 250_000
+    wit = synth.scalars_from_ints([50_001, 250_000, 7])
+    x = dev.add_input(S(5))
+    ox = ora.add_input(synth.mont(5))
+    res = dev.range_check_batch(S(mn), S(mx), torch.from_numpy(wit.view(np.int64)).to("cuda:0"))
+    ores = [int(ora.L.range_check(ora.c, po.fr(synth.mont(mn)), po.fr(synth.mont(mx)), ora.allocate(w))) for w in wit]
+    pg.is_non_zero(dev, x, S(5))            # an assert_equal row: zero_var on an output wire
+    ora.L.is_non_zero(ora.c, ox, po.fr(synth.mont(5)))
+    y = pg.conditionally_select_one(dev, x, ores[0])
+    ora.L.conditionally_select_one(ora.c, ox, ores[0])
+    dev.constrain_to_constant(y, S(5), None)
+    ora.L.composer_constrain_to_constant(ora.c, y, po.fr(synth.mont(5)), None)
+    same(dev, ora)
+    n = dev.circuit_size()
+    padded = 1 << (n - 1).bit_length()
+    sig = dev.permutation(padded).cpu().numpy().view(np.uint64)
+    assert np.array_equal(sig, ora.sigma(padded))
+    # sigma is a permutation of the 4 * padded positions, and it only ever links positions of the same Variable
+    assert np.array_equal(np.sort(sig.reshape(-1)), np.arange(4 * padded, dtype=np.uint64))
+    exp = dev.export()
+    wires = np.stack([exp["w_l"], exp["w_r"], exp["w_o"], dev.materialize()["w_4"].cpu().numpy().view(np.uint64)])
+    src_var = wires.reshape(-1)
+    flat = sig[:, :n]
+    dst_var = np.concatenate([np.pad(wires[w], (0, padded - n)) for w in range(4)])[flat.reshape(-1).astype(np.int64)]
+    assert np.array_equal(dst_var, src_var)
