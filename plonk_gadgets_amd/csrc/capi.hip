@@ -178,7 +178,10 @@ pg_status launch(pg_engine *e, const typename GD::Args &A_in, const pg_columns *
         // inversion pre-pass: all of the call's inverses by Montgomery's trick (invert.hpp)
         const uint64_t elems = batch * GD::kInv;
         PG_TRY(ensure_inv_scratch(e, elems));
-        const uint64_t lanes_wanted = (uint64_t)e->num_cus * 4 * 64;  // one wave per SIMD
+#ifndef PG_INV_WAVES_PER_SIMD
+#define PG_INV_WAVES_PER_SIMD 1
+#endif
+        const uint64_t lanes_wanted = (uint64_t)e->num_cus * 4 * 64 * PG_INV_WAVES_PER_SIMD;
         uint64_t per_lane = (elems + lanes_wanted - 1) / lanes_wanted;
         if (per_lane < 1) per_lane = 1;
         if (per_lane > 32) per_lane = 32;

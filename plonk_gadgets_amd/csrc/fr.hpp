@@ -139,6 +139,7 @@ __device__ __forceinline__ void mac96(uint32_t a, uint32_t b, uint64_t &acc, uin
     asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(ex) : "v"(a), "v"(b) : "vcc");
 }
 
+// (Two interleaved accumulator chains per column were measured 16 % SLOWER at every occupancy: tools/fr_mul_bench.hip.)
 __device__ __forceinline__ Fr fr_mul(const Fr &x, const Fr &y) {
     const uint32_t Q[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
     uint32_t a[8], b[8], m[8], r[8];

@@ -243,7 +243,10 @@ struct ScalarMixGD {
         Fr v, y, s, a, b, inv, z;
         uint32_t err, pad[3];
     };
-    static constexpr int W = 128;
+#ifndef PG_MIX_W
+#define PG_MIX_W 64
+#endif
+    static constexpr int W = PG_MIX_W;
     static constexpr int kInv = 2;
     __device__ static Fr inv_element(const Args &A, uint64_t item, uint32_t e) {
         return e == 0 ? load_fr(A.v, item) : fr_sub(load_fr(A.a, item), load_fr(A.b, item));

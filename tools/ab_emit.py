@@ -15,10 +15,11 @@ VDIR = os.path.join(ROOT, "tools", "variants")
 
 VARIANTS = {
     "base": [],
-    "mb16": ["-DPG_MB_W=16"],
-    "mb64": ["-DPG_MB_W=64"],
-    "mb16_grid8": ["-DPG_MB_W=16", "-DPG_GRID_BLOCKS_PER_CU=8"],
-    "mb32_grid8": ["-DPG_MB_W=32", "-DPG_GRID_BLOCKS_PER_CU=8"],
+    "inv2": ["-DPG_INV_WAVES_PER_SIMD=2"],
+    "inv4": ["-DPG_INV_WAVES_PER_SIMD=4"],
+    "mix64": ["-DPG_MIX_W=64"],
+    "mix256": ["-DPG_MIX_W=256"],
+    "mix64_inv2": ["-DPG_MIX_W=64", "-DPG_INV_WAVES_PER_SIMD=2"],
 }
 
 
@@ -29,6 +30,57 @@ def build():
         out = os.path.join(VDIR, f"lib_{name}.so")
         b.build(force=True, extra_flags=flags, out=out)
         print("built", out)
+
+
+def run_c3(log2_chunk=20, rounds=4):
+    """fused scalar mix (BASELINE config C3): plan once, time invert pre-pass + emit"""
+    import numpy as np
+    import torch
+    from plonk_gadgets_amd import _lib
+    import plonk_gadgets_amd as pg
+    import bench
+    dev = torch.device("cuda", 0)
+    chunk = 1 << log2_chunk
+    ins = [torch.from_numpy(np.ascontiguousarray(x).view(np.int64)).to(dev) for x in bench.mix_inputs(chunk)]
+    roff = torch.empty((chunk + 1,), dtype=torch.int64, device=dev)
+    voff = torch.empty((chunk + 1,), dtype=torch.int64, device=dev)
+    res = torch.empty((chunk, 2), dtype=torch.int64, device=dev)
+    cols = pg.Columns.allocate(10 * chunk, 15 * chunk, dev)
+    cc = cols.as_c()
+    stream = torch.cuda.current_stream(dev)
+    sp = C.c_void_p(stream.cuda_stream)
+    libs = {}
+    for name in VARIANTS:
+        path = os.path.join(VDIR, f"lib_{name}.so")
+        if not os.path.exists(path):
+            continue
+        lib = C.CDLL(path)
+        for fn, (r, a) in _lib.SIGNATURES.items():
+            f = getattr(lib, fn)
+            f.restype, f.argtypes = r, a
+        h = C.c_void_p()
+        assert lib.pg_engine_create(0, C.byref(h)) == 0
+        lay, nerr = _lib.LayoutC(), C.c_uint64()
+        assert lib.pg_scalar_mix_plan(h, ins[0].data_ptr(), chunk, roff.data_ptr(), voff.data_ptr(), None, C.byref(lay),
+                                      C.byref(nerr), sp) == 0
+        libs[name] = (lib, h)
+    nbytes = chunk * 2320
+    times = {n: [] for n in libs}
+    for r in range(rounds + 1):
+        for name, (lib, h) in libs.items():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            st = lib.pg_scalar_mix_batch(h, *[t.data_ptr() for t in ins], chunk, roff.data_ptr(), voff.data_ptr(), 3, 5, 0,
+                                         C.byref(cc), res.data_ptr(), sp)
+            assert st == 0
+            e1.record(stream)
+            torch.cuda.synchronize()
+            if r:
+                times[name].append(e0.elapsed_time(e1))
+    for name, ts in times.items():
+        ts = sorted(ts)
+        print(json.dumps({"variant": name, "flags": VARIANTS[name], "median_ms": ts[len(ts) // 2], "min_ms": ts[0],
+                          "gbps_median": nbytes / ts[len(ts) // 2] / 1e6}))
 
 
 def run_c4(log2_chunk=19, rounds=4):
@@ -136,6 +188,8 @@ def run(log2_chunk=18, rounds=4):
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build()
+    elif sys.argv[1] == "run_c3":
+        run_c3(*(int(x) for x in sys.argv[2:]))
     elif sys.argv[1] == "run_c4":
         run_c4(*(int(x) for x in sys.argv[2:]))
     else:

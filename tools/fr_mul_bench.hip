@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../plonk_gadgets_amd/csrc/fr.hpp"
@@ -24,8 +25,8 @@ __global__ __launch_bounds__(256) void chain_kernel(const Fr *in, Fr *out, int i
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-int main() {
-    const int blocks = 256 * 8, threads = 256, iters = 2000;
+int main(int argc, char **argv) {
+    const int blocks = argc > 1 ? atoi(argv[1]) : 256 * 8, threads = argc > 2 ? atoi(argv[2]) : 256, iters = 2000;
     const size_t n = (size_t)blocks * threads;
     std::vector<Fr> h(2 * n);
     uint64_t s = 0x9e3779b97f4a7c15ull;
@@ -50,7 +51,7 @@ int main() {
             CK(hipEventSynchronize(e1));
             float ms;
             CK(hipEventElapsedTime(&ms, e0, e1));
-            if (rep) printf("variant %d: %.3f ms, %.3e mont-mul/s\n", variant, ms, 2.0 * iters * n / (ms * 1e-3));
+            if (rep) printf("variant %d (%d blocks x %d): %.3f ms, %.3e mont-mul/s\n", variant, blocks, threads, ms, 2.0 * iters * n / (ms * 1e-3));
         }
     }
     std::vector<Fr> o0(n), o1(n);
