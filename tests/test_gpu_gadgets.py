@@ -214,3 +214,110 @@ def test_scalar_mix_golden(engine):
     torch.cuda.synchronize()
     assert_cols(cols.to_numpy(), g)
     assert np.array_equal(u64(res), g["result_vars"]) and err.cpu().numpy().tolist() == g["err_mask"].tolist()
+
+
+# ---- canaries: no emitter writes outside the ranges its layout announces ------------------------
+
+PAD = 24  # rows / variables of guard on each side of every column
+
+
+def guarded_columns(n_gates, n_vars):
+    import plonk_gadgets_amd as pg
+    big = pg.Columns.allocate(n_gates + 2 * PAD, n_vars + 2 * PAD, "cuda:0")
+    for name in COLS:
+        getattr(big, name).fill_(0x5A5A5A5A5A5A5A5A)
+    view = pg.Columns(*[getattr(big, n)[PAD:PAD + n_gates] for n in COLS[:8]], big.var_values[PAD:PAD + n_vars])
+    return big, view
+
+
+def assert_guards_intact(big, n_gates, n_vars):
+    for name in COLS:
+        t = getattr(big, name)
+        n = n_vars if name == "var_values" else n_gates
+        assert bool((t[:PAD] == 0x5A5A5A5A5A5A5A5A).all()) and bool((t[PAD + n:] == 0x5A5A5A5A5A5A5A5A).all()), name
+        assert bool((t[PAD:PAD + n] != 0x5A5A5A5A5A5A5A5A).any()) or n == 0, name
+
+
+@pytest.mark.parametrize("batch", [1, 15, 33, 257])
+def test_no_writes_outside_layout(engine, batch):
+    import ctypes as C
+    import plonk_gadgets_amd as pg
+    from plonk_gadgets_amd import _lib
+    lib, h, st = engine._lib, engine._h, engine._stream()
+    wit = dev(synth.random_scalars(batch, 3))
+    # range_check, n = 19
+    mn, mx = pg.BlsScalar.from_int(50_000), pg.BlsScalar.from_int(250_000)
+    lay = engine.range_check_layout(mn, mx, batch)
+    big, view = guarded_columns(lay.n_gates, lay.n_vars)
+    engine.range_check_batch(mn, mx, wit, 3, 5, out=view)
+    torch.cuda.synchronize()
+    assert_guards_intact(big, lay.n_gates, lay.n_vars)
+    # max_bound uniform, n = 129
+    mxb = pg.BlsScalar.from_int(2**128 - 1)
+    lay = engine.max_bound_layout(mxb, batch)
+    big, view = guarded_columns(lay.n_gates, lay.n_vars)
+    engine.max_bound_batch(mxb, wit, 3, 5, out=view)
+    torch.cuda.synchronize()
+    assert_guards_intact(big, lay.n_gates, lay.n_vars)
+    # max_bound ragged
+    bounds = dev(synth.scalars_from_ints([(int(x) % 2**60) << (int(x) % 190) for x in synth.splitmix64(batch, 8)]))
+    nb = torch.empty((batch,), dtype=torch.int32, device="cuda:0")
+    roff = torch.empty((batch + 1,), dtype=torch.int64, device="cuda:0")
+    voff = torch.empty((batch + 1,), dtype=torch.int64, device="cuda:0")
+    lc = _lib.LayoutC()
+    assert lib.pg_max_bound_ragged_plan(h, bounds.data_ptr(), batch, nb.data_ptr(), roff.data_ptr(), voff.data_ptr(),
+                                        C.byref(lc), st) == 0
+    big, view = guarded_columns(int(lc.n_gates), int(lc.n_vars))
+    cc = view.as_c()
+    assert lib.pg_max_bound_ragged_batch(h, bounds.data_ptr(), wit.data_ptr(), batch, nb.data_ptr(), roff.data_ptr(),
+                                         voff.data_ptr(), 3, 5, C.byref(cc), None, st) == 0
+    torch.cuda.synchronize()
+    assert_guards_intact(big, int(lc.n_gates), int(lc.n_vars))
+    # the fused mix with some failing items
+    v, y, s, a, b = mix_inputs(batch, 5, zeros=range(0, batch, 7))
+    ins = [dev(x) for x in (v, y, s, a, b)]
+    nerr = C.c_uint64()
+    assert lib.pg_scalar_mix_plan(h, ins[0].data_ptr(), batch, roff.data_ptr(), voff.data_ptr(), None, C.byref(lc),
+                                  C.byref(nerr), st) in (0, 1)
+    big, view = guarded_columns(int(lc.n_gates), int(lc.n_vars))
+    cc = view.as_c()
+    assert lib.pg_scalar_mix_batch(h, *[t.data_ptr() for t in ins], batch, roff.data_ptr(), voff.data_ptr(), 3, 5, 0,
+                                   C.byref(cc), None, st) == 0
+    torch.cuda.synchronize()
+    assert_guards_intact(big, int(lc.n_gates), int(lc.n_vars))
+    # stand-alone scalar gadgets
+    vars_a = dev(np.arange(5, 5 + batch, dtype=np.uint64))
+    vars_b = dev(np.arange(5 + batch, 5 + 2 * batch, dtype=np.uint64))
+    for fn, per in (("pg_conditionally_select_zero_batch", 1), ("pg_conditionally_select_one_batch", 4),
+                    ("pg_maybe_equal_batch", 3)):
+        big, view = guarded_columns(per * batch, per * batch)
+        cc = view.as_c()
+        assert getattr(lib, fn)(h, vars_a.data_ptr(), ins[1].data_ptr(), vars_b.data_ptr(), ins[3].data_ptr(), batch, 3,
+                                5 + 2 * batch, C.byref(cc), None, st) == 0
+        torch.cuda.synchronize()
+        assert_guards_intact(big, per * batch, per * batch)
+
+
+def test_invalid_arguments_are_rejected(engine):
+    """NULL / misaligned pointers and non-reduced scalars come back as PG_ERR_INVALID_ARGUMENT, never as a launch"""
+    import ctypes as C
+    import plonk_gadgets_amd as pg
+    from plonk_gadgets_amd import _lib
+    lib, h, st = engine._lib, engine._h, engine._stream()
+    mn, mx = pg.BlsScalar.from_int(0), pg.BlsScalar.from_int(2**64)
+    wit = dev(synth.random_scalars(4, 1))
+    lay = engine.range_check_layout(mn, mx, 4)
+    cols = pg.Columns.allocate(lay.n_gates, lay.n_vars, "cuda:0")
+    cc = cols.as_c()
+    assert lib.pg_range_check_batch(h, C.byref(mn.c), C.byref(mx.c), None, 4, 0, 0, C.byref(cc), None, st) == 2
+    assert lib.pg_range_check_batch(h, C.byref(mn.c), C.byref(mx.c), wit.data_ptr() + 8, 4, 0, 0, C.byref(cc), None, st) == 2
+    bad = _lib.ColumnsC(*[getattr(cols, n).data_ptr() for n in COLS])
+    bad.q_l = None
+    assert lib.pg_range_check_batch(h, C.byref(mn.c), C.byref(mx.c), wit.data_ptr(), 4, 0, 0, C.byref(bad), None, st) == 2
+    bad = _lib.ColumnsC(*[getattr(cols, n).data_ptr() for n in COLS])
+    bad.var_values = cols.var_values.data_ptr() + 8
+    assert lib.pg_range_check_batch(h, C.byref(mn.c), C.byref(mx.c), wit.data_ptr(), 4, 0, 0, C.byref(bad), None, st) == 2
+    notred = _lib.Scalar.of([2**64 - 1] * 4)
+    assert lib.pg_range_check_batch(h, C.byref(mn.c), C.byref(notred), wit.data_ptr(), 4, 0, 0, C.byref(cc), None, st) == 2
+    assert lib.pg_range_check_batch(None, C.byref(mn.c), C.byref(mx.c), wit.data_ptr(), 4, 0, 0, C.byref(cc), None, st) == 2
+    assert b"NULL" in lib.pg_last_error()

@@ -15,11 +15,7 @@ VDIR = os.path.join(ROOT, "tools", "variants")
 
 VARIANTS = {
     "base": [],
-    "inv2": ["-DPG_INV_WAVES_PER_SIMD=2"],
-    "inv4": ["-DPG_INV_WAVES_PER_SIMD=4"],
-    "mix64": ["-DPG_MIX_W=64"],
-    "mix256": ["-DPG_MIX_W=256"],
-    "mix64_inv2": ["-DPG_MIX_W=64", "-DPG_INV_WAVES_PER_SIMD=2"],
+    "ablate_amul": ["-DPG_ABLATE_AMUL"],
 }
 
 
