@@ -62,6 +62,11 @@ int oracle_range_check_batch(fr_t min_range, fr_t max_range, const fr_t *witness
                              oracle_columns_t *out, uint64_t *result_vars, uint64_t *gate_base, uint64_t *var_base,
                              uint64_t *n_gates, uint64_t *n_vars);
 
+/* oracle/fast.c: the same output as oracle_range_check_batch's columns (rows relative to the call, Variables from
+ * var_base), written directly at closed-form offsets by `threads` POSIX threads, mont(2^i) from a table. */
+int oracle_range_check_fast(fr_t min_range, fr_t max_range, const fr_t *witness, size_t batch, uint64_t var_base,
+                            int threads, oracle_columns_t *out, uint64_t *result_vars);
+
 /* for i: allocate(witness[i]); max_bound(max_range[i], .) */
 int oracle_max_bound_batch(const fr_t *max_range, const fr_t *witness, size_t batch, int check, oracle_columns_t *out,
                            uint64_t *result_vars, uint64_t *num_bits, uint64_t *gate_base, uint64_t *var_base,

@@ -30,7 +30,7 @@ class Columns(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("fr.c", "composer.c", "gadgets.c", "fr.h", "composer.h", "gadgets.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("fr.c", "composer.c", "gadgets.c", "fast.c", "fr.h", "composer.h", "gadgets.h")]
     stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -72,6 +72,7 @@ def lib():
         "conditionally_select_zero": (u64, [vp, u64, u64]), "conditionally_select_one": (u64, [vp, u64, u64]),
         "is_non_zero": (C.c_int, [vp, u64, Fr]), "maybe_equal": (u64, [vp, AllocatedScalar, AllocatedScalar]),
         "oracle_range_check_batch": (C.c_int, [Fr, Fr, vp, sz, C.c_int, P(Columns), vp, P(u64), P(u64), P(u64), P(u64)]),
+        "oracle_range_check_fast": (C.c_int, [Fr, Fr, vp, sz, u64, C.c_int, P(Columns), vp]),
         "oracle_max_bound_batch": (C.c_int, [vp, vp, sz, C.c_int, P(Columns), vp, vp, P(u64), P(u64), P(u64), P(u64)]),
         "oracle_scalar_mix_batch": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_int, P(Columns), vp, vp, P(u64), P(u64),
                                             P(u64), P(u64)]),
@@ -146,6 +147,27 @@ def range_check_batch(min_mont, max_mont, witness: np.ndarray, check: bool = Tru
     assert ng.value == G * batch and nv.value == V * batch, (ng.value, nv.value, G, V, batch)
     arrs.update(result_vars=res, gate_base=gb.value, var_base=vb.value, n_gates=ng.value, n_vars=nv.value,
                 num_bits=n, satisfied=(rc == 0))
+    return arrs
+
+
+def range_check_fast(min_mont, max_mont, witness: np.ndarray, threads: int = 1, var_base: int = 5):
+    """oracle/fast.c: same columns as range_check_batch, flat arrays + mont(2^i) table + threads"""
+    L = lib()
+    witness = _as_fr_array(witness)
+    batch = witness.shape[0]
+    mn, mx = fr(min_mont), fr(max_mont)
+    n = int(L.num_bits_closest_power_of_two(L.fr_sub(mx, L.fr_from_u64(1))))
+    G, V = 4 * n + 11, 2 * n + 524
+    arrs, cols = _alloc_columns(G * batch, V * batch)
+    res = np.zeros(batch, dtype=np.uint64)
+    import time
+    for a in arrs.values():
+        a.fill(0)  # touch the pages: first-touch faults are not the algorithm's time
+    t0 = time.perf_counter()
+    rc = L.oracle_range_check_fast(mn, mx, witness.ctypes.data, batch, var_base, threads, C.byref(cols), res.ctypes.data)
+    seconds = time.perf_counter() - t0
+    assert rc == 0
+    arrs.update(result_vars=res, n_gates=G * batch, n_vars=V * batch, num_bits=n, var_base=var_base, seconds=seconds)
     return arrs
 
 
