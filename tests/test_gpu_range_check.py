@@ -248,3 +248,14 @@ def test_config_c2_full_size_properties(engine):
             assert np.array_equal(got, ora[name][s * G:(s + 1) * G] - np.uint64(s * V)), (name, i)
     del cols, vv
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("mn,mx,batch", [(0, 2**254, 4096), (2**126, 2**127 + 1, 6000), (0, 2**64, 20000)])
+def test_medium_batches_every_limb(engine, mn, mx, batch):
+    """thousands of items, every limb of every column, vs oracle/fast.c (itself pinned to the faithful restatement
+    by tests/test_oracle_fast.py): about half of the witnesses out of range for the n = 129 and n = 65 shapes"""
+    from oracle import pyoracle as po
+    wit = mixed_witnesses(mn, mx, batch // 2, seed=batch)[:batch]
+    ora = po.range_check_fast(synth.mont(mn), synth.mont(mx), wit, threads=8, var_base=5)
+    gpu = run_gpu(engine, mn, mx, wit)
+    assert_same(gpu, ora)
