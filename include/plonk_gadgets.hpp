@@ -1,0 +1,216 @@
+// plonk_gadgets.hpp -- C++ host side above the C ABI (include/plonk_gadgets_hip.h): the reference's public
+// interface, name for name, over a device-resident composer.
+//
+// The reference is a Rust library; no Rust toolchain exists in this build environment, so the host layer a Rust
+// user would get from the shim in INTEGRATION.md is provided in C++ instead (header only, links only against
+// libplonk_gadgets_hip.so).  Mirrors /root/reference/src/lib.rs:37-45:
+//     pub use allocated_scalar::AllocatedScalar;        -> plonk_gadgets::AllocatedScalar
+//     pub use errors::Error;                            -> plonk_gadgets::Error
+//     pub use range as RangeGadgets;                    -> plonk_gadgets::RangeGadgets::{range_check, max_bound}
+//     pub use scalar as ScalarGadgets;                  -> plonk_gadgets::ScalarGadgets::{conditionally_select_zero,
+//                                                          conditionally_select_one, is_non_zero, maybe_equal}
+// plus the slice of dusk_plonk::prelude the gadgets and their tests use (BlsScalar, Variable, StandardComposer).
+// Same argument order, same return shapes (Result<(), Error> is `Result`), same error behaviour; conditions on
+// which the reference panics throw std::runtime_error.  Every call runs on the GPU; nothing is computed here
+// except BlsScalar host arithmetic for forming public arguments.
+#pragma once
+
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "plonk_gadgets_hip.h"
+
+namespace plonk_gadgets {
+
+// src/errors.rs:13-18
+enum class Error { NonExistingInverse };
+
+// Result<(), Error>
+struct Result {
+    std::optional<Error> err;
+    bool is_ok() const { return !err.has_value(); }
+    bool is_err() const { return err.has_value(); }
+};
+
+inline void pg_throw(pg_status st, const char *where) {
+    if (st != PG_OK) throw std::runtime_error(std::string(where) + ": " + pg_status_string(st) + " (" + pg_last_error() + ")");
+}
+
+// dusk_plonk::bls12_381::BlsScalar: 4 x u64 Montgomery limbs
+class BlsScalar {
+  public:
+    pg_scalar s{};
+    BlsScalar() = default;
+    explicit BlsScalar(const pg_scalar &raw) : s(raw) {}
+    static BlsScalar from(uint64_t v) { BlsScalar r; pg_scalar_from_u64(v, &r.s); return r; }
+    static BlsScalar zero() { return from(0); }
+    static BlsScalar one() { return from(1); }
+    // canonical little-endian limbs -> scalar
+    static BlsScalar from_raw(const uint64_t raw[4]) { BlsScalar r; pg_scalar_from_canonical(raw, &r.s); return r; }
+    // BlsScalar::from(2).pow(&[e, 0, 0, 0]) as the reference's tests write it
+    static BlsScalar pow_of_2(uint64_t e) {
+        BlsScalar r = one(), two = from(2);
+        for (uint64_t i = 0; i < e; i++) r = r * two;
+        return r;
+    }
+    BlsScalar operator+(const BlsScalar &o) const { BlsScalar r; pg_scalar_add(&s, &o.s, &r.s); return r; }
+    BlsScalar operator-(const BlsScalar &o) const { BlsScalar r; pg_scalar_sub(&s, &o.s, &r.s); return r; }
+    BlsScalar operator*(const BlsScalar &o) const { BlsScalar r; pg_scalar_mul(&s, &o.s, &r.s); return r; }
+    BlsScalar operator-() const { BlsScalar r; pg_scalar_neg(&s, &r.s); return r; }
+    bool operator==(const BlsScalar &o) const {
+        return s.l[0] == o.s.l[0] && s.l[1] == o.s.l[1] && s.l[2] == o.s.l[2] && s.l[3] == o.s.l[3];
+    }
+    bool operator!=(const BlsScalar &o) const { return !(*this == o); }
+};
+
+// dusk_plonk::constraint_system::Variable(usize)
+struct Variable {
+    uint64_t index = 0;
+    bool operator==(const Variable &o) const { return index == o.index; }
+};
+
+class Engine {
+  public:
+    pg_engine *h = nullptr;
+    explicit Engine(int device = 0) { pg_throw(pg_engine_create(device, &h), "pg_engine_create"); }
+    ~Engine() { pg_engine_destroy(h); }
+    Engine(const Engine &) = delete;
+    Engine &operator=(const Engine &) = delete;
+};
+
+// dusk_plonk::constraint_system::StandardComposer, the slice the gadgets and their tests call
+class StandardComposer {
+  public:
+    pg_composer *h = nullptr;
+    // StandardComposer::new()
+    explicit StandardComposer(Engine &e, uint64_t gate_capacity = 1 << 16, uint64_t var_capacity = 1 << 16) {
+        pg_throw(pg_composer_create(e.h, gate_capacity, var_capacity, 1, nullptr, &h), "pg_composer_create");
+    }
+    ~StandardComposer() { pg_composer_destroy(h); }
+    StandardComposer(const StandardComposer &) = delete;
+    StandardComposer &operator=(const StandardComposer &) = delete;
+
+    uint64_t circuit_size() const { return pg_composer_circuit_size(h); }
+    uint64_t num_variables() const { return pg_composer_num_variables(h); }
+    Variable zero_var() const { return Variable{pg_composer_zero_var(h)}; }
+
+    Variable add_input(const BlsScalar &s) {
+        Variable v;
+        pg_throw(pg_composer_add_input(h, &s.s, &v.index), "add_input");
+        return v;
+    }
+    Variable add_witness_to_circuit_description(const BlsScalar &value) {
+        Variable v;
+        pg_throw(pg_composer_add_witness_to_circuit_description(h, &value.s, &v.index), "add_witness_to_circuit_description");
+        return v;
+    }
+    void constrain_to_constant(Variable a, const BlsScalar &constant, const std::optional<BlsScalar> &pi) {
+        pg_throw(pg_composer_constrain_to_constant(h, a.index, &constant.s, pi ? &pi->s : nullptr), "constrain_to_constant");
+    }
+    void assert_equal(Variable a, Variable b) { pg_throw(pg_composer_assert_equal(h, a.index, b.index), "assert_equal"); }
+    void poly_gate(Variable a, Variable b, Variable c, const BlsScalar &q_m, const BlsScalar &q_l, const BlsScalar &q_r,
+                   const BlsScalar &q_o, const BlsScalar &q_c, const std::optional<BlsScalar> &pi) {
+        pg_throw(pg_composer_poly_gate(h, a.index, b.index, c.index, &q_m.s, &q_l.s, &q_r.s, &q_o.s, &q_c.s, pi ? &pi->s : nullptr),
+                 "poly_gate");
+    }
+    Variable add(std::pair<BlsScalar, Variable> q_l_a, std::pair<BlsScalar, Variable> q_r_b, const BlsScalar &q_c,
+                 const std::optional<BlsScalar> &pi) {
+        Variable v;
+        pg_throw(pg_composer_add(h, &q_l_a.first.s, q_l_a.second.index, &q_r_b.first.s, q_r_b.second.index, &q_c.s,
+                                 pi ? &pi->s : nullptr, &v.index), "add");
+        return v;
+    }
+    Variable mul(const BlsScalar &q_m, Variable a, Variable b, const BlsScalar &q_c, const std::optional<BlsScalar> &pi) {
+        Variable v;
+        pg_throw(pg_composer_mul(h, &q_m.s, a.index, b.index, &q_c.s, pi ? &pi->s : nullptr, &v.index), "mul");
+        return v;
+    }
+    void mul_gate(Variable a, Variable b, Variable c, const BlsScalar &q_m, const BlsScalar &q_o, const BlsScalar &q_c,
+                  const std::optional<BlsScalar> &pi) {
+        pg_throw(pg_composer_mul_gate(h, a.index, b.index, c.index, &q_m.s, &q_o.s, &q_c.s, pi ? &pi->s : nullptr), "mul_gate");
+    }
+    Variable boolean_gate(Variable a) {
+        pg_throw(pg_composer_boolean_gate(h, a.index), "boolean_gate");
+        return a;
+    }
+
+    // what prove + verify establish in the reference's tests, restricted to gate satisfiability:
+    // -1 when every row holds, else the first failing row
+    int64_t check() {
+        int64_t bad = 0;
+        pg_throw(pg_composer_check(h, &bad), "check");
+        return bad;
+    }
+    BlsScalar value(Variable v) {
+        BlsScalar r;
+        pg_throw(pg_composer_read_value(h, v.index, &r.s), "read_value");
+        return r;
+    }
+};
+
+// src/allocated_scalar.rs:17-30
+struct AllocatedScalar {
+    Variable var;
+    BlsScalar scalar;
+    static AllocatedScalar allocate(StandardComposer &composer, const BlsScalar &scalar) {
+        pg_allocated_scalar out;
+        pg_throw(pg_allocated_scalar_allocate(composer.h, &scalar.s, &out), "AllocatedScalar::allocate");
+        return AllocatedScalar{Variable{out.var}, BlsScalar(out.scalar)};
+    }
+    pg_allocated_scalar c() const { return pg_allocated_scalar{var.index, scalar.s}; }
+};
+
+namespace RangeGadgets {
+// src/range.rs:27-32
+inline Variable range_check(StandardComposer &composer, const BlsScalar &min_range, const BlsScalar &max_range,
+                            const AllocatedScalar &witness) {
+    Variable out;
+    const pg_allocated_scalar w = witness.c();
+    pg_throw(pg_range_check(composer.h, &min_range.s, &max_range.s, &w, &out.index), "range_check");
+    return out;
+}
+// src/range.rs:82-86
+inline std::pair<Variable, uint64_t> max_bound(StandardComposer &composer, const BlsScalar &max_range,
+                                               const AllocatedScalar &witness) {
+    Variable out;
+    uint64_t num_bits = 0;
+    const pg_allocated_scalar w = witness.c();
+    pg_throw(pg_max_bound(composer.h, &max_range.s, &w, &out.index, &num_bits), "max_bound");
+    return {out, num_bits};
+}
+}  // namespace RangeGadgets
+
+namespace ScalarGadgets {
+// src/scalar.rs:21-25
+inline Variable conditionally_select_zero(StandardComposer &composer, Variable x, Variable select) {
+    Variable out;
+    pg_throw(pg_conditionally_select_zero(composer.h, x.index, select.index, &out.index), "conditionally_select_zero");
+    return out;
+}
+// src/scalar.rs:36-40
+inline Variable conditionally_select_one(StandardComposer &composer, Variable y, Variable selector) {
+    Variable out;
+    pg_throw(pg_conditionally_select_one(composer.h, y.index, selector.index, &out.index), "conditionally_select_one");
+    return out;
+}
+// src/scalar.rs:63-67
+inline Result is_non_zero(StandardComposer &composer, Variable var, const BlsScalar &value_assigned) {
+    const pg_status st = pg_is_non_zero(composer.h, var.index, &value_assigned.s);
+    if (st == PG_ERR_NON_EXISTING_INVERSE) return Result{Error::NonExistingInverse};
+    pg_throw(st, "is_non_zero");
+    return Result{};
+}
+// src/scalar.rs:105-109
+inline Variable maybe_equal(StandardComposer &composer, const AllocatedScalar &a, const AllocatedScalar &b) {
+    Variable out;
+    const pg_allocated_scalar ca = a.c(), cb = b.c();
+    pg_throw(pg_maybe_equal(composer.h, &ca, &cb, &out.index), "maybe_equal");
+    return out;
+}
+}  // namespace ScalarGadgets
+
+}  // namespace plonk_gadgets
