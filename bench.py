@@ -133,7 +133,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # PG_FORCE_DIST=1: take the multi-rank code path even with one rank (rehearsal of the RCCL calls on a 1-GPU box)
+    distributed = world > 1 or os.environ.get("PG_FORCE_DIST") == "1"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

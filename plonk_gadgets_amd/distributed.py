@@ -158,8 +158,8 @@ class GatherPipeline:
                 work.wait()
                 if consume is not None:
                     consume(self.gathered[kb], kk)
-            if self.world > 1:
-                # the collective must see the emitted chunk: order it after the compute stream
+            if dist.is_initialized():
+                # the collective is ordered after the emission on the compute stream by torch's ProcessGroup
                 work = dist.all_gather_into_tensor(self._gflat[b], self.local[b], group=self.group, async_op=True)
             else:
                 self.gathered[b][0].copy_(self.local[b])
