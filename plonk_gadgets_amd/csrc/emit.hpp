@@ -80,6 +80,24 @@ __device__ __forceinline__ void fill_common_table(uint4 *table, const uint4 *pow
     }
 }
 
+// ragged batches: item that owns tile-relative position r (off[] = exclusive prefix sums in LDS, off[Wt] = total).
+// Items much larger than a sweep step are found by walking on from the previous item; small items (a step skips
+// many of them) by bisection.
+template <bool SMALL_ITEMS>
+__device__ __forceinline__ uint32_t find_item(const uint32_t *off, uint32_t Wt, uint32_t r, uint32_t it) {
+    if constexpr (SMALL_ITEMS) {
+        uint32_t lo = it, hi = Wt;  // invariant: off[lo] <= r < off[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (off[mid] <= r) lo = mid; else hi = mid;
+        }
+        return lo;
+    } else {
+        while (r >= off[it + 1]) it++;
+        return it;
+    }
+}
+
 // GD interface (all static, all __device__):
 //   struct Args; struct ItemRec;
 //   static constexpr int  W;             items per tile (<= 256)
@@ -147,7 +165,7 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
             for (uint32_t idx = tid; idx < total; idx += kThreads) {
                 if constexpr (GD::kRagged) {
                     const uint32_t r = idx >> 1;
-                    while (r >= s_roff[it + 1]) it++;
+                    it = find_item<GD::W >= 64>(s_roff, Wt, r, it);
                     j = r - s_roff[it];
                 }
                 uint4 v[5];
@@ -179,7 +197,7 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                     if (rr >= total_rows) rr = total_rows - 1;
                     uint32_t j, vo;
                     if constexpr (GD::kRagged) {
-                        while (rr >= s_roff[it + 1]) it++;
+                        it = find_item<GD::W >= 64>(s_roff, Wt, rr, it);
                         j = rr - s_roff[it];
                         vo = s_voff[it];
                     } else {
@@ -210,7 +228,7 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
             if constexpr (!GD::kRagged) { it = k / V; k -= it * V; }
             for (uint32_t s = tid; s < total_vars; s += kThreads) {
                 if constexpr (GD::kRagged) {
-                    while (s >= s_voff[it + 1]) it++;
+                    it = find_item<GD::W >= 64>(s_voff, Wt, s, it);
                     k = s - s_voff[it];
                 }
                 FrVec val;

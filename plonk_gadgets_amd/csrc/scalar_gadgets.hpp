@@ -241,6 +241,8 @@ struct ScalarMixGD {
     using Args = ScalarMixArgs;
     struct alignas(16) ItemRec {
         Fr v, y, s, a, b, inv, z;
+        Fr sy;  // y * s, once per item (the variable sweep must stay free of multiplications: a wave that meets one
+                // slot needing a product pays the whole multiplication)
         uint32_t err, pad[3];
     };
 #ifndef PG_MIX_W
@@ -262,6 +264,7 @@ struct ScalarMixGD {
         R.err = fr_is_zero(R.v) ? 1u : 0u;
         R.inv = load_fr(A.inv, 2 * item);
         R.z = load_fr(A.inv, 2 * item + 1);
+        R.sy = fr_mul(R.y, R.s);  // scalar.rs:43
         if (A.result_vars) {
             const uint64_t vb = O.var_base + O.var_off[item];
             const uint64_t nz = R.err ? 1 : 3;
@@ -294,11 +297,10 @@ struct ScalarMixGD {
         k -= nz;
         if (k < 4) {
             if (k == 0) return fr_one();
-            const Fr sy = fr_mul(R.y, R.s);
-            if (k == 1) return sy;
+            if (k == 1) return R.sy;
             const Fr oms = fr_sub(fr_one(), R.s);
             if (k == 2) return oms;
-            return fr_add(sy, oms);
+            return fr_add(R.sy, oms);
         }
         k -= 4;
         const Fr u = fr_sub(R.a, R.b);

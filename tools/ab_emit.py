@@ -15,7 +15,9 @@ VDIR = os.path.join(ROOT, "tools", "variants")
 
 VARIANTS = {
     "base": [],
-    "ablate_amul": ["-DPG_ABLATE_AMUL"],
+    "mix128": ["-DPG_MIX_W=128"],
+    "mix256": ["-DPG_MIX_W=256"],
+    "mix32": ["-DPG_MIX_W=32"],
 }
 
 
