@@ -22,12 +22,6 @@ struct Fr {
     uint64_t l[4];
 };
 
-#if defined(__HIP_DEVICE_COMPILE__)
-#define PG_CONST_SPACE __constant__
-#else
-#define PG_CONST_SPACE
-#endif
-
 // q
 #define PG_Q0 0xffffffff00000001ull
 #define PG_Q1 0x53bda402fffe5bfeull

@@ -321,3 +321,45 @@ def test_invalid_arguments_are_rejected(engine):
     assert lib.pg_range_check_batch(h, C.byref(mn.c), C.byref(notred), wit.data_ptr(), 4, 0, 0, C.byref(cc), None, st) == 2
     assert lib.pg_range_check_batch(None, C.byref(mn.c), C.byref(mx.c), wit.data_ptr(), 4, 0, 0, C.byref(cc), None, st) == 2
     assert b"NULL" in lib.pg_last_error()
+
+
+def test_config_c4_medium_every_limb(engine):
+    """BASELINE config 4 shape: 1 500 x max_bound with random 253-bit bounds (data-dependent ladder length),
+    half of the witnesses below their bound, every limb vs the faithful oracle"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from oracle import pyoracle as po
+    mr, wt = bench.c4_inputs(1500, seed=0xC4)
+    ora = po.max_bound_batch(mr, wt)
+    assert ora["satisfied"]
+    cols, res, nb, lay = engine.max_bound_ragged_batch(dev(mr), dev(wt), 3, 5)
+    torch.cuda.synchronize()
+    assert (lay.n_gates, lay.n_vars) == (ora["n_gates"], ora["n_vars"])
+    assert_cols(cols.to_numpy(), ora)
+    assert np.array_equal(u64(res), ora["result_vars"])
+    assert nb.cpu().numpy().astype(np.uint64).tolist() == ora["num_bits"].tolist()
+    # what the gadget decides: (max - 1 - w) mod q fits the ladder's n bits.  (With 253-bit bounds that is NOT
+    # w < max for every field element: a witness close to q wraps to a small difference -- the reference's
+    # max_bound alone has the same blind spot, range_check closes it with min_bound.)
+    outcomes = [synth.to_int(cols.to_numpy()["var_values"][int(r) - 5]) for r in ora["result_vars"][:64]]
+    ns = ora["num_bits"][:64]
+    expect = [int((synth.to_int(m) - 1 - synth.to_int(w)) % Q < 2**int(n)) for w, m, n in zip(wt[:64], mr[:64], ns)]
+    assert outcomes == expect and 0 < sum(expect) < 64
+
+
+def test_config_c3_medium_every_limb(engine):
+    """BASELINE config 3 shape: 20 000 fused items (is_non_zero + conditionally_select_one + maybe_equal), b = a for
+    about half of them, every limb vs the faithful oracle"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from oracle import pyoracle as po
+    v, y, s, a, b = bench.mix_inputs(20000, seed=0xC3)
+    ora = po.scalar_mix_batch(v, y, s, a, b)
+    assert ora["satisfied"]
+    cols, res, err, nerr, lay = engine.scalar_mix_batch(dev(v), dev(y), dev(s), dev(a), dev(b), 3, 5, zero_var=0)
+    torch.cuda.synchronize()
+    assert nerr == 0 and (lay.n_gates, lay.n_vars) == (200000, 300000)
+    assert_cols(cols.to_numpy(), ora)
+    assert np.array_equal(u64(res), ora["result_vars"])
