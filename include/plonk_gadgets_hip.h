@@ -114,6 +114,14 @@ pg_status pg_range_check_batch(pg_engine *e, const pg_scalar *min_range, const p
                                const pg_columns *out, pg_variable *d_result_vars /* may be NULL */, void *stream);
 
 
+/* pg_range_check_allocated_batch: the gadget alone, on witnesses that are ALREADY allocated --
+ *     result[i] = range_check(composer, min, max, AllocatedScalar { var: d_witness_var[i], scalar: d_witness[i] });
+ * 4n+11 rows and 2n+523 variables per item (no allocate). */
+pg_status pg_range_check_allocated_batch(pg_engine *e, const pg_scalar *min_range, const pg_scalar *max_range,
+                                         const pg_variable *d_witness_var, const pg_scalar *d_witness, uint64_t batch,
+                                         uint64_t gate_base, uint64_t var_base, const pg_columns *out,
+                                         pg_variable *d_result_vars /* may be NULL */, void *stream);
+
 /* pg_max_bound_batch: one public bound for the whole batch.  For every witness i,
  *     w = AllocatedScalar::allocate(composer, witness[i]);
  *     (result[i], n) = max_bound(composer, max_range, w);             src/range.rs:82-113
@@ -122,6 +130,11 @@ pg_status pg_max_bound_layout(const pg_scalar *max_range, uint64_t batch, pg_lay
 pg_status pg_max_bound_batch(pg_engine *e, const pg_scalar *max_range, const pg_scalar *d_witness, uint64_t batch,
                              uint64_t gate_base, uint64_t var_base, const pg_columns *out,
                              pg_variable *d_result_vars /* may be NULL */, void *stream);
+
+/* same, on already-allocated witnesses: 2n+5 rows and n+261 variables per item */
+pg_status pg_max_bound_allocated_batch(pg_engine *e, const pg_scalar *max_range, const pg_variable *d_witness_var,
+                                       const pg_scalar *d_witness, uint64_t batch, uint64_t gate_base, uint64_t var_base,
+                                       const pg_columns *out, pg_variable *d_result_vars /* may be NULL */, void *stream);
 
 /* Ragged max_bound: one public bound PER ITEM (device array), so the ladder length n_i and with it the rows
  * (2 n_i + 5) and variables (n_i + 262) of an item depend on public data.  The plan computes n_i

@@ -348,9 +348,10 @@ pg_status pg_range_check_layout(const pg_scalar *min_range, const pg_scalar *max
     return PG_OK;
 }
 
-pg_status pg_range_check_batch(pg_engine *e, const pg_scalar *min_range, const pg_scalar *max_range,
-                               const pg_scalar *d_witness, uint64_t batch, uint64_t gate_base, uint64_t var_base,
-                               const pg_columns *out, pg_variable *d_result_vars, void *stream) {
+static pg_status range_check_common(pg_engine *e, const pg_scalar *min_range, const pg_scalar *max_range,
+                                    const pg_variable *d_witness_var, const pg_scalar *d_witness, uint64_t batch,
+                                    uint64_t gate_base, uint64_t var_base, const pg_columns *out,
+                                    pg_variable *d_result_vars, void *stream) {
     if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
     pg_layout lay;
     PG_TRY(pg_range_check_layout(min_range, max_range, batch, &lay));
@@ -364,9 +365,25 @@ pg_status pg_range_check_batch(pg_engine *e, const pg_scalar *min_range, const p
     A.max_range = to_fr(max_range);
     A.n = (uint32_t)lay.num_bits;
     A.witness = reinterpret_cast<const uint4 *>(d_witness);
+    A.witness_vars = d_witness_var;
     A.result_vars = d_result_vars;
     A.pow2 = e->d_pow2;
     return launch<pg::RangeCheckGD>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream);
+}
+
+pg_status pg_range_check_batch(pg_engine *e, const pg_scalar *min_range, const pg_scalar *max_range,
+                               const pg_scalar *d_witness, uint64_t batch, uint64_t gate_base, uint64_t var_base,
+                               const pg_columns *out, pg_variable *d_result_vars, void *stream) {
+    return range_check_common(e, min_range, max_range, nullptr, d_witness, batch, gate_base, var_base, out, d_result_vars, stream);
+}
+
+pg_status pg_range_check_allocated_batch(pg_engine *e, const pg_scalar *min_range, const pg_scalar *max_range,
+                                         const pg_variable *d_witness_var, const pg_scalar *d_witness, uint64_t batch,
+                                         uint64_t gate_base, uint64_t var_base, const pg_columns *out,
+                                         pg_variable *d_result_vars, void *stream) {
+    if (batch) PG_TRY(check_u64s(d_witness_var, "d_witness_var"));
+    return range_check_common(e, min_range, max_range, d_witness_var, d_witness, batch, gate_base, var_base, out,
+                              d_result_vars, stream);
 }
 
 /* ---- max_bound ------------------------------------------------------------ */
@@ -383,9 +400,9 @@ pg_status pg_max_bound_layout(const pg_scalar *max_range, uint64_t batch, pg_lay
     return PG_OK;
 }
 
-pg_status pg_max_bound_batch(pg_engine *e, const pg_scalar *max_range, const pg_scalar *d_witness, uint64_t batch,
-                             uint64_t gate_base, uint64_t var_base, const pg_columns *out, pg_variable *d_result_vars,
-                             void *stream) {
+static pg_status max_bound_common(pg_engine *e, const pg_scalar *max_range, const pg_variable *d_witness_var,
+                                  const pg_scalar *d_witness, uint64_t batch, uint64_t gate_base, uint64_t var_base,
+                                  const pg_columns *out, pg_variable *d_result_vars, void *stream) {
     if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
     pg_layout lay;
     PG_TRY(pg_max_bound_layout(max_range, batch, &lay));
@@ -397,9 +414,23 @@ pg_status pg_max_bound_batch(pg_engine *e, const pg_scalar *max_range, const pg_
     A.max_range = to_fr(max_range);
     A.n = (uint32_t)lay.num_bits;
     A.witness = reinterpret_cast<const uint4 *>(d_witness);
+    A.witness_vars = d_witness_var;
     A.result_vars = d_result_vars;
     A.pow2 = e->d_pow2;
     return launch<pg::MaxBoundGD<false>>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream);
+}
+
+pg_status pg_max_bound_batch(pg_engine *e, const pg_scalar *max_range, const pg_scalar *d_witness, uint64_t batch,
+                             uint64_t gate_base, uint64_t var_base, const pg_columns *out, pg_variable *d_result_vars,
+                             void *stream) {
+    return max_bound_common(e, max_range, nullptr, d_witness, batch, gate_base, var_base, out, d_result_vars, stream);
+}
+
+pg_status pg_max_bound_allocated_batch(pg_engine *e, const pg_scalar *max_range, const pg_variable *d_witness_var,
+                                       const pg_scalar *d_witness, uint64_t batch, uint64_t gate_base, uint64_t var_base,
+                                       const pg_columns *out, pg_variable *d_result_vars, void *stream) {
+    if (batch) PG_TRY(check_u64s(d_witness_var, "d_witness_var"));
+    return max_bound_common(e, max_range, d_witness_var, d_witness, batch, gate_base, var_base, out, d_result_vars, stream);
 }
 
 pg_status pg_max_bound_ragged_plan(pg_engine *e, const pg_scalar *d_max_range, uint64_t batch, uint32_t *d_num_bits,

@@ -276,3 +276,37 @@ class Engine:
         st = self._lib.pg_fill_bytes(self._h, dst.data_ptr(), nbytes, pattern, self._stream())
         if st != 0:
             raise PgError(st, "pg_fill_bytes")
+
+    # ---- gadgets on witnesses that are already allocated (the reference's exact argument: an AllocatedScalar) ----
+    def range_check_allocated_batch(self, min_range: BlsScalar, max_range: BlsScalar, witness_var: torch.Tensor,
+                                    witness: torch.Tensor, gate_base: int = 0, var_base: int = 0):
+        """range_check(composer, min, max, AllocatedScalar{var, scalar}) per item: no allocate, 2n+523 variables"""
+        self._check_scalars(witness)
+        batch = witness.shape[0]
+        self._check_vars(witness_var, batch)
+        lay = self.range_check_layout(min_range, max_range, batch)
+        out = Columns.allocate(lay.n_gates, lay.n_vars - batch, self.device, gate_base, var_base)
+        res = torch.empty((batch,), dtype=torch.int64, device=self.device)
+        cols = out.as_c()
+        st = self._lib.pg_range_check_allocated_batch(self._h, C.byref(min_range.c), C.byref(max_range.c),
+                                                      witness_var.data_ptr(), witness.data_ptr(), batch, gate_base,
+                                                      var_base, C.byref(cols), res.data_ptr(), self._stream())
+        if st != 0:
+            raise PgError(st, "pg_range_check_allocated_batch")
+        return out, res
+
+    def max_bound_allocated_batch(self, max_range: BlsScalar, witness_var: torch.Tensor, witness: torch.Tensor,
+                                  gate_base: int = 0, var_base: int = 0):
+        self._check_scalars(witness)
+        batch = witness.shape[0]
+        self._check_vars(witness_var, batch)
+        lay = self.max_bound_layout(max_range, batch)
+        out = Columns.allocate(lay.n_gates, lay.n_vars - batch, self.device, gate_base, var_base)
+        res = torch.empty((batch,), dtype=torch.int64, device=self.device)
+        cols = out.as_c()
+        st = self._lib.pg_max_bound_allocated_batch(self._h, C.byref(max_range.c), witness_var.data_ptr(),
+                                                    witness.data_ptr(), batch, gate_base, var_base, C.byref(cols),
+                                                    res.data_ptr(), self._stream())
+        if st != 0:
+            raise PgError(st, "pg_max_bound_allocated_batch")
+        return out, res, lay.num_bits

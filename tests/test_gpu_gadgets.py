@@ -363,3 +363,35 @@ def test_config_c3_medium_every_limb(engine):
     assert nerr == 0 and (lay.n_gates, lay.n_vars) == (200000, 300000)
     assert_cols(cols.to_numpy(), ora)
     assert np.array_equal(u64(res), ora["result_vars"])
+
+
+@pytest.mark.parametrize("batch", [1, 31, 32, 33, 100])
+def test_gadgets_on_allocated_witnesses(engine, batch):
+    """range_check / max_bound exactly as the reference takes them: on AllocatedScalars that already exist"""
+    import ctypes as C
+    import plonk_gadgets_amd as pg
+    from oracle import pyoracle as po
+    mn, mx = 50_000, 250_000
+    vals = synth.scalars_from_ints([mn + int(v) % (2 * (mx - mn)) for v in synth.splitmix64(batch, 77)])
+    for gadget in ("range_check", "max_bound"):
+        c = po.Composer()
+        ws = [c.allocate(v) for v in vals]
+        g0, v0 = c.n, c.num_vars
+        res = []
+        for w in ws:
+            if gadget == "range_check":
+                res.append(int(c.L.range_check(c.c, po.fr(synth.mont(mn)), po.fr(synth.mont(mx)), w)))
+            else:
+                nb = C.c_uint64()
+                res.append(int(c.L.max_bound(c.c, po.fr(synth.mont(mx)), w, C.byref(nb))))
+        assert c.check() == -1
+        exp = c.export(g0, v0)
+        wv = dev(np.array([w.var for w in ws], dtype=np.uint64))
+        if gadget == "range_check":
+            cols, got = engine.range_check_allocated_batch(pg.BlsScalar.from_int(mn), pg.BlsScalar.from_int(mx), wv,
+                                                           dev(vals), g0, v0)
+        else:
+            cols, got, _ = engine.max_bound_allocated_batch(pg.BlsScalar.from_int(mx), wv, dev(vals), g0, v0)
+        torch.cuda.synchronize()
+        assert_cols(cols.to_numpy(), exp)
+        assert u64(got).tolist() == res
