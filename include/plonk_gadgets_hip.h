@@ -251,6 +251,11 @@ pg_status pg_maybe_equal(pg_composer *c, const pg_allocated_scalar *a, const pg_
 pg_status pg_composer_range_check_batch(pg_composer *c, const pg_scalar *min_range, const pg_scalar *max_range,
                                         const pg_scalar *d_witness, uint64_t batch, pg_variable *d_result_vars);
 
+/* copy rows [gate_first, gate_first + n_gates) of the live columns and variables [var_first, var_first + n_vars)
+ * into caller-owned device buffers (any member of dst may be NULL); enqueued on the composer's stream */
+pg_status pg_composer_copy_out(pg_composer *c, uint64_t gate_first, uint64_t n_gates, uint64_t var_first, uint64_t n_vars,
+                               const pg_columns *dst);
+
 /* read-back and checks */
 pg_status pg_composer_read_value(pg_composer *c, pg_variable v, pg_scalar *out); /* synchronises */
 /* every row satisfies q_m a b + q_l a + q_r b + q_o c + q_4 d + q_c + PI = 0?  *first_bad = -1 or the first failing row */

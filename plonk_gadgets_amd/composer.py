@@ -139,26 +139,12 @@ class StandardComposer:
 
     def export(self, gate_base: int = 0, var_base: int = 0) -> dict:
         """numpy copy of the live columns (rows >= gate_base, variables >= var_base)"""
-        import numpy as np
-        cc = _lib.ColumnsC()
-        _chk(self._lib.pg_composer_columns(self._h, C.byref(cc)), "columns")
+        n, nv = self.circuit_size() - gate_base, self.num_variables() - var_base
+        cols = Columns.allocate(n, nv, self.engine.device, gate_base, var_base)
+        cc = cols.as_c()
+        _chk(self._lib.pg_composer_copy_out(self._h, gate_base, n, var_base, nv, C.byref(cc)), "copy_out")
         _chk(self._lib.pg_composer_sync(self._h), "sync")
-        n, nv = self.circuit_size(), self.num_variables()
-        out = {}
-        for name in Columns.SCALAR_COLS:
-            t = torch.empty((n, 4), dtype=torch.int64, device=self.engine.device)
-            if n:
-                _memcpy_d2d(t, getattr(cc, name), n * 32)
-            out[name] = t.cpu().numpy().view(np.uint64)[gate_base:]
-        for name in Columns.WIRE_COLS:
-            t = torch.empty((n,), dtype=torch.int64, device=self.engine.device)
-            if n:
-                _memcpy_d2d(t, getattr(cc, name), n * 8)
-            out[name] = t.cpu().numpy().view(np.uint64)[gate_base:]
-        t = torch.empty((nv, 4), dtype=torch.int64, device=self.engine.device)
-        _memcpy_d2d(t, cc.var_values, nv * 32)
-        out["var_values"] = t.cpu().numpy().view(np.uint64)[var_base:]
-        return out
+        return cols.to_numpy()
 
     def permutation(self, padded_n: int | None = None) -> torch.Tensor:
         """sigma as int64[4, padded_n]; entry [w, i] = w' * padded_n + i' (next position of the Variable)"""
@@ -178,15 +164,6 @@ class StandardComposer:
         fc = _lib.FullColumnsC(**{k: v.data_ptr() for k, v in t.items()})
         _chk(self._lib.pg_composer_materialize(self._h, C.byref(fc)), "materialize")
         return t
-
-
-def _memcpy_d2d(dst: torch.Tensor, src_ptr: int, nbytes: int):
-    """copy nbytes from a raw device pointer into a torch tensor (hipMemcpy through torch's runtime)"""
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    rc = hip.hipMemcpy(dst.data_ptr(), src_ptr, nbytes, 3)  # hipMemcpyDeviceToDevice
-    if rc != 0:
-        raise RuntimeError(f"hipMemcpy failed: {rc}")
 
 
 @dataclass
