@@ -16,8 +16,11 @@
  *     (Montgomery limbs, little-endian, fully reduced).
  *   - pointers named `d_*` and every pointer inside `pg_columns` are DEVICE
  *     pointers on the engine's GPU; everything else is host memory.
- *   - the caller allocates and frees every buffer; the engine owns only its
- *     constant tables.  Sizes come from the `pg_*_layout` queries.
+ *   - the caller allocates and frees every output buffer (sizes come from the
+ *     `pg_*_layout` / `pg_*_plan` queries); the engine owns only its constant
+ *     table and grow-only scratch (inverses of the current call, prefix-sum
+ *     temporaries).  Because that scratch is per engine, calls on one engine
+ *     must be issued on ONE stream at a time (one engine per stream/thread).
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *     Batch calls enqueue and return; synchronise the stream (or call
  *     pg_engine_sync) before reading results.
