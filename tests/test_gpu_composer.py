@@ -265,3 +265,20 @@ def test_permutation_matches_oracle_bookkeeping(engine):
     flat = sig[:, :n]
     dst_var = np.concatenate([np.pad(wires[w], (0, padded - n)) for w in range(4)])[flat.reshape(-1).astype(np.int64)]
     assert np.array_equal(dst_var, src_var)
+
+
+def test_permutation_on_a_batched_circuit(engine):
+    """sigma of a 300-item batched range_check circuit (n = 65: 81 303 rows, 325 k wire positions) vs the oracle"""
+    from oracle import pyoracle as po
+    mn, mx, batch = 0, 2**64, 300
+    wit = synth.uniform_below(batch, 2**64 + 2**60, seed=5)
+    dev = pg.StandardComposer(engine, 1 << 17, 1 << 18)
+    ora = po.Composer()
+    dev.range_check_batch(S(mn), S(mx), torch.from_numpy(wit.view(np.int64)).to("cuda:0"))
+    for w in wit:
+        ora.L.range_check(ora.c, po.fr(synth.mont(mn)), po.fr(synth.mont(mx)), ora.allocate(w))
+    n = dev.circuit_size()
+    assert n == ora.n == 3 + batch * 271
+    padded = 1 << (n - 1).bit_length()
+    assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded))
+    assert dev.check() == -1
