@@ -129,7 +129,15 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
     GD::fill_table(A, s_table, tid);
     __syncthreads();
 
-    for (uint32_t tile = blockIdx.x; tile < O.tiles; tile += gridDim.x) {
+    for (uint32_t t = blockIdx.x; t < O.tiles; t += gridDim.x) {
+#if defined(PG_XCD_REMAP)
+        // workgroups b and b + 8 share an XCD (round-robin dispatch): give each XCD one contiguous eighth of the tiles
+        // (bijective for any tile count; speed only, nothing depends on the placement)
+        const uint32_t q8 = O.tiles >> 3, r8 = O.tiles & 7, x = t & 7, k = t >> 3;
+        const uint32_t tile = x * q8 + (x < r8 ? x : r8) + k;
+#else
+        const uint32_t tile = t;
+#endif
         const uint64_t w0 = (uint64_t)tile * W;
         const uint32_t Wt = (uint32_t)((O.batch - w0) < (uint64_t)W ? (O.batch - w0) : (uint64_t)W);
         uint64_t row0, var0;  // tile's first row / variable relative to the call

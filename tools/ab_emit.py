@@ -15,9 +15,7 @@ VDIR = os.path.join(ROOT, "tools", "variants")
 
 VARIANTS = {
     "base": [],
-    "mix128": ["-DPG_MIX_W=128"],
-    "mix256": ["-DPG_MIX_W=256"],
-    "mix32": ["-DPG_MIX_W=32"],
+    "xcd": ["-DPG_XCD_REMAP"],
 }
 
 
