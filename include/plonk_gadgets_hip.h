@@ -283,6 +283,15 @@ pg_status pg_composer_materialize(pg_composer *c, const pg_full_columns *out);
  * map to themselves.  padded_n >= circuit_size (the prover pads to a power of two). */
 pg_status pg_composer_permutation(pg_composer *c, uint64_t padded_n, uint64_t *d_sigma);
 
+/* Satisfiability of the rows of ONE batch call whose wires all point into its own variables (the allocate-style
+ * batches: range_check, max_bound, scalar_mix): q_m a b + q_l a + q_r b + q_o c + q_c = 0 on every row, with
+ * a/b/c = var_values[wire - var_base] (a wire equal to zero_var reads as 0: is_non_zero's assert_equal row).
+ * *first_bad = -1, or the first row that fails or references any other Variable outside
+ * [var_base, var_base + n_vars).  Synchronises `stream`.  A size-independent property check: it scales to
+ * the full 2^20-item batches where a limb-for-limb comparison with the CPU oracle does not. */
+pg_status pg_check_rows(pg_engine *e, const pg_columns *cols, uint64_t n_gates, uint64_t var_base, uint64_t n_vars,
+                        pg_variable zero_var, int64_t *first_bad, void *stream);
+
 /* ---- diagnostics ----------------------------------------------------------
  * pg_fill_bytes: a bare streaming fill (16 B per lane, same store form and grid shape as the emitters) used by
  * bench.py to measure the practical HBM write ceiling on the same box. */

@@ -82,11 +82,28 @@ struct FourthWire {
 };
 
 // q_m a b + q_l a + q_r b + q_o c + q_4 d + q_c + PI == 0 on every row; first unsatisfied row -> *first_bad
-__global__ __launch_bounds__(kThreads) void check_kernel(const ComposerCols C, uint64_t n, const uint64_t *pi_gate,
-                                                        const uint4 *pi_val, uint32_t n_pi, const FourthWire *fw,
-                                                        uint32_t n_fw, unsigned long long *first_bad) {
+// var_base: Variable index of C.vars[0] (0 for a composer; the call's var_base for the columns of one batch call);
+// a wire outside [var_base, var_base + n_vars) marks the row as bad instead of being dereferenced
+// (a wire equal to zero_var reads as 0 even when zero_var lies outside the table: assert_equal's output wire)
+__global__ __launch_bounds__(kThreads) void check_kernel(const ComposerCols C, uint64_t n, uint64_t var_base, uint64_t n_vars,
+                                                        uint64_t zero_var, const uint64_t *pi_gate, const uint4 *pi_val,
+                                                        uint32_t n_pi, const FourthWire *fw, uint32_t n_fw,
+                                                        unsigned long long *first_bad) {
     for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kThreads) {
-        const Fr a = get_fr(C.vars, C.w[0][i]), b = get_fr(C.vars, C.w[1][i]), c = get_fr(C.vars, C.w[2][i]);
+        Fr val[3];
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const uint64_t w = C.w[k][i], rel = w - var_base;
+            if (rel < n_vars) val[k] = get_fr(C.vars, rel);
+            else if (w == zero_var) val[k] = fr_zero();
+            else ok = false;
+        }
+        if (!ok) {
+            atomicMin(first_bad, (unsigned long long)i);
+            continue;
+        }
+        const Fr a = val[0], b = val[1], c = val[2];
         Fr t = fr_mul(fr_mul(get_fr(C.q[0], i), a), b);
         t = fr_add(t, fr_mul(get_fr(C.q[1], i), a));
         t = fr_add(t, fr_mul(get_fr(C.q[2], i), b));

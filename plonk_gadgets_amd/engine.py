@@ -310,3 +310,13 @@ class Engine:
         if st != 0:
             raise PgError(st, "pg_max_bound_allocated_batch")
         return out, res, lay.num_bits
+
+    def check_rows(self, cols: Columns, var_base: int | None = None, zero_var: int = 0) -> int:
+        """every row of a self-contained batch satisfied?  -1, or the first failing row (device-side check)"""
+        bad = C.c_int64()
+        cc = cols.as_c()
+        st = self._lib.pg_check_rows(self._h, C.byref(cc), cols.q_m.shape[0], cols.var_base if var_base is None else var_base,
+                                     cols.var_values.shape[0], zero_var, C.byref(bad), self._stream())
+        if st != 0:
+            raise PgError(st, "pg_check_rows")
+        return bad.value

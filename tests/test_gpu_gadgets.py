@@ -395,3 +395,34 @@ def test_gadgets_on_allocated_witnesses(engine, batch):
         torch.cuda.synchronize()
         assert_cols(cols.to_numpy(), exp)
         assert u64(got).tolist() == res
+
+
+def test_check_rows_detects_corruption(engine):
+    """the device-side satisfiability check used at full size: green on good output, points at a corrupted row"""
+    import plonk_gadgets_amd as pg
+    mn, mx = pg.BlsScalar.from_int(50_000), pg.BlsScalar.from_int(250_000)
+    wit = dev(synth.random_scalars(200, 3))
+    cols, _ = engine.range_check_batch(mn, mx, wit, 3, 5)
+    assert engine.check_rows(cols) == -1
+    # n = 19: 87 rows, 562 variables per item.  Variable 2*562+3 is bit 1 of item 2's max block (used by its boolean
+    # and ladder rows); variable 1234 is bit 108 of the same block: allocated (range.rs:128-131) but on no row.
+    cols.var_values[2 * 562 + 3, 0] ^= 1   # flip one bit of a used variable
+    assert engine.check_rows(cols) == 2 * 87 + 2 + 2 * 1  # the boolean row of that bit
+    cols.var_values[2 * 562 + 3, 0] ^= 1
+    cols.var_values[1234, 0] ^= 1          # an unused bit variable: no row can notice
+    assert engine.check_rows(cols) == -1
+    cols.var_values[1234, 0] ^= 1
+    cols.q_c[4321, 2] ^= 4                 # ... of one selector
+    assert engine.check_rows(cols) == 4321
+    cols.q_c[4321, 2] ^= 4
+    cols.w_o[777] = 10**12                 # a wire pointing outside the batch's variables
+    assert engine.check_rows(cols) == 777
+    # ragged max_bound and the fused mix are self-contained as well
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    mr, wt = bench.c4_inputs(300, seed=9)
+    c4, _, _, _ = engine.max_bound_ragged_batch(dev(mr), dev(wt), 3, 5)
+    assert engine.check_rows(c4) == -1
+    c3, _, _, _, _ = engine.scalar_mix_batch(*(dev(x) for x in bench.mix_inputs(5000, seed=3)), 3, 5, zero_var=0)
+    assert engine.check_rows(c3) == -1

@@ -235,6 +235,8 @@ def test_config_c2_full_size_properties(engine):
     # every result is 1 at n = 255 (every field element fits 255 bits): the last variable of each item is mont(1)
     one = torch.tensor(np.array(synth.mont(1), dtype=np.uint64).view(np.int64), device="cuda:0")
     assert bool((vv[:, V - 1, :] == one).all())
+    # every one of the 1.08e9 rows satisfies its gate equation over the emitted variable table (device-side check)
+    assert engine.check_rows(cols, var_base=5) == -1
     idx = [0, 31, 32, 33, batch // 2 - 1, batch // 2, batch - 33, batch - 1] + [int(x) % batch for x in synth.splitmix64(8, 9)]
     ora = po.range_check_batch(synth.mont(mn), synth.mont(mx), np.ascontiguousarray(wit[idx]))
     for s, i in enumerate(idx):
