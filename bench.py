@@ -189,64 +189,40 @@ def main():
         desc = ("C2: 2^%d witnesses/GPU x (allocate + range_check(min=0,max=2^254)), n=255, 1031 rows + 1034 vars "
                 "per witness" % args.log2_batch)
     elif args.workload == "c3":
-        import ctypes as C
-        from plonk_gadgets_amd import _lib
         chunk = batch if args.log2_chunk < 0 else min(batch, 1 << args.log2_chunk)
         ins = [to_dev(x) for x in mix_inputs(batch, seed=0xC3 + rank)]
-        roff = torch.empty((chunk + 1,), dtype=torch.int64, device=dev)
-        voff = torch.empty((chunk + 1,), dtype=torch.int64, device=dev)
-        lay_c, nerr = _lib.LayoutC(), C.c_uint64()
-        st = eng._lib.pg_scalar_mix_plan(eng._h, ins[0].data_ptr(), chunk, roff.data_ptr(), voff.data_ptr(), None,
-                                         C.byref(lay_c), C.byref(nerr), eng._stream())
-        assert st == 0 and nerr.value == 0
-        rows_per_launch, vars_per_launch = int(lay_c.n_gates), int(lay_c.n_vars)
-        assert rows_per_launch == 10 * chunk and vars_per_launch == 15 * chunk
+        _, roff, voff = eng.ragged_buffers(chunk)
+        lay, nerr = eng.scalar_mix_plan(ins[0][:chunk], roff, voff)
+        assert nerr == 0 and (lay.n_gates, lay.n_vars) == (10 * chunk, 15 * chunk)
+        rows_per_launch, vars_per_launch = lay.n_gates, lay.n_vars
         cols = pg.Columns.allocate(rows_per_launch, vars_per_launch, dev)
         res = torch.empty((chunk, 2), dtype=torch.int64, device=dev)
-        cc = cols.as_c()
         read_bytes = chunk * 160
 
         def launch(c):
-            # the plan (zero test + prefix sums) is part of the pass: inputs decide the ragged layout
-            ptrs = [t[c * chunk:(c + 1) * chunk].data_ptr() for t in ins]
-            st = eng._lib.pg_scalar_mix_plan(eng._h, ptrs[0], chunk, roff.data_ptr(), voff.data_ptr(), None,
-                                             C.byref(lay_c), C.byref(nerr), eng._stream())
-            assert st == 0
-            st = eng._lib.pg_scalar_mix_batch(eng._h, *ptrs, chunk, roff.data_ptr(), voff.data_ptr(), 3, 5, 0,
-                                              C.byref(cc), res.data_ptr(), eng._stream())
-            assert st == 0
-        kernel = "pg::emit_kernel<pg::ScalarMixGD> (+ plan/scan kernels)"
+            # the plan (zero test + prefix sums) is part of the pass: the inputs decide the ragged layout
+            part = [t[c * chunk:(c + 1) * chunk] for t in ins]
+            eng.scalar_mix_plan(part[0], roff, voff)
+            eng.scalar_mix_emit(*part, roff, voff, cols, res, 3, 5, 0)
+        kernel = "pg::emit_kernel<pg::ScalarMixGD> (+ plan/scan kernels and the inversion pre-pass)"
         desc = ("C3: 2^%d items/GPU x (5 add_input + is_non_zero + conditionally_select_one + maybe_equal), one "
                 "emit launch, 10 rows + 15 vars per item" % args.log2_batch)
     else:
-        import ctypes as C
-        from plonk_gadgets_amd import _lib
         chunk = batch if args.log2_chunk < 0 else min(batch, 1 << args.log2_chunk)
+        assert batch == chunk, "c4 is timed as one launch over the whole batch"
         mr_np, wt_np = c4_inputs(batch, seed=0xC4 + rank)
         mr, wt = to_dev(mr_np), to_dev(wt_np)
-        nb = torch.empty((chunk,), dtype=torch.int32, device=dev)
-        roff = torch.empty((chunk + 1,), dtype=torch.int64, device=dev)
-        voff = torch.empty((chunk + 1,), dtype=torch.int64, device=dev)
-        lay_c = _lib.LayoutC()
-        st = eng._lib.pg_max_bound_ragged_plan(eng._h, mr.data_ptr(), chunk, nb.data_ptr(), roff.data_ptr(),
-                                               voff.data_ptr(), C.byref(lay_c), eng._stream())
-        assert st == 0
-        rows_per_launch, vars_per_launch = int(lay_c.n_gates), int(lay_c.n_vars)
+        nb, roff, voff = eng.ragged_buffers(chunk)
+        lay = eng.max_bound_ragged_plan(mr, nb, roff, voff)
+        rows_per_launch, vars_per_launch = lay.n_gates, lay.n_vars
         cols = pg.Columns.allocate(rows_per_launch, vars_per_launch, dev)
         res = torch.empty((chunk,), dtype=torch.int64, device=dev)
-        cc = cols.as_c()
         read_bytes = chunk * 64
-        assert batch == chunk, "c4 is timed as one launch over the whole batch"
 
         def launch(c):
-            st = eng._lib.pg_max_bound_ragged_plan(eng._h, mr.data_ptr(), chunk, nb.data_ptr(), roff.data_ptr(),
-                                                   voff.data_ptr(), C.byref(lay_c), eng._stream())
-            assert st == 0
-            st = eng._lib.pg_max_bound_ragged_batch(eng._h, mr.data_ptr(), wt.data_ptr(), chunk, nb.data_ptr(),
-                                                    roff.data_ptr(), voff.data_ptr(), 3, 5, C.byref(cc), res.data_ptr(),
-                                                    eng._stream())
-            assert st == 0
-        kernel = "pg::emit_kernel<pg::MaxBoundGD<true>> (+ plan/scan kernels)"
+            eng.max_bound_ragged_plan(mr, nb, roff, voff)
+            eng.max_bound_ragged_emit(mr, wt, nb, roff, voff, cols, res, 3, 5)
+        kernel = "pg::emit_kernel<pg::MaxBoundGD<true>> (+ plan/scan kernels and the inversion pre-pass)"
         desc = ("C4: 2^%d items/GPU x (allocate + max_bound(random 253-bit bound)), data-dependent ladder length, "
                 "ragged rows" % args.log2_batch)
 

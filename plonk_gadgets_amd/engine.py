@@ -320,3 +320,48 @@ class Engine:
         if st != 0:
             raise PgError(st, "pg_check_rows")
         return bad.value
+
+    # ---- two-step forms of the ragged batches (plan once into caller-owned buffers, emit many times) ------------
+    def ragged_buffers(self, batch: int):
+        """(num_bits int32[batch], row_off int64[batch+1], var_off int64[batch+1]) for the *_plan calls"""
+        return (torch.empty((batch,), dtype=torch.int32, device=self.device),
+                torch.empty((batch + 1,), dtype=torch.int64, device=self.device),
+                torch.empty((batch + 1,), dtype=torch.int64, device=self.device))
+
+    def max_bound_ragged_plan(self, max_range: torch.Tensor, num_bits, row_off, var_off) -> Layout:
+        lay = _lib.LayoutC()
+        st = self._lib.pg_max_bound_ragged_plan(self._h, max_range.data_ptr(), max_range.shape[0], num_bits.data_ptr(),
+                                                row_off.data_ptr(), var_off.data_ptr(), C.byref(lay), self._stream())
+        if st != 0:
+            raise PgError(st, "pg_max_bound_ragged_plan")
+        return self._layout(lay)
+
+    def max_bound_ragged_emit(self, max_range, witness, num_bits, row_off, var_off, out: Columns, result_vars=None,
+                              gate_base: int = 0, var_base: int = 0):
+        cols = out.as_c()
+        st = self._lib.pg_max_bound_ragged_batch(self._h, max_range.data_ptr(), witness.data_ptr(), witness.shape[0],
+                                                 num_bits.data_ptr(), row_off.data_ptr(), var_off.data_ptr(), gate_base,
+                                                 var_base, C.byref(cols),
+                                                 result_vars.data_ptr() if result_vars is not None else None, self._stream())
+        if st != 0:
+            raise PgError(st, "pg_max_bound_ragged_batch")
+
+    def scalar_mix_plan(self, v: torch.Tensor, row_off, var_off, err_mask=None):
+        """-> (Layout, err_count); PG_ERR_NON_EXISTING_INVERSE is reported through err_count, not raised"""
+        lay, nerr = _lib.LayoutC(), C.c_uint64()
+        st = self._lib.pg_scalar_mix_plan(self._h, v.data_ptr(), v.shape[0], row_off.data_ptr(), var_off.data_ptr(),
+                                          err_mask.data_ptr() if err_mask is not None else None, C.byref(lay),
+                                          C.byref(nerr), self._stream())
+        if st not in (0, 1):
+            raise PgError(st, "pg_scalar_mix_plan")
+        return self._layout(lay), int(nerr.value)
+
+    def scalar_mix_emit(self, v, y, s, a, b, row_off, var_off, out: Columns, result_vars=None, gate_base: int = 0,
+                        var_base: int = 0, zero_var: int = 0):
+        cols = out.as_c()
+        st = self._lib.pg_scalar_mix_batch(self._h, v.data_ptr(), y.data_ptr(), s.data_ptr(), a.data_ptr(), b.data_ptr(),
+                                           v.shape[0], row_off.data_ptr(), var_off.data_ptr(), gate_base, var_base, zero_var,
+                                           C.byref(cols), result_vars.data_ptr() if result_vars is not None else None,
+                                           self._stream())
+        if st != 0:
+            raise PgError(st, "pg_scalar_mix_batch")
