@@ -56,6 +56,37 @@ def range_check_sharded(engine, min_range, max_range, witness_local: torch.Tenso
     return cols, res, info
 
 
+def exchange_totals(n_gates: int, n_vars: int, device, group=None):
+    """the one real exchange of a ragged sharded batch: every rank learns every shard's (rows, variables) totals,
+    16 bytes per rank, and derives its bases by an exclusive prefix sum.  Returns (gates_per_rank, vars_per_rank)."""
+    if not dist.is_initialized():
+        return [n_gates], [n_vars]
+    world = dist.get_world_size(group)
+    mine = torch.tensor([n_gates, n_vars], dtype=torch.int64, device=device)
+    allt = torch.empty((world * 2,), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(allt, mine, group=group)
+    allt = allt.view(world, 2).cpu()
+    return [int(x) for x in allt[:, 0]], [int(x) for x in allt[:, 1]]
+
+
+def max_bound_ragged_sharded(engine, max_range_local: torch.Tensor, witness_local: torch.Tensor, gate_base: int = 0,
+                             var_base: int = 0, group=None):
+    """Ragged max_bound (one public bound per item) over ranks: every rank plans its contiguous shard, the shard
+    totals are all-gathered (exchange_totals), and each rank emits at the global numbering its prefix gives it.
+    Returns (Columns, result_vars, ShardInfo, gates_per_rank, vars_per_rank)."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    batch = witness_local.shape[0]
+    nb, roff, voff = engine.ragged_buffers(batch)
+    lay = engine.max_bound_ragged_plan(max_range_local, nb, roff, voff)
+    gates, vars_ = exchange_totals(lay.n_gates, lay.n_vars, witness_local.device, group)
+    g0, v0 = gate_base + sum(gates[:rank]), var_base + sum(vars_[:rank])
+    cols = Columns.allocate(lay.n_gates, lay.n_vars, witness_local.device, g0, v0)
+    res = torch.empty((batch,), dtype=torch.int64, device=witness_local.device)
+    engine.max_bound_ragged_emit(max_range_local, witness_local, nb, roff, voff, cols, res, g0, v0)
+    return cols, res, ShardInfo(rank, world, -1, -1, g0, v0), gates, vars_
+
+
 def _gather_1d(local: torch.Tensor, counts: list[int], group) -> torch.Tensor:
     """all-gather of per-rank tensors whose leading sizes are `counts` (equal -> one all_gather_into_tensor;
     ragged -> pad to the maximum, gather, strip)"""

@@ -45,6 +45,31 @@ class OracleEngine:
         return out, res
 
 
+    # ---- ragged max_bound stand-ins (plan = per-item ladder bits and prefix sums, emit = oracle rows relocated) ----
+    def ragged_buffers(self, batch):
+        return (torch.empty((batch,), dtype=torch.int32), torch.empty((batch + 1,), dtype=torch.int64),
+                torch.empty((batch + 1,), dtype=torch.int64))
+
+    def max_bound_ragged_plan(self, max_range, nb, roff, voff):
+        import plonk_gadgets_amd as pg
+        ns = [pg.num_bits_closest_power_of_two(pg.BlsScalar.from_limbs(m) - pg.BlsScalar.one())
+              for m in max_range.numpy().view(np.uint64)]
+        nb.copy_(torch.tensor(ns, dtype=torch.int32))
+        roff.copy_(torch.tensor(np.concatenate([[0], np.cumsum([2 * n + 5 for n in ns])]), dtype=torch.int64))
+        voff.copy_(torch.tensor(np.concatenate([[0], np.cumsum([n + 262 for n in ns])]), dtype=torch.int64))
+        return pg.Layout(0, 0, 0, int(roff[-1]), int(voff[-1]))
+
+    def max_bound_ragged_emit(self, max_range, witness, nb, roff, voff, out, result_vars=None, gate_base=0, var_base=0):
+        from oracle import pyoracle as po
+        ora = po.max_bound_batch(max_range.numpy().view(np.uint64), witness.numpy().view(np.uint64))
+        shift = np.uint64((var_base - 5) % 2**64)
+        for k in COLS:
+            a = ora[k] + shift if k.startswith("w_") else ora[k]
+            getattr(out, k).copy_(torch.from_numpy(a.view(np.int64)))
+        if result_vars is not None:
+            result_vars.copy_(torch.from_numpy((ora["result_vars"] + shift).view(np.int64)))
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -56,6 +81,12 @@ def free_port():
 def witnesses(total):
     inside = synth.scalars_from_ints([MN + int(v) % (MX - MN) for v in synth.splitmix64(total // 2, 3)])
     return np.ascontiguousarray(np.concatenate([inside, synth.random_scalars(total - total // 2, 4)]))
+
+
+def ragged_inputs():
+    bounds = synth.scalars_from_ints([200, 2**128 - 1, 100, 2**200 + 7, 3])
+    rwit = synth.scalars_from_ints([100, 2**127, 200, 5, 2])
+    return bounds, rwit
 
 
 def worker(rank, world, port, total, q):
@@ -86,6 +117,15 @@ def worker(rank, world, port, total, q):
         pipe.run(wl, per_rank, 3, 5, consume=lambda g, k: seen.append((k, g.clone())))
         out["pipe"] = [(k, g.numpy().view(np.uint64).copy()) for k, g in seen]
         out["pipe_lay"] = (pipe.lay.n_gates, pipe.lay.n_vars)
+        # ragged max_bound: uneven shards (rank 0: 3 items, rank 1: 2), per-item bounds
+        bounds, rwit = ragged_inputs()
+        lo2, hi2 = (0, 3) if rank == 0 else (3, 5)
+        rc, rr, info2, gates, vars_ = pd.max_bound_ragged_sharded(
+            eng, torch.from_numpy(bounds[lo2:hi2].view(np.int64)), torch.from_numpy(rwit[lo2:hi2].view(np.int64)), 3, 5)
+        rfull, rres = pd.gather_columns(rc, rr, gates, vars_)
+        out["ragged"] = {k: getattr(rfull, k).numpy().view(np.uint64).copy() for k in COLS}
+        out["ragged"]["result_vars"] = rres.numpy().view(np.uint64).copy()
+        out["ragged_bases"] = (info2.gate_base, info2.var_base, gates, vars_)
         q.put((rank, out))
     except Exception as e:  # surface the failure instead of leaving the parent waiting on the queue
         import traceback
@@ -116,6 +156,15 @@ def test_sharded_gather_matches_single_process(total):
     for r in range(world):
         for k in COLS + ("result_vars",):
             assert np.array_equal(got[r][k], ora[k]), (r, k)
+    # ragged sharded max_bound == the single-process oracle over all five items
+    bounds, rwit = ragged_inputs()
+    rora = po.max_bound_batch(bounds, rwit)
+    for r in range(world):
+        for k in COLS + ("result_vars",):
+            assert np.array_equal(got[r]["ragged"][k], rora[k]), (r, k)
+    ns = rora["num_bits"].tolist()
+    first3_g, first3_v = sum(2 * n + 5 for n in ns[:3]), sum(n + 262 for n in ns[:3])
+    assert got[0]["ragged_bases"][:2] == (3, 5) and got[1]["ragged_bases"][:2] == (3 + first3_g, 5 + first3_v)
     # packed chunks: gathered[src] of chunk k == the oracle rows of items src*4 + 2k .. +2, at global numbering
     G, V = 4 * ora["num_bits"] + 11, 2 * ora["num_bits"] + 524
     ng, nv = got[0]["pipe_lay"]
