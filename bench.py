@@ -269,17 +269,21 @@ def main():
     fill = None
     if not args.no_fill and rank == 0:
         nbytes = cols.q_m.numel() * 8
-        eng.fill_bytes(cols.q_m)
-        torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        reps = 5
-        for _ in range(reps):
-            eng.fill_bytes(cols.q_m)
-        e1.record(stream)
-        torch.cuda.synchronize(dev)
-        fill = {"gbps": nbytes * reps / (e0.elapsed_time(e1) / 1e3) / 1e9, "bytes_per_launch": nbytes,
-                "what": "pg::fill_kernel, 16 B/lane streaming stores over one selector column"}
+        fill = {"bytes_per_launch": nbytes,
+                "what": "pg::fill_kernel, 16 B/lane streaming stores over one selector column's buffer, written as 1 "
+                        "linear stream / as 5 concurrent parts (the emitters' shape)"}
+        for streams in (1, 5):
+            eng.fill_bytes(cols.q_m, streams)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            reps = 5
+            for _ in range(reps):
+                eng.fill_bytes(cols.q_m, streams)
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            fill["gbps_%d_stream%s" % (streams, "" if streams == 1 else "s")] = nbytes * reps / (e0.elapsed_time(e1) / 1e3) / 1e9
+        fill["gbps"] = max(v for k, v in fill.items() if k.startswith("gbps_"))
 
     # ---- N > 1: gather-inclusive rate of the chunked all-gather pipeline (bounded sample) -----------------
     allgather = None

@@ -294,9 +294,10 @@ pg_status pg_check_rows(pg_engine *e, const pg_columns *cols, uint64_t n_gates, 
 
 /* ---- diagnostics ----------------------------------------------------------
  * pg_fill_bytes: a bare streaming fill (16 B per lane, same store form and grid shape as the emitters) used by
- * bench.py to measure the practical HBM write ceiling on the same box. */
+ * bench.py to measure the practical HBM write ceiling on the same box.  The buffer is written
+ * as `streams` (1..16) equal parts advanced together, like the emitters' concurrent columns. */
 pg_status pg_fill_bytes(pg_engine *e, void *d_dst /* 16-byte aligned */, uint64_t bytes /* multiple of 16 */,
-                        uint64_t pattern, void *stream);
+                        uint32_t streams, uint64_t pattern, void *stream);
 
 #ifdef __cplusplus
 }

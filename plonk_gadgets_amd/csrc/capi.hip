@@ -559,13 +559,15 @@ pg_status pg_scalar_mix_batch(pg_engine *e, const pg_scalar *d_v, const pg_scala
     return launch<pg::ScalarMixGD>(e, A, out, batch, gate_base, var_base, zero_var, d_row_off, d_var_off, stream);
 }
 
-pg_status pg_fill_bytes(pg_engine *e, void *d_dst, uint64_t bytes, uint64_t pattern, void *stream) {
+pg_status pg_fill_bytes(pg_engine *e, void *d_dst, uint64_t bytes, uint32_t streams, uint64_t pattern, void *stream) {
     if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
     if (!d_dst || !aligned(d_dst, 16) || (bytes & 15)) return fail(PG_ERR_INVALID_ARGUMENT, "dst/bytes not 16-byte aligned");
     if (bytes == 0) return PG_OK;
     PG_HIP_TRY(hipSetDevice(e->device));
-    hipLaunchKernelGGL(pg::fill_kernel, dim3((uint32_t)e->num_cus * 8), dim3(pg::kThreads), 0,
-                       static_cast<hipStream_t>(stream), static_cast<uint4 *>(d_dst), bytes / 16, pattern);
+    if (streams < 1 || streams > 16) return fail(PG_ERR_INVALID_ARGUMENT, "streams must be in [1, 16]");
+    const uint64_t pieces = (bytes / 16 / streams + 65535) / 65536, cap = (uint64_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
+    hipLaunchKernelGGL(pg::fill_kernel, dim3((uint32_t)(pieces < cap ? pieces : cap)), dim3(pg::kThreads), 0,
+                       static_cast<hipStream_t>(stream), static_cast<uint4 *>(d_dst), bytes / 16, streams, pattern);
     PG_HIP_TRY(hipGetLastError());
     return PG_OK;
 }

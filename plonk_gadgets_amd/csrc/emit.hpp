@@ -254,13 +254,20 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
     }
 }
 
-// bare streaming fill: the practical write ceiling the emitters are compared with
-__global__ __launch_bounds__(kThreads) void fill_kernel(uint4 *dst, uint64_t n16, uint64_t pattern) {
+// bare streaming fill: the practical write ceiling the emitters are compared with.  The buffer is split into
+// `streams` equal contiguous parts that every workgroup advances together, 4 KiB per part per pass -- the emitters'
+// shape (five selector columns at once); one single linear stream measures ~18 % lower on MI355X.
+__global__ __launch_bounds__(kThreads) void fill_kernel(uint4 *dst, uint64_t n16, uint32_t streams, uint64_t pattern) {
     const uint4 v = make_uint4((uint32_t)pattern, (uint32_t)(pattern >> 32), (uint32_t)~pattern, (uint32_t)(~pattern >> 32));
-    // each workgroup walks contiguous 64 KiB pieces, grid-strided
-    constexpr uint64_t kPiece = 4096;  // uint4 per piece
-    for (uint64_t base = (uint64_t)blockIdx.x * kPiece; base < n16; base += (uint64_t)gridDim.x * kPiece)
-        for (uint64_t i = base + threadIdx.x; i < base + kPiece && i < n16; i += kThreads) store16(dst + i, v);
+    const uint64_t part = n16 / streams;       // uint4 per part (the remainder is filled by the last part's tail loop)
+    constexpr uint64_t kPiece = 65536;         // 1 MiB of each part per workgroup piece
+    for (uint64_t base = (uint64_t)blockIdx.x * kPiece; base < part; base += (uint64_t)gridDim.x * kPiece) {
+        const uint64_t end = base + kPiece < part ? base + kPiece : part;
+        for (uint64_t i = base + threadIdx.x; i < end; i += kThreads)
+            for (uint32_t s = 0; s < streams; s++) store16(dst + (uint64_t)s * part + i, v);
+    }
+    if (blockIdx.x == 0)
+        for (uint64_t i = part * streams + threadIdx.x; i < n16; i += kThreads) store16(dst + i, v);
 }
 
 // ---- exclusive prefix sums for ragged batches ---------------------------

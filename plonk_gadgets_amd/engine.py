@@ -270,10 +270,10 @@ class Engine:
         return out, res, err, nerr, lay
 
     # ---- diagnostics -----------------------------------------------------------------
-    def fill_bytes(self, dst: torch.Tensor, pattern: int = 0x0123456789ABCDEF):
-        """bare 16-B-per-lane streaming fill of `dst` (the write ceiling bench.py quotes beside the emitters)"""
+    def fill_bytes(self, dst: torch.Tensor, streams: int = 5, pattern: int = 0x0123456789ABCDEF):
+        """bare 16-B-per-lane streaming fill of `dst` as `streams` concurrent parts (the write ceiling bench.py quotes)"""
         nbytes = dst.numel() * dst.element_size()
-        st = self._lib.pg_fill_bytes(self._h, dst.data_ptr(), nbytes, pattern, self._stream())
+        st = self._lib.pg_fill_bytes(self._h, dst.data_ptr(), nbytes, streams, pattern, self._stream())
         if st != 0:
             raise PgError(st, "pg_fill_bytes")
 

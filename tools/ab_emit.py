@@ -15,7 +15,9 @@ VDIR = os.path.join(ROOT, "tools", "variants")
 
 VARIANTS = {
     "base": [],
-    "xcd": ["-DPG_XCD_REMAP"],
+    "pad24k_3percu": ["-DPG_EMIT_LDS_PAD=24576"],
+    "pad40k_2percu": ["-DPG_EMIT_LDS_PAD=40960"],
+    "pad100k_1percu": ["-DPG_EMIT_LDS_PAD=102400"],
 }
 
 
