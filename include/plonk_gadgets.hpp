@@ -182,6 +182,17 @@ inline std::pair<Variable, uint64_t> max_bound(StandardComposer &composer, const
     pg_throw(pg_max_bound(composer.h, &max_range.s, &w, &out.index, &num_bits), "max_bound");
     return {out, num_bits};
 }
+// src/range.rs:119-123 -- private in the reference (its in-file unit test calls it); exposed for the same purpose
+inline std::pair<Variable, std::vector<Variable>> scalar_decomposition_gadget(StandardComposer &composer, size_t num_bits,
+                                                                              const AllocatedScalar &witness) {
+    Variable is_equal;
+    std::vector<uint64_t> bits(num_bits ? num_bits : 1);
+    const pg_allocated_scalar w = witness.c();
+    pg_throw(pg_scalar_decomposition_gadget(composer.h, num_bits, &w, &is_equal.index, bits.data()), "scalar_decomposition_gadget");
+    std::vector<Variable> out;
+    for (size_t i = 0; i < num_bits; i++) out.push_back(Variable{bits[i]});
+    return {is_equal, out};
+}
 }  // namespace RangeGadgets
 
 namespace ScalarGadgets {

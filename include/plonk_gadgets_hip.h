@@ -125,6 +125,15 @@ pg_status pg_range_check_allocated_batch(pg_engine *e, const pg_scalar *min_rang
                                          uint64_t gate_base, uint64_t var_base, const pg_columns *out,
                                          pg_variable *d_result_vars /* may be NULL */, void *stream);
 
+/* scalar_decomposition_gadget(composer, num_bits, witness) -> (is_equal, bit Variables)   src/range.rs:119-158
+ * (private in the reference, exercised by its unit test at :205-233): per item 2*num_bits+4 rows and num_bits+260
+ * variables; the bit Variables of item i are var_base + i*(num_bits+260) + [0, num_bits), is_equal is the item's
+ * last variable.  num_bits > 256 -> PG_ERR_INVALID_ARGUMENT (the reference panics on the slice, :134). */
+pg_status pg_scalar_decomposition_layout(uint64_t num_bits, uint64_t batch, pg_layout *out);
+pg_status pg_scalar_decomposition_batch(pg_engine *e, uint64_t num_bits, const pg_variable *d_witness_var,
+                                        const pg_scalar *d_witness, uint64_t batch, uint64_t gate_base, uint64_t var_base,
+                                        const pg_columns *out, pg_variable *d_result_vars /* may be NULL */, void *stream);
+
 /* pg_max_bound_batch: one public bound for the whole batch.  For every witness i,
  *     w = AllocatedScalar::allocate(composer, witness[i]);
  *     (result[i], n) = max_bound(composer, max_range, w);             src/range.rs:82-113
@@ -244,6 +253,9 @@ pg_status pg_range_check(pg_composer *c, const pg_scalar *min_range, const pg_sc
                          const pg_allocated_scalar *witness, pg_variable *out);                           /* src/range.rs:27-43 */
 pg_status pg_max_bound(pg_composer *c, const pg_scalar *max_range, const pg_allocated_scalar *witness, pg_variable *out,
                        uint64_t *num_bits);                                                               /* src/range.rs:82-113 */
+/* src/range.rs:119-123; d_bits_out (host, may be NULL) receives the first num_bits bit Variables */
+pg_status pg_scalar_decomposition_gadget(pg_composer *c, uint64_t num_bits, const pg_allocated_scalar *witness,
+                                         pg_variable *is_equal, pg_variable *bits_out);
 pg_status pg_conditionally_select_zero(pg_composer *c, pg_variable x, pg_variable select, pg_variable *out); /* src/scalar.rs:21-27 */
 pg_status pg_conditionally_select_one(pg_composer *c, pg_variable y, pg_variable selector, pg_variable *out); /* src/scalar.rs:36-59 */
 /* PG_ERR_NON_EXISTING_INVERSE after the first variable + row were appended, like the reference (src/scalar.rs:69-79) */

@@ -6,4 +6,5 @@ this package is the thin host side: scalar helpers, buffer plumbing on torch dev
 from .scalar import BlsScalar, bits_count, num_bits_closest_power_of_two  # noqa: F401
 from .engine import Columns, Engine, Layout, NonExistingInverse, PgError  # noqa: F401
 from .composer import (AllocatedScalar, StandardComposer, Variable, conditionally_select_one,  # noqa: F401
-                       conditionally_select_zero, is_non_zero, max_bound, maybe_equal, range_check)
+                       conditionally_select_zero, is_non_zero, max_bound, maybe_equal, range_check,
+                       scalar_decomposition_gadget)

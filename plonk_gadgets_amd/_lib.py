@@ -66,6 +66,11 @@ SIGNATURES = {
                                                  C.c_uint64, C.c_uint64, _P(ColumnsC), C.c_void_p, C.c_void_p]),
     "pg_max_bound_allocated_batch": (C.c_int, [C.c_void_p, _P(Scalar), C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                                C.c_uint64, _P(ColumnsC), C.c_void_p, C.c_void_p]),
+    "pg_scalar_decomposition_layout": (C.c_int, [C.c_uint64, C.c_uint64, _P(LayoutC)]),
+    "pg_scalar_decomposition_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                                C.c_uint64, _P(ColumnsC), C.c_void_p, C.c_void_p]),
+    "pg_scalar_decomposition_gadget": (C.c_int, [C.c_void_p, C.c_uint64, _P(AllocatedScalarC), _P(C.c_uint64),
+                                                 _P(C.c_uint64)]),
     "pg_max_bound_layout": (C.c_int, [_P(Scalar), C.c_uint64, _P(LayoutC)]),
     "pg_max_bound_batch": (C.c_int, [C.c_void_p, _P(Scalar), C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                      _P(ColumnsC), C.c_void_p, C.c_void_p]),

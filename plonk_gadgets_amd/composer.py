@@ -198,6 +198,16 @@ def max_bound(composer: StandardComposer, max_range: BlsScalar, witness: Allocat
     return out.value, nb.value
 
 
+def scalar_decomposition_gadget(composer: StandardComposer, num_bits: int, witness: AllocatedScalar):
+    """src/range.rs:119-123 (private in the reference; its unit test at :205-233 calls it) -> (is_equal, bit Variables)"""
+    out = C.c_uint64()
+    bits = (C.c_uint64 * max(num_bits, 1))()
+    w = witness._c()
+    _chk(composer._lib.pg_scalar_decomposition_gadget(composer._h, num_bits, C.byref(w), C.byref(out), bits),
+         "scalar_decomposition_gadget")
+    return out.value, [int(bits[i]) for i in range(num_bits)]
+
+
 # ---- ScalarGadgets (/root/reference/src/scalar.rs) --------------------------------------------------------
 def conditionally_select_zero(composer: StandardComposer, x: Variable, select: Variable) -> Variable:
     """src/scalar.rs:21-27"""

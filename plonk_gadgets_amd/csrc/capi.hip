@@ -386,6 +386,38 @@ pg_status pg_range_check_allocated_batch(pg_engine *e, const pg_scalar *min_rang
                               d_result_vars, stream);
 }
 
+/* ---- scalar_decomposition_gadget -------------------------------------------- */
+pg_status pg_scalar_decomposition_layout(uint64_t num_bits, uint64_t batch, pg_layout *out) {
+    if (!out) return fail(PG_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (num_bits > 256) return fail(PG_ERR_INVALID_ARGUMENT, "num_bits > 256 (the reference panics: src/range.rs:134)");
+    out->num_bits = num_bits;
+    out->gates_per_item = 2 * num_bits + 4;
+    out->vars_per_item = num_bits + 260;
+    out->n_gates = out->gates_per_item * batch;
+    out->n_vars = out->vars_per_item * batch;
+    return PG_OK;
+}
+
+pg_status pg_scalar_decomposition_batch(pg_engine *e, uint64_t num_bits, const pg_variable *d_witness_var,
+                                        const pg_scalar *d_witness, uint64_t batch, uint64_t gate_base, uint64_t var_base,
+                                        const pg_columns *out, pg_variable *d_result_vars, void *stream) {
+    if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
+    pg_layout lay;
+    PG_TRY(pg_scalar_decomposition_layout(num_bits, batch, &lay));
+    if (batch == 0) return PG_OK;
+    PG_TRY(check_u64s(d_witness_var, "d_witness_var"));
+    PG_TRY(check_scalars(d_witness, "d_witness"));
+    PG_TRY(check_u64s(d_result_vars, "d_result_vars", true));
+    PG_TRY(check_columns(out));
+    pg::DecompositionGD::Args A{};
+    A.n = (uint32_t)num_bits;
+    A.witness = reinterpret_cast<const uint4 *>(d_witness);
+    A.witness_vars = d_witness_var;
+    A.result_vars = d_result_vars;
+    A.pow2 = e->d_pow2;
+    return launch<pg::DecompositionGD>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream);
+}
+
 /* ---- max_bound ------------------------------------------------------------ */
 pg_status pg_max_bound_layout(const pg_scalar *max_range, uint64_t batch, pg_layout *out) {
     if (!max_range || !out) return fail(PG_ERR_INVALID_ARGUMENT, "NULL argument");

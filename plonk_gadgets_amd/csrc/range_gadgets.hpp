@@ -348,6 +348,70 @@ struct MaxBoundGD {
     }
 };
 
+// ---- scalar_decomposition_gadget alone (range.rs:119-158): the bound block without its add row ------------------
+// Private in the reference but exercised directly by its unit test (range.rs:205-233).  The witness is an existing
+// AllocatedScalar; rows: A0 const, n x (boolean, ladder add), then maybe_equal(accumulator, witness): 2n+4 rows,
+// n+260 variables [256 bits | A_0..A_n | u z y].  Implemented as the bound block shifted by one row / one variable:
+// with the block base at -1 the block's "T" slot is exactly the sentinel kWitnessWire.
+struct DecompositionGD {
+    struct Args {
+        uint32_t n;                    // num_bits, 0..256
+        const uint4 *witness;          // assignments of the witnesses
+        const uint64_t *witness_vars;  // their Variables
+        uint64_t *result_vars;         // is_equal per item
+        const uint4 *pow2;
+        const uint4 *inv;
+    };
+    static constexpr int kInv = 1;
+    __device__ static Fr inv_element(const Args &A, uint64_t item, uint32_t) {
+        FrVec x;
+        x.v[0] = A.witness[item * 2];
+        x.v[1] = A.witness[item * 2 + 1];
+        return bound_u(x.f, fr_from_mont(x.f), A.n);
+    }
+    struct alignas(16) ItemRec {
+        BoundRec b;
+        uint32_t y, pad[3];
+    };
+    static constexpr int W = 32;
+    static constexpr bool kRagged = false, kRecInRows = false, kUsePow2 = true;
+    __device__ static const uint4 *pow2(const Args &A) { return A.pow2; }
+    __device__ static uint32_t rows_per_item(const Args &A) { return 2 * A.n + 4; }
+    __device__ static uint32_t vars_per_item(const Args &A) { return A.n + 260; }
+    __device__ static void fill_table(const Args &, uint4 *table, uint32_t tid) {
+        if (tid == T_QC_A || tid == T_QC_B) {
+            table[2 * tid] = make_uint4(0, 0, 0, 0);
+            table[2 * tid + 1] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    __device__ static void item(const Args &A, const EmitOut &O, uint64_t item, const uint4 *, ItemRec &R) {
+        FrVec x, z;
+        x.v[0] = A.witness[item * 2];
+        x.v[1] = A.witness[item * 2 + 1];
+        z.v[0] = A.inv[item * 2];
+        z.v[1] = A.inv[item * 2 + 1];
+        R.y = bound_item(x.f, A.n, z.f, R.b);
+        const uint64_t V = vars_per_item(A);
+        if (A.result_vars) A.result_vars[item] = O.var_base + item * V + (V - 1);
+    }
+    __device__ static void selectors(const Args &A, const ItemRec &, uint32_t j, const uint4 *table, uint32_t h, uint4 out[5]) {
+        uint32_t id[5];
+        bound_selector_ids(j + 1, A.n, false, id);
+        ids_to_values(id, table, h, out);
+    }
+    __device__ static void wires(const Args &A, const EmitOut &, const ItemRec &, uint64_t item, uint64_t vbase, uint32_t j,
+                                 uint64_t out[3]) {
+        uint32_t off[3];
+        bound_wire_offsets(j + 1, A.n, kWitnessWire, kWitnessWire, off);
+        const uint64_t xvar = A.witness_vars[item];
+#pragma unroll
+        for (int c = 0; c < 3; c++) out[c] = off[c] == kWitnessWire ? xvar : vbase + off[c];
+    }
+    __device__ static Fr var_value(const Args &A, const ItemRec &R, const uint4 *, uint32_t k) {
+        return bound_var_value(R.b, R.y, k + 1, A.n);
+    }
+};
+
 // plan of a ragged max_bound batch: ladder bits and row/variable counts per item (range.rs:87-90)
 __global__ __launch_bounds__(kThreads) void max_bound_plan_kernel(const uint4 *max_range, uint64_t batch, const uint4 *pow2,
                                                                  uint32_t *num_bits, uint32_t *rows, uint32_t *vars) {

@@ -5,6 +5,7 @@
 //   /root/reference/tests/scalar_gadgets_tests.rs   test_maybe_equal (:13-68), test_conditionally_select_0 (:70-122),
 //                                                   test_conditionally_select_1 (:124-178), test_is_not_zero (:180-236)
 //   /root/reference/src/range.rs:196-203            counting_scalar_bits
+//   /root/reference/src/range.rs:205-233            scalar_decomposition_test
 //
 // Where the reference calls prover.prove()/verifier.verify() (dusk-plonk's proving system: out of scope here) this
 // suite checks what that round trip establishes for the gadget layer:
@@ -300,6 +301,30 @@ static void counting_scalar_bits() {
     CHECK(pg_bits_count(&two_pow_128.s) == 129);
 }
 
+// src/range.rs:205-233
+static void scalar_decomposition_test(Engine &e) {
+    // Proving: -100 does not fit 8 bits, so is_eq = 0 and constraining it to zero holds
+    StandardComposer prover(e);
+    auto witness = AllocatedScalar::allocate(prover, -BlsScalar::from(100));
+    auto [is_eq, bits] = scalar_decomposition_gadget(prover, 8, witness);
+    prover.constrain_to_constant(is_eq, BlsScalar::zero(), std::nullopt);
+    CHECK(bits.size() == 8);
+    CHECK(prover.check() == -1);
+    // Verification: the same circuit built from witness 1
+    StandardComposer verifier(e);
+    auto vw = AllocatedScalar::allocate(verifier, BlsScalar::from(1));
+    auto [vis_eq, vbits] = scalar_decomposition_gadget(verifier, 8, vw);
+    (void)vbits;
+    verifier.constrain_to_constant(vis_eq, BlsScalar::zero(), std::nullopt);
+    CHECK(same_structure(download(prover), download(verifier)));
+    // oracle
+    composer_t *o = composer_new();
+    var_t r = ::scalar_decomposition_gadget(o, 8, allocated_scalar_allocate(o, fr_neg(fr_from_u64(100))), nullptr);
+    composer_constrain_to_constant(o, r, FR_ZERO, nullptr);
+    CHECK(equals_oracle(prover, o));
+    composer_free(o);
+}
+
 // the reference panics where these throw: unknown Variable, composer overflow
 static void panics_become_exceptions(Engine &e) {
     StandardComposer small(e, 8, 8);
@@ -316,6 +341,7 @@ int main() {
     Engine e(0);
     struct { const char *name; std::function<void()> fn; } tests[] = {
         {"counting_scalar_bits", [&] { counting_scalar_bits(); }},
+        {"scalar_decomposition_test", [&] { scalar_decomposition_test(e); }},
         {"max_bound_test", [&] { max_bound_test(e); }},
         {"range_check_test", [&] { range_check_test(e); }},
         {"test_maybe_equal", [&] { test_maybe_equal(e); }},

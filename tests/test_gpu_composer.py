@@ -282,3 +282,38 @@ def test_permutation_on_a_batched_circuit(engine):
     padded = 1 << (n - 1).bit_length()
     assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded))
     assert dev.check() == -1
+
+
+def test_scalar_decomposition_reference_unit_test(engine):
+    """src/range.rs:205-233 (scalar_decomposition_test): -100 does not fit 8 bits -> is_eq constrained to 0 holds; the
+    verifier-side circuit, built from witness 1, has the same structure"""
+    from oracle import pyoracle as po
+    built = {}
+    for name, wv in (("prover", Q - 100), ("verifier", 1)):
+        dev, ora = pg.StandardComposer(engine), po.Composer()
+        witness = pg.AllocatedScalar.allocate(dev, S(wv))
+        is_eq, bits = pg.scalar_decomposition_gadget(dev, 8, witness)
+        dev.constrain_to_constant(is_eq, S(0), None)
+        obits = (C.c_uint64 * 8)()
+        ois = int(ora.L.scalar_decomposition_gadget(ora.c, 8, ora.allocate(synth.mont(wv)), obits))
+        ora.L.composer_constrain_to_constant(ora.c, ois, po.fr(synth.mont(0)), None)
+        assert is_eq == ois and bits == list(obits)
+        same(dev, ora)
+        built[name] = dev.export()
+        # prover: -100 needs more than 8 bits -> is_eq = 0 and the circuit is satisfied; verifier's witness 1 fits
+        assert (dev.check() == -1) == (name == "prover")
+        assert dev.value(is_eq).to_int() == (0 if name == "prover" else 1)
+    for k in ("q_m", "q_l", "q_r", "q_o", "q_c", "w_l", "w_r", "w_o"):
+        assert np.array_equal(built["prover"][k], built["verifier"][k])
+    # num_bits edge cases: 0, 255, 256 bits, and > 256 (the reference panics on the slice, src/range.rs:134)
+    for nbits in (0, 1, 255, 256):
+        dev, ora = pg.StandardComposer(engine), po.Composer()
+        w = pg.AllocatedScalar.allocate(dev, S(Q - 12345))
+        is_eq, bits = pg.scalar_decomposition_gadget(dev, nbits, w)
+        ois = int(ora.L.scalar_decomposition_gadget(ora.c, nbits, ora.allocate(synth.mont(Q - 12345)), None))
+        assert is_eq == ois and len(bits) == nbits
+        same(dev, ora)
+        assert dev.check() == -1
+    dev = pg.StandardComposer(engine)
+    with pytest.raises(pg.PgError, match="num_bits"):
+        pg.scalar_decomposition_gadget(dev, 257, pg.AllocatedScalar.allocate(dev, S(5)))

@@ -27,6 +27,6 @@ def test_cpp_reference_suite_on_gpu():
     p = subprocess.run([binary], capture_output=True, text=True, timeout=600)
     print(p.stdout[-4000:], p.stderr[-2000:])
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    for name in ("counting_scalar_bits", "max_bound_test", "range_check_test", "test_maybe_equal",
+    for name in ("counting_scalar_bits", "scalar_decomposition_test", "max_bound_test", "range_check_test", "test_maybe_equal",
                  "test_conditionally_select_0", "test_conditionally_select_1", "test_is_not_zero"):
         assert f"test {name} ... ok" in p.stdout

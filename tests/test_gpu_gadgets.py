@@ -426,3 +426,31 @@ def test_check_rows_detects_corruption(engine):
     assert engine.check_rows(c4) == -1
     c3, _, _, _, _ = engine.scalar_mix_batch(*(dev(x) for x in bench.mix_inputs(5000, seed=3)), 3, 5, zero_var=0)
     assert engine.check_rows(c3) == -1
+
+
+@pytest.mark.parametrize("num_bits,batch", [(8, 5), (64, 33), (255, 70), (256, 3), (0, 4)])
+def test_scalar_decomposition_batch(engine, num_bits, batch):
+    """scalar_decomposition_gadget (src/range.rs:119-158) batched over existing witnesses vs the oracle"""
+    import ctypes as C
+    from plonk_gadgets_amd import _lib
+    from oracle import pyoracle as po
+    small = synth.scalars_from_ints([int(x) % (1 << max(num_bits, 1)) for x in synth.splitmix64(batch // 2 + 1, 4)])
+    vals = np.ascontiguousarray(np.concatenate([small, synth.random_scalars(batch, 5)])[:batch])
+    c = po.Composer()
+    ws = [c.allocate(v) for v in vals]
+    g0, v0 = c.n, c.num_vars
+    res = [int(c.L.scalar_decomposition_gadget(c.c, num_bits, w, None)) for w in ws]
+    assert c.check() == -1
+    exp = c.export(g0, v0)
+    import plonk_gadgets_amd as pg
+    lay = _lib.LayoutC()
+    assert engine._lib.pg_scalar_decomposition_layout(num_bits, batch, C.byref(lay)) == 0
+    cols = pg.Columns.allocate(int(lay.n_gates), int(lay.n_vars), "cuda:0", g0, v0)
+    cc = cols.as_c()
+    out = torch.empty((batch,), dtype=torch.int64, device="cuda:0")
+    wv = dev(np.array([w.var for w in ws], dtype=np.uint64))
+    assert engine._lib.pg_scalar_decomposition_batch(engine._h, num_bits, wv.data_ptr(), dev(vals).data_ptr(), batch, g0, v0,
+                                                     C.byref(cc), out.data_ptr(), engine._stream()) == 0
+    torch.cuda.synchronize()
+    assert_cols(cols.to_numpy(), exp)
+    assert u64(out).tolist() == res
