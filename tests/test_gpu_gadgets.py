@@ -454,3 +454,29 @@ def test_scalar_decomposition_batch(engine, num_bits, batch):
     torch.cuda.synchronize()
     assert_cols(cols.to_numpy(), exp)
     assert u64(out).tolist() == res
+
+
+def test_fuzz_very_ragged_max_bound(engine):
+    """per-item bounds of every bit length 1..255 mixed inside the same tiles (ladder lengths 2..255 side by side),
+    batch sizes around the tile width: every limb vs the faithful oracle"""
+    import random
+    from oracle import pyoracle as po
+    rng = random.Random(77)
+    for batch in (1, 15, 16, 17, 47, 120):
+        bounds, wits = [], []
+        for i in range(batch):
+            bits = rng.randrange(1, 256)
+            b = rng.randrange(1 << (bits - 1), min(1 << bits, Q))
+            bounds.append(b)
+            c = rng.random()
+            wits.append(rng.randrange(0, b) if c < 0.5 else rng.randrange(Q) if c < 0.85 else rng.choice([b - 1, b, 0, Q - 1]))
+        mr, wt = synth.scalars_from_ints(bounds), synth.scalars_from_ints(wits)
+        ora = po.max_bound_batch(mr, wt)
+        assert ora["satisfied"]
+        cols, res, nb, lay = engine.max_bound_ragged_batch(dev(mr), dev(wt), 3, 5)
+        torch.cuda.synchronize()
+        assert (lay.n_gates, lay.n_vars) == (ora["n_gates"], ora["n_vars"])
+        assert_cols(cols.to_numpy(), ora)
+        assert np.array_equal(u64(res), ora["result_vars"])
+        assert nb.cpu().numpy().astype(np.uint64).tolist() == ora["num_bits"].tolist()
+        assert engine.check_rows(cols) == -1

@@ -261,3 +261,32 @@ def test_medium_batches_every_limb(engine, mn, mx, batch):
     ora = po.range_check_fast(synth.mont(mn), synth.mont(mx), wit, threads=8, var_base=5)
     gpu = run_gpu(engine, mn, mx, wit)
     assert_same(gpu, ora)
+
+
+def test_fuzz_ladder_lengths(engine):
+    """48 random (min, max) pairs covering ladder lengths all over 2..255, random batch sizes around the tile width,
+    witnesses inside / outside / at the edges: every limb vs oracle/fast.c"""
+    from oracle import pyoracle as po
+    import random
+    rng = random.Random(20261003)
+    seen = set()
+    for trial in range(48):
+        bits = rng.choice([1, 2, 3, 7, 8, 31, 32, 33, 63, 64, 65, 127, 128, 200, 251, 252, 253, 254, 255]) if trial < 19 \
+            else rng.randrange(1, 256)
+        mx = rng.randrange(1 << (bits - 1), min(1 << bits, Q)) if bits > 1 else rng.choice([1, 2])
+        mn = rng.randrange(0, mx) if rng.random() < 0.7 else 0
+        batch = rng.choice([1, 2, 31, 32, 33, 63, 64, 65]) if trial % 3 == 0 else rng.randrange(1, 80)
+        ws = []
+        for i in range(batch):
+            c = rng.random()
+            ws.append(rng.randrange(mn, mx) if c < 0.45 and mx > mn else rng.randrange(Q) if c < 0.8
+                      else rng.choice([mn, mx - 1, mx, (mn - 1) % Q, 0, Q - 1]))
+        wit = synth.scalars_from_ints(ws)
+        ora = po.range_check_fast(synth.mont(mn), synth.mont(mx), wit, threads=4, var_base=5)
+        seen.add(ora["num_bits"])
+        gpu = run_gpu(engine, mn, mx, wit)
+        try:
+            assert_same(gpu, ora)
+        except AssertionError as e:
+            raise AssertionError(f"trial {trial}: min={mn:#x} max={mx:#x} n={ora['num_bits']} batch={batch}: {e}")
+    assert len(seen) >= 25 and {2, 252, 255} & seen
