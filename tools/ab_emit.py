@@ -15,9 +15,9 @@ VDIR = os.path.join(ROOT, "tools", "variants")
 
 VARIANTS = {
     "base": [],
-    "pad24k_3percu": ["-DPG_EMIT_LDS_PAD=24576"],
-    "pad40k_2percu": ["-DPG_EMIT_LDS_PAD=40960"],
-    "pad100k_1percu": ["-DPG_EMIT_LDS_PAD=102400"],
+    "buf_plain": ["-DPG_STORE_AUX=0"],
+    "buf_sc1": ["-DPG_STORE_AUX=16"],
+    "buf_sc0sc1": ["-DPG_STORE_AUX=17"],
 }
 
 
