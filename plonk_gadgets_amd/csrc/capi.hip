@@ -19,6 +19,12 @@
 #include "composer.hpp"
 #include "permutation.hpp"
 
+#ifndef PG_GRID_BLOCKS_PER_CU
+// more workgroups than can be resident: the dispatcher back-fills CUs as tiles finish (+6 % over a persistent
+// 8-per-CU grid on the C2 shape, tools/ab_emit.py)
+#define PG_GRID_BLOCKS_PER_CU 64
+#endif
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -92,9 +98,12 @@ struct pg_engine {
     uint64_t *d_blk_rows = nullptr, *d_blk_vars = nullptr;
     uint32_t *d_err_count = nullptr;
     uint64_t scratch_items = 0;
-    // scratch of the inversion pre-pass (grow-only): inverses and running products, 32 B per element each
-    uint4 *d_inv = nullptr, *d_prefix = nullptr;
+    // scratch of the inversion pre-pass (grow-only): running products, 32 B per element
+    uint4 *d_prefix = nullptr;
     uint64_t inv_elems = 0;
+    // the pre-pass runs on its own stream beside the rows-only emit launch
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_inv = nullptr;
 };
 
 namespace {
@@ -159,23 +168,25 @@ pg::EmitOut make_out(const pg_columns *c, uint64_t batch, int W, uint64_t gate_b
 pg_status ensure_inv_scratch(pg_engine *e, uint64_t elems) {
     if (elems <= e->inv_elems) return PG_OK;
     PG_HIP_TRY(hipSetDevice(e->device));
-    if (e->d_inv) { (void)hipFree(e->d_inv); e->d_inv = nullptr; }
     if (e->d_prefix) { (void)hipFree(e->d_prefix); e->d_prefix = nullptr; }
     e->inv_elems = 0;
-    PG_HIP_TRY(hipMalloc(&e->d_inv, elems * 2 * sizeof(uint4)));
     PG_HIP_TRY(hipMalloc(&e->d_prefix, elems * 2 * sizeof(uint4)));
     e->inv_elems = elems;
     return PG_OK;
 }
 
+// One batched gadget call = the emit kernel on the caller's stream and, for gadgets that invert, the inversion pre-pass
+// on the engine's high-priority side stream.  The two write disjoint bytes (the pre-pass owns the inverse slots of
+// the variable table), so they run concurrently; the caller's stream is made to wait for both before the call's
+// results can be consumed.
 template <class GD>
-pg_status launch(pg_engine *e, const typename GD::Args &A_in, const pg_columns *c, uint64_t batch, uint64_t gate_base,
+pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, uint64_t batch, uint64_t gate_base,
                  uint64_t var_base, uint64_t zero_var, const uint64_t *row_off, const uint64_t *var_off, void *stream) {
     if ((batch + GD::W - 1) / GD::W > 0xffffffffull) return fail(PG_ERR_INVALID_ARGUMENT, "batch too large for one call");
     PG_HIP_TRY(hipSetDevice(e->device));
-    typename GD::Args A = A_in;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const pg::EmitOut O = make_out(c, batch, GD::W, gate_base, var_base, zero_var, row_off, var_off);
     if constexpr (GD::kInv > 0) {
-        // inversion pre-pass: all of the call's inverses by Montgomery's trick (invert.hpp)
         const uint64_t elems = batch * GD::kInv;
         PG_TRY(ensure_inv_scratch(e, elems));
 #ifndef PG_INV_WAVES_PER_SIMD
@@ -187,21 +198,18 @@ pg_status launch(pg_engine *e, const typename GD::Args &A_in, const pg_columns *
         if (per_lane > 32) per_lane = 32;
         const uint64_t lanes = (elems + per_lane - 1) / per_lane;
         const uint32_t blocks = (uint32_t)((lanes + pg::kThreads - 1) / pg::kThreads);
-        hipLaunchKernelGGL(pg::batch_invert_kernel<GD>, dim3(blocks), dim3(pg::kThreads), 0,
-                           static_cast<hipStream_t>(stream), A, elems, (uint32_t)per_lane, e->d_inv, e->d_prefix);
+        PG_HIP_TRY(hipEventRecord(e->ev_fork, st));  // the pre-pass reads the call's inputs: order it after the stream
+        PG_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+        hipLaunchKernelGGL(pg::batch_invert_kernel<GD>, dim3(blocks), dim3(pg::kThreads), 0, e->side, A, O, elems,
+                           (uint32_t)per_lane, e->d_prefix);
         PG_HIP_TRY(hipGetLastError());
-        A.inv = e->d_inv;
+        PG_HIP_TRY(hipEventRecord(e->ev_inv, e->side));
     }
-    const pg::EmitOut O = make_out(c, batch, GD::W, gate_base, var_base, zero_var, row_off, var_off);
-#ifndef PG_GRID_BLOCKS_PER_CU
-// more workgroups than can be resident: the dispatcher back-fills CUs as tiles finish (+6 % over a persistent
-// 8-per-CU grid on the C2 shape, tools/ab_emit.py)
-#define PG_GRID_BLOCKS_PER_CU 64
-#endif
     const uint32_t max_blocks = (uint32_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
     const uint32_t grid = O.tiles < max_blocks ? O.tiles : max_blocks;
-    hipLaunchKernelGGL(pg::emit_kernel<GD>, dim3(grid), dim3(pg::kThreads), 0, static_cast<hipStream_t>(stream), A, O);
+    hipLaunchKernelGGL(pg::emit_kernel<GD>, dim3(grid), dim3(pg::kThreads), 0, st, A, O);
     PG_HIP_TRY(hipGetLastError());
+    if constexpr (GD::kInv > 0) PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_inv, 0));  // join
     return PG_OK;
 }
 
@@ -218,7 +226,6 @@ pg_status scalar_args(const pg_variable *a_var, const pg_scalar *a_val, const pg
     A->b_val = reinterpret_cast<const uint4 *>(b_val);
     A->result_vars = res;
     A->err_mask = nullptr;
-    A->inv = nullptr;
     return PG_OK;
 }
 
@@ -286,11 +293,20 @@ pg_status pg_engine_create(int device, pg_engine **out) {
         delete e;
         return fail(PG_ERR_HIP, "hipMalloc(pow2 table) failed");
     }
+    // the pre-pass is the critical path of a call with small items: highest priority, so its waves are placed ahead of
+    // the rows-only emit launch it runs beside
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_inv, hipEventDisableTiming) != hipSuccess) {
+        pg_engine_destroy(e);
+        return fail(PG_ERR_HIP, "creating the engine's side stream / events failed");
+    }
     hipLaunchKernelGGL(pg::pow2_table_kernel, dim3(1), dim3(64), 0, nullptr, e->d_pow2);
     hipError_t err = hipDeviceSynchronize();
     if (err != hipSuccess) {
-        (void)hipFree(e->d_pow2);
-        delete e;
+        pg_engine_destroy(e);
         return fail(PG_ERR_HIP, std::string("pow2 table kernel: ") + hipGetErrorString(err));
     }
     *out = e;
@@ -300,14 +316,16 @@ pg_status pg_engine_create(int device, pg_engine **out) {
 void pg_engine_destroy(pg_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    (void)hipFree(e->d_pow2);
+    if (e->d_pow2) (void)hipFree(e->d_pow2);
     if (e->d_rows) (void)hipFree(e->d_rows);
     if (e->d_vars) (void)hipFree(e->d_vars);
     if (e->d_blk_rows) (void)hipFree(e->d_blk_rows);
     if (e->d_blk_vars) (void)hipFree(e->d_blk_vars);
     if (e->d_err_count) (void)hipFree(e->d_err_count);
-    if (e->d_inv) (void)hipFree(e->d_inv);
     if (e->d_prefix) (void)hipFree(e->d_prefix);
+    if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_inv) (void)hipEventDestroy(e->ev_inv);
     delete e;
 }
 

@@ -110,9 +110,14 @@ __device__ __forceinline__ uint32_t find_item(const uint32_t *off, uint32_t Wt, 
 //   void selectors(A, rec, j, table, h, uint4 out[5])
 //   void wires(A, O, rec, item, item_var_base, j, uint64_t out[3])
 //   Fr   var_value(A, rec, table, k)
+//   bool is_inv_slot(A, rec, k)          item-variable k holds an inverse (written by the pre-pass, not here)
+//   int  kInv; Fr inv_element(A, item, e); uint4 *inv_slot(A, O, item, e)   the pre-pass's view (invert.hpp)
 #ifndef PG_EMIT_WAVES_PER_SIMD
 #define PG_EMIT_WAVES_PER_SIMD 1  // __launch_bounds__ second argument (waves per SIMD the register allocator must allow)
 #endif
+// Nothing this kernel writes depends on a field inversion: the variables that hold inverses (z of maybe_equal, inv of
+// is_non_zero) are written, at their final slots, by the inversion pre-pass (invert.hpp), which runs concurrently on
+// the engine's side stream; the variable sweep here skips exactly those slots (GD::is_inv_slot).
 template <class GD>
 __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(const typename GD::Args A, const EmitOut O) {
     constexpr int W = GD::W;
@@ -239,11 +244,13 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                     it = find_item<GD::W >= 64>(s_voff, Wt, s, it);
                     k = s - s_voff[it];
                 }
-                FrVec val;
-                val.f = GD::var_value(A, s_item[it], s_table, k);
-                uint4 *dst = O.vars + (var0 + s) * 2;
-                store16(dst, val.v[0]);
-                store16(dst + 1, val.v[1]);
+                if (!GD::is_inv_slot(A, s_item[it], k)) {  // inverse slots belong to the pre-pass
+                    FrVec val;
+                    val.f = GD::var_value(A, s_item[it], s_table, k);
+                    uint4 *dst = O.vars + (var0 + s) * 2;
+                    store16(dst, val.v[0]);
+                    store16(dst + 1, val.v[1]);
+                }
                 if constexpr (!GD::kRagged) {
                     k += kThreads;
                     if (k >= V) { const uint32_t d = k / V; it += d; k -= d * V; }

@@ -6,9 +6,11 @@
 // them up keeping the running products in a scratch array, inverts ONE product, and unwinds:
 //     inv(x_k) = inv(x_0..x_k) * (x_0..x_{k-1}),   inv(x_0..x_{k-1}) = inv(x_0..x_k) * x_k
 // 3 multiplications per element + 383 / G.  Zero elements are skipped and come out as zero (the reference's
-// unwrap_or(zero) at scalar.rs:122).  The emit kernel's item phase then just loads its inverses.
-// The element values themselves are recomputed from the gadget's inputs by the policy (GD::inv_element) in both
-// passes instead of being staged in memory.
+// unwrap_or(zero) at scalar.rs:122).  Each inverse goes straight to its final slot in the call's variable table
+// (GD::inv_slot; NULL when the item has no such variable -- an is_non_zero item that stopped at its error), which the
+// emit kernel leaves alone: the two kernels write disjoint bytes, so they run concurrently on two streams and the
+// call joins them at the end.  The element values themselves are recomputed from the gadget's inputs by the policy
+// (GD::inv_element) in both passes instead of being staged in memory.
 #pragma once
 
 #include "emit.hpp"
@@ -16,8 +18,11 @@
 namespace pg {
 
 template <class GD>
-__global__ __launch_bounds__(kThreads) void batch_invert_kernel(const typename GD::Args A, uint64_t n_elems, uint32_t per_lane,
-                                                               uint4 *inv, uint4 *prefix) {
+__global__ __launch_bounds__(kThreads) void batch_invert_kernel(const typename GD::Args A, const EmitOut O, uint64_t n_elems,
+                                                               uint32_t per_lane, uint4 *prefix) {
+    // this kernel is a long dependent chain of multiply-adds on one wave per SIMD and usually runs beside the
+    // rows-only emit launch: let its waves win the issue arbitration
+    __builtin_amdgcn_s_setprio(3);
     const uint64_t T = (uint64_t)gridDim.x * kThreads;
     const uint64_t gtid = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
     Fr acc = fr_one();
@@ -59,8 +64,11 @@ __global__ __launch_bounds__(kThreads) void batch_invert_kernel(const typename G
             o.f = have_prev ? fr_mul(accinv, prev) : accinv;
             accinv = fr_mul(accinv, x);
         }
-        inv[2 * s] = o.v[0];
-        inv[2 * s + 1] = o.v[1];
+        uint4 *slot = GD::inv_slot(A, O, s / GD::kInv, (uint32_t)(s % GD::kInv));
+        if (slot) {
+            slot[0] = o.v[0];
+            slot[1] = o.v[1];
+        }
     }
 }
 

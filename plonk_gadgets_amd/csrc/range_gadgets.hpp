@@ -30,8 +30,7 @@ namespace pg {
 struct alignas(16) BoundRec {
     Fr Tm;  // T in Montgomery form (the block's first variable)
     Fr Tc;  // canonical integer of T
-    Fr U;   // A_n - T
-    Fr Z;   // U^-1 or 0
+    Fr U;   // A_n - T   (its inverse z is written by the pre-pass, invert.hpp)
 };
 
 // u = accumulator - witness (scalar.rs:121) of a bound block: A_n - T with A_n = mont(T mod 2^n); 0 when T fits n bits
@@ -40,15 +39,17 @@ __device__ __forceinline__ Fr bound_u(const Fr &Tm, const Fr &Tc, uint32_t n) {
     return fr_sub(fr_to_mont(raw_low_bits(Tc, n)), Tm);
 }
 
-// per-item arithmetic of one bound block; Z = u^-1 or 0 comes from the inversion pre-pass (invert.hpp)
-__device__ __forceinline__ uint32_t bound_item(const Fr &Tm, uint32_t n, const Fr &Z, BoundRec &b) {
+// per-item arithmetic of one bound block (z = u^-1 or 0, scalar.rs:122, is the pre-pass's business)
+__device__ __forceinline__ uint32_t bound_item(const Fr &Tm, uint32_t n, BoundRec &b) {
     const Fr Tc = fr_from_mont(Tm);  // scalar_to_bits -> to_bytes, range.rs:163
     b.Tm = Tm;
     b.Tc = Tc;
     b.U = bound_u(Tm, Tc, n);
-    b.Z = Z;                         // scalar.rs:122
     return fr_is_zero(b.U) ? 1u : 0u;  // y = 1 - u z
 }
+
+// offset of z inside a bound block's variables
+__device__ __forceinline__ uint32_t bound_z_offset(uint32_t n) { return 259 + n; }
 
 // selector table ids of block row jj; is_min selects the min_bound flavour of row 0
 __device__ __forceinline__ void bound_selector_ids(uint32_t jj, uint32_t n, bool is_min, uint32_t id[5]) {
@@ -116,7 +117,7 @@ __device__ __forceinline__ Fr bound_var_value(const BoundRec &B, uint32_t y, uin
 #endif
     }
     if (kk == 258 + n) return B.U;
-    if (kk == 259 + n) return B.Z;
+    // kk == 259 + n is z: written by the pre-pass, never asked for here
     return y ? fr_one() : fr_zero();  // scalar.rs:126
 }
 
@@ -135,7 +136,6 @@ struct RangeCheckGD {
                                        // first variable; else: the existing Variables the items range-check
         uint64_t *result_vars;
         const uint4 *pow2;
-        const uint4 *inv;  // [batch][2] from the inversion pre-pass
     };
     static constexpr int kInv = 2;
     // element e of item: u of the max block (e = 0) / min block (e = 1)
@@ -146,12 +146,21 @@ struct RangeCheckGD {
         const Fr Tm = e == 0 ? fr_sub(fr_sub(A.max_range, fr_one()), x.f) : fr_sub(x.f, A.min_range);
         return bound_u(Tm, fr_from_mont(Tm), A.n);
     }
+    // z of the max block (e = 0) / min block (e = 1)
+    __device__ static uint4 *inv_slot(const Args &A, const EmitOut &O, uint64_t item, uint32_t e) {
+        const uint64_t V = 2 * A.n + 523 + (A.witness_vars ? 0u : 1u), VB = A.n + 261;
+        return O.vars + 2 * (item * V + (A.witness_vars ? 0u : 1u) + e * VB + bound_z_offset(A.n));
+    }
     struct alignas(16) ItemRec {
         Fr x;
         BoundRec b[2];
         uint32_t y[2];
         uint32_t pad[2];
     };
+    __device__ static bool is_inv_slot(const Args &A, const ItemRec &, uint32_t k) {
+        const uint32_t x0 = A.witness_vars ? 0u : 1u, VB = A.n + 261, z = bound_z_offset(A.n);
+        return k == x0 + z || k == x0 + VB + z;
+    }
 #ifndef PG_RC_W
 #define PG_RC_W 32
 #endif
@@ -179,11 +188,8 @@ struct RangeCheckGD {
         x.v[1] = A.witness[item * 2 + 1];
         R.x = x.f;
         // T = (max-1) - x  (range.rs:102)   |   T = x - min  (range.rs:69)
-        FrVec z0, z1;
-        z0.v[0] = A.inv[item * 4]; z0.v[1] = A.inv[item * 4 + 1];
-        z1.v[0] = A.inv[item * 4 + 2]; z1.v[1] = A.inv[item * 4 + 3];
-        R.y[0] = bound_item(fr_sub(lds_fr(table, T_QC_A), x.f), A.n, z0.f, R.b[0]);
-        R.y[1] = bound_item(fr_add(x.f, lds_fr(table, T_QC_B)), A.n, z1.f, R.b[1]);
+        R.y[0] = bound_item(fr_sub(lds_fr(table, T_QC_A), x.f), A.n, R.b[0]);
+        R.y[1] = bound_item(fr_add(x.f, lds_fr(table, T_QC_B)), A.n, R.b[1]);
         const uint64_t V = vars_per_item(A);
         if (A.result_vars) A.result_vars[item] = O.var_base + item * V + (V - 1);
     }
@@ -242,9 +248,14 @@ struct MaxBoundGD {
         const uint64_t *witness_vars;  // NULL: items allocate their witness; else existing Variables (uniform only)
         uint64_t *result_vars;
         const uint4 *pow2;
-        const uint4 *inv;  // [batch] from the inversion pre-pass
     };
     static constexpr int kInv = 1;
+    __device__ static uint4 *inv_slot(const Args &A, const EmitOut &O, uint64_t item, uint32_t) {
+        const uint32_t n = RAGGED ? A.num_bits_v[item] : A.n;
+        const uint32_t x0 = (!RAGGED && A.witness_vars) ? 0u : 1u;
+        const uint64_t first = RAGGED ? O.var_off[item] : item * (uint64_t)(n + 261 + x0);
+        return O.vars + 2 * (first + x0 + bound_z_offset(n));
+    }
     __device__ static Fr inv_element(const Args &A, uint64_t item, uint32_t) {
         FrVec x, m;
         x.v[0] = A.witness[item * 2];
@@ -307,10 +318,7 @@ struct MaxBoundGD {
         }
         R.qc = qc;
         R.n = n;
-        FrVec z;
-        z.v[0] = A.inv[item * 2];
-        z.v[1] = A.inv[item * 2 + 1];
-        R.y = bound_item(fr_sub(qc, x.f), n, z.f, R.b);  // range.rs:102
+        R.y = bound_item(fr_sub(qc, x.f), n, R.b);  // range.rs:102
         if (A.result_vars) {
             const uint64_t first = RAGGED ? O.var_off[item] : item * (uint64_t)(n + 261 + xo(A));
             A.result_vars[item] = O.var_base + first + (n + 260 + xo(A));  // Y is the item's last variable
@@ -339,6 +347,9 @@ struct MaxBoundGD {
         for (int c = 0; c < 3; c++) out[c] = off[c] == kWitnessWire ? xvar : vbase + off[c];
     }
 
+    __device__ static bool is_inv_slot(const Args &A, const ItemRec &R, uint32_t k) {
+        return k == xo(A) + bound_z_offset(RAGGED ? R.n : A.n);
+    }
     __device__ static Fr var_value(const Args &A, const ItemRec &R, const uint4 *, uint32_t k) {
         if (xo(A)) {
             if (k == 0) return R.x;
@@ -360,7 +371,6 @@ struct DecompositionGD {
         const uint64_t *witness_vars;  // their Variables
         uint64_t *result_vars;         // is_equal per item
         const uint4 *pow2;
-        const uint4 *inv;
     };
     static constexpr int kInv = 1;
     __device__ static Fr inv_element(const Args &A, uint64_t item, uint32_t) {
@@ -368,6 +378,10 @@ struct DecompositionGD {
         x.v[0] = A.witness[item * 2];
         x.v[1] = A.witness[item * 2 + 1];
         return bound_u(x.f, fr_from_mont(x.f), A.n);
+    }
+    // the block shifted by one variable: z sits at (259 + n) - 1
+    __device__ static uint4 *inv_slot(const Args &A, const EmitOut &O, uint64_t item, uint32_t) {
+        return O.vars + 2 * (item * (uint64_t)(A.n + 260) + bound_z_offset(A.n) - 1);
     }
     struct alignas(16) ItemRec {
         BoundRec b;
@@ -385,12 +399,10 @@ struct DecompositionGD {
         }
     }
     __device__ static void item(const Args &A, const EmitOut &O, uint64_t item, const uint4 *, ItemRec &R) {
-        FrVec x, z;
+        FrVec x;
         x.v[0] = A.witness[item * 2];
         x.v[1] = A.witness[item * 2 + 1];
-        z.v[0] = A.inv[item * 2];
-        z.v[1] = A.inv[item * 2 + 1];
-        R.y = bound_item(x.f, A.n, z.f, R.b);
+        R.y = bound_item(x.f, A.n, R.b);
         const uint64_t V = vars_per_item(A);
         if (A.result_vars) A.result_vars[item] = O.var_base + item * V + (V - 1);
     }
@@ -407,6 +419,7 @@ struct DecompositionGD {
 #pragma unroll
         for (int c = 0; c < 3; c++) out[c] = off[c] == kWitnessWire ? xvar : vbase + off[c];
     }
+    __device__ static bool is_inv_slot(const Args &A, const ItemRec &, uint32_t k) { return k + 1 == bound_z_offset(A.n); }
     __device__ static Fr var_value(const Args &A, const ItemRec &R, const uint4 *, uint32_t k) {
         return bound_var_value(R.b, R.y, k + 1, A.n);
     }

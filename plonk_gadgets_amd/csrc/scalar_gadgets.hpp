@@ -83,7 +83,6 @@ struct ScalarArgs {
     const uint4 *a_val, *b_val;
     uint64_t *result_vars;
     uint8_t *err_mask;  // is_non_zero only
-    const uint4 *inv;   // [batch] from the inversion pre-pass (maybe_equal, is_non_zero)
 };
 
 // ---- conditionally_select_zero ------------------------------------------------
@@ -92,6 +91,7 @@ struct SelectZeroGD {
     struct alignas(16) ItemRec { Fr out; };
     static constexpr int W = 256;
     static constexpr int kInv = 0;
+    __device__ static bool is_inv_slot(const Args &, const ItemRec &, uint32_t) { return false; }
     static constexpr bool kRagged = false, kRecInRows = false, kUsePow2 = false;
     __device__ static uint32_t rows_per_item(const Args &) { return 1; }
     __device__ static uint32_t vars_per_item(const Args &) { return 1; }
@@ -120,6 +120,7 @@ struct SelectOneGD {
     struct alignas(16) ItemRec { Fr sy, oms; };
     static constexpr int W = 256;
     static constexpr int kInv = 0;
+    __device__ static bool is_inv_slot(const Args &, const ItemRec &, uint32_t) { return false; }
     static constexpr bool kRagged = false, kRecInRows = false, kUsePow2 = false;
     __device__ static uint32_t rows_per_item(const Args &) { return 4; }
     __device__ static uint32_t vars_per_item(const Args &) { return 4; }
@@ -152,19 +153,21 @@ struct SelectOneGD {
 // ---- maybe_equal ----------------------------------------------------------------
 struct MaybeEqualGD {
     using Args = ScalarArgs;
-    struct alignas(16) ItemRec { Fr u, z; };
+    struct alignas(16) ItemRec { Fr u; };
     static constexpr int W = 256;
     static constexpr int kInv = 1;
     __device__ static Fr inv_element(const Args &A, uint64_t item, uint32_t) {
         return fr_sub(load_fr(A.a_val, item), load_fr(A.b_val, item));  // scalar.rs:121
     }
+    // variables of an item: u, z, y -- z is the pre-pass's (scalar.rs:122-123)
+    __device__ static uint4 *inv_slot(const Args &, const EmitOut &O, uint64_t item, uint32_t) { return O.vars + 2 * (item * 3 + 1); }
+    __device__ static bool is_inv_slot(const Args &, const ItemRec &, uint32_t k) { return k == 1; }
     static constexpr bool kRagged = false, kRecInRows = false, kUsePow2 = false;
     __device__ static uint32_t rows_per_item(const Args &) { return 3; }
     __device__ static uint32_t vars_per_item(const Args &) { return 3; }
     __device__ static void fill_table(const Args &, uint4 *, uint32_t) {}
     __device__ static void item(const Args &A, const EmitOut &O, uint64_t item, const uint4 *, ItemRec &R) {
         R.u = fr_sub(load_fr(A.a_val, item), load_fr(A.b_val, item));
-        R.z = load_fr(A.inv, item);  // scalar.rs:122
         if (A.result_vars) A.result_vars[item] = O.var_base + item * 3 + 2;
     }
     __device__ static void selectors(const Args &, const ItemRec &, uint32_t j, const uint4 *table, uint32_t h, uint4 out[5]) {
@@ -180,23 +183,27 @@ struct MaybeEqualGD {
     }
     __device__ static Fr var_value(const Args &, const ItemRec &R, const uint4 *, uint32_t k) {
         if (k == 0) return R.u;
-        if (k == 1) return R.z;
-        return fr_is_zero(R.u) ? fr_one() : fr_zero();
+        return fr_is_zero(R.u) ? fr_one() : fr_zero();  // k == 2 (k == 1 is z: the pre-pass's)
     }
 };
 
 // ---- is_non_zero (ragged: an item whose value is 0 stops after 1 row / 1 variable) ----------
 struct IsNonZeroGD {
     using Args = ScalarArgs;
-    struct alignas(16) ItemRec { Fr value, inv; };
+    struct alignas(16) ItemRec { Fr value; };
     static constexpr int W = 256;
     static constexpr int kInv = 1;
     __device__ static Fr inv_element(const Args &A, uint64_t item, uint32_t) { return load_fr(A.b_val, item); }  // scalar.rs:73
+    // variables of an item: var_assigned, inv, one -- an item whose value is 0 stopped before `inv` existed (scalar.rs:79)
+    __device__ static uint4 *inv_slot(const Args &A, const EmitOut &O, uint64_t item, uint32_t) {
+        if (fr_is_zero(load_fr(A.b_val, item))) return nullptr;
+        return O.vars + 2 * (O.var_off[item] + 1);
+    }
+    __device__ static bool is_inv_slot(const Args &, const ItemRec &, uint32_t k) { return k == 1; }
     static constexpr bool kRagged = true, kRecInRows = false, kUsePow2 = false;
     __device__ static void fill_table(const Args &, uint4 *, uint32_t) {}
     __device__ static void item(const Args &A, const EmitOut &, uint64_t item, const uint4 *, ItemRec &R) {
         R.value = load_fr(A.b_val, item);
-        R.inv = load_fr(A.inv, item);
     }
     __device__ static void selectors(const Args &, const ItemRec &, uint32_t j, const uint4 *table, uint32_t h, uint4 out[5]) {
         RowOut r;
@@ -211,8 +218,7 @@ struct IsNonZeroGD {
     }
     __device__ static Fr var_value(const Args &, const ItemRec &R, const uint4 *, uint32_t k) {
         if (k == 0) return R.value;
-        if (k == 1) return R.inv;
-        return fr_one();
+        return fr_one();  // k == 2 (k == 1 is inv: the pre-pass's)
     }
 };
 
@@ -234,15 +240,14 @@ __global__ __launch_bounds__(kThreads) void is_non_zero_plan_kernel(const uint4 
 struct ScalarMixArgs {
     const uint4 *v, *y, *s, *a, *b;
     uint64_t *result_vars;  // [batch][2]: select_one's output, maybe_equal's output
-    const uint4 *inv;       // [batch][2] from the inversion pre-pass: v^-1, (a-b)^-1
 };
 
 struct ScalarMixGD {
     using Args = ScalarMixArgs;
+    // every variable of the item, in emission order, is computed once by the item's lane: the variable sweep is then
+    // a plain LDS -> HBM copy (a wave that met one slot needing arithmetic would pay it for all 64 lanes)
     struct alignas(16) ItemRec {
-        Fr v, y, s, a, b, inv, z;
-        Fr sy;  // y * s, once per item (the variable sweep must stay free of multiplications: a wave that meets one
-                // slot needing a product pays the whole multiplication)
+        Fr vals[15];
         uint32_t err, pad[3];
     };
 #ifndef PG_MIX_W
@@ -253,21 +258,42 @@ struct ScalarMixGD {
     __device__ static Fr inv_element(const Args &A, uint64_t item, uint32_t e) {
         return e == 0 ? load_fr(A.v, item) : fr_sub(load_fr(A.a, item), load_fr(A.b, item));
     }
+    // item variables: [v y s a b | va inv one | one' sy oms out | u z yeq]; an item with v = 0 has no inv / one
+    __device__ static uint4 *inv_slot(const Args &A, const EmitOut &O, uint64_t item, uint32_t e) {
+        const bool err = fr_is_zero(load_fr(A.v, item));
+        if (e == 0) return err ? nullptr : O.vars + 2 * (O.var_off[item] + 6);
+        return O.vars + 2 * (O.var_off[item] + 5 + (err ? 1 : 3) + 4 + 1);
+    }
+    __device__ static bool is_inv_slot(const Args &, const ItemRec &R, uint32_t k) {
+        const uint32_t nz = R.err ? 1 : 3;
+        return (!R.err && k == 6) || k == 5 + nz + 4 + 1;
+    }
     static constexpr bool kRagged = true, kRecInRows = true, kUsePow2 = false;
     __device__ static void fill_table(const Args &, uint4 *, uint32_t) {}
     __device__ static void item(const Args &A, const EmitOut &O, uint64_t item, const uint4 *, ItemRec &R) {
-        R.v = load_fr(A.v, item);
-        R.y = load_fr(A.y, item);
-        R.s = load_fr(A.s, item);
-        R.a = load_fr(A.a, item);
-        R.b = load_fr(A.b, item);
-        R.err = fr_is_zero(R.v) ? 1u : 0u;
-        R.inv = load_fr(A.inv, 2 * item);
-        R.z = load_fr(A.inv, 2 * item + 1);
-        R.sy = fr_mul(R.y, R.s);  // scalar.rs:43
+        const Fr v = load_fr(A.v, item), y = load_fr(A.y, item), s = load_fr(A.s, item), a = load_fr(A.a, item),
+                 b = load_fr(A.b, item);
+        const uint32_t err = fr_is_zero(v) ? 1u : 0u;
+        R.err = err;
+        uint32_t k = 0;
+        R.vals[k++] = v; R.vals[k++] = y; R.vals[k++] = s; R.vals[k++] = a; R.vals[k++] = b;  // 5 x add_input
+        R.vals[k++] = v;                                                                     // var_assigned, scalar.rs:69
+        if (!err) {
+            R.vals[k++] = fr_zero();                                                         // inverse: the pre-pass's slot
+            R.vals[k++] = fr_one();                                                          // one, scalar.rs:83
+        }
+        const Fr sy = fr_mul(y, s), oms = fr_sub(fr_one(), s);
+        R.vals[k++] = fr_one();                                                              // scalar.rs:41
+        R.vals[k++] = sy;                                                                    // scalar.rs:43
+        R.vals[k++] = oms;                                                                   // scalar.rs:45-50
+        R.vals[k++] = fr_add(sy, oms);                                                       // scalar.rs:53-58
+        const Fr u = fr_sub(a, b);
+        R.vals[k++] = u;                                                                     // scalar.rs:111-117
+        R.vals[k++] = fr_zero();                                                             // z: the pre-pass's slot
+        R.vals[k++] = fr_is_zero(u) ? fr_one() : fr_zero();                                  // scalar.rs:126
         if (A.result_vars) {
             const uint64_t vb = O.var_base + O.var_off[item];
-            const uint64_t nz = R.err ? 1 : 3;
+            const uint64_t nz = err ? 1 : 3;
             A.result_vars[2 * item] = vb + 5 + nz + 3;
             A.result_vars[2 * item + 1] = vb + 5 + nz + 4 + 2;
         }
@@ -289,25 +315,7 @@ struct ScalarMixGD {
         row(R, vbase, O.zero_var, j, r);
         out[0] = r.w[0]; out[1] = r.w[1]; out[2] = r.w[2];
     }
-    __device__ static Fr var_value(const Args &, const ItemRec &R, const uint4 *, uint32_t k) {
-        if (k < 5) return k == 0 ? R.v : k == 1 ? R.y : k == 2 ? R.s : k == 3 ? R.a : R.b;
-        k -= 5;
-        const uint32_t nz = R.err ? 1 : 3;
-        if (k < nz) return k == 0 ? R.v : k == 1 ? R.inv : fr_one();
-        k -= nz;
-        if (k < 4) {
-            if (k == 0) return fr_one();
-            if (k == 1) return R.sy;
-            const Fr oms = fr_sub(fr_one(), R.s);
-            if (k == 2) return oms;
-            return fr_add(R.sy, oms);
-        }
-        k -= 4;
-        const Fr u = fr_sub(R.a, R.b);
-        if (k == 0) return u;
-        if (k == 1) return R.z;
-        return fr_is_zero(u) ? fr_one() : fr_zero();
-    }
+    __device__ static Fr var_value(const Args &, const ItemRec &R, const uint4 *, uint32_t k) { return R.vals[k]; }
 };
 
 __global__ __launch_bounds__(kThreads) void scalar_mix_plan_kernel(const uint4 *v, uint64_t batch, uint32_t *rows, uint32_t *vars,
