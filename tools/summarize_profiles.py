@@ -12,8 +12,15 @@ R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
 DST = os.path.join(ROOT, "profiles")
 summary = {}
+
+
+def newest(pattern):
+    """gpurun merges runs into the same directory: take the most recent file that matches"""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 for w in ("c2", "c3", "c4"):
-    st = glob.glob(os.path.join(SRC, f"stats_{w}", "*", "*kernel_stats.csv"))[0]
+    st = newest(os.path.join(SRC, f"stats_{w}", "*", "*kernel_stats.csv"))
     shutil.copy(st, os.path.join(DST, f"{R}_{w}_kernel_stats.csv"))
     log = open(os.path.join(SRC, f"stats_{w}.log")).read().strip().splitlines()
     line = [l for l in log if l.startswith("{")][-1]
@@ -21,7 +28,7 @@ for w in ("c2", "c3", "c4"):
     chunk = json.loads(line)["config"]["items_per_launch"]
     vals = {}
     for kind, cn in (("pmcw", "WRITE_SIZE"), ("pmcf", "FETCH_SIZE")):
-        f = glob.glob(os.path.join(SRC, f"{kind}_{w}", "*", "*counter_collection.csv"))[0]
+        f = newest(os.path.join(SRC, f"{kind}_{w}", "*", "*counter_collection.csv"))
         keep = [r for r in csv.DictReader(open(f)) if "emit_kernel" in r["Kernel_Name"] or "batch_invert" in r["Kernel_Name"]]
         with open(os.path.join(DST, f"{R}_{w}_pmc_{cn.lower()}.csv"), "w") as o:
             wr = csv.DictWriter(o, fieldnames=list(keep[0].keys()))
