@@ -198,12 +198,19 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
         if (per_lane > 32) per_lane = 32;
         const uint64_t lanes = (elems + per_lane - 1) / per_lane;
         const uint32_t blocks = (uint32_t)((lanes + pg::kThreads - 1) / pg::kThreads);
+#if defined(PG_SEQUENTIAL_PREPASS)  // A/B build: the pre-pass on the caller's stream, ahead of the emit kernel
+        hipLaunchKernelGGL(pg::batch_invert_kernel<GD>, dim3(blocks), dim3(pg::kThreads), 0, st, A, O, elems,
+                           (uint32_t)per_lane, e->d_prefix);
+        PG_HIP_TRY(hipGetLastError());
+        PG_HIP_TRY(hipEventRecord(e->ev_inv, st));
+#else
         PG_HIP_TRY(hipEventRecord(e->ev_fork, st));  // the pre-pass reads the call's inputs: order it after the stream
         PG_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
         hipLaunchKernelGGL(pg::batch_invert_kernel<GD>, dim3(blocks), dim3(pg::kThreads), 0, e->side, A, O, elems,
                            (uint32_t)per_lane, e->d_prefix);
         PG_HIP_TRY(hipGetLastError());
         PG_HIP_TRY(hipEventRecord(e->ev_inv, e->side));
+#endif
     }
     const uint32_t max_blocks = (uint32_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
     const uint32_t grid = O.tiles < max_blocks ? O.tiles : max_blocks;

@@ -15,9 +15,7 @@ VDIR = os.path.join(ROOT, "tools", "variants")
 
 VARIANTS = {
     "base": [],
-    "buf_plain": ["-DPG_STORE_AUX=0"],
-    "buf_sc1": ["-DPG_STORE_AUX=16"],
-    "buf_sc0sc1": ["-DPG_STORE_AUX=17"],
+    "sequential_prepass": ["-DPG_SEQUENTIAL_PREPASS"],
 }
 
 
