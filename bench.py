@@ -202,7 +202,7 @@ def main():
         def launch(c):
             # the plan (zero test + prefix sums) is part of the pass: the inputs decide the ragged layout
             part = [t[c * chunk:(c + 1) * chunk] for t in ins]
-            eng.scalar_mix_plan(part[0], roff, voff)
+            eng.scalar_mix_plan_async(part[0], roff, voff)  # no host round trip: the buffers hold the worst case
             eng.scalar_mix_emit(*part, roff, voff, cols, res, 3, 5, 0)
         kernel = "pg::emit_kernel<pg::ScalarMixGD> (+ plan/scan kernels and the inversion pre-pass)"
         desc = ("C3: 2^%d items/GPU x (5 add_input + is_non_zero + conditionally_select_one + maybe_equal), one "
@@ -220,7 +220,7 @@ def main():
         read_bytes = chunk * 64
 
         def launch(c):
-            eng.max_bound_ragged_plan(mr, nb, roff, voff)
+            eng.max_bound_ragged_plan_async(mr, nb, roff, voff)
             eng.max_bound_ragged_emit(mr, wt, nb, roff, voff, cols, res, 3, 5)
         kernel = "pg::emit_kernel<pg::MaxBoundGD<true>> (+ plan/scan kernels and the inversion pre-pass)"
         desc = ("C4: 2^%d items/GPU x (allocate + max_bound(random 253-bit bound)), data-dependent ladder length, "

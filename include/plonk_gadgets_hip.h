@@ -160,6 +160,17 @@ pg_status pg_max_bound_ragged_batch(pg_engine *e, const pg_scalar *d_max_range, 
                                     const uint64_t *d_var_off, uint64_t gate_base, uint64_t var_base,
                                     const pg_columns *out, pg_variable *d_result_vars /* may be NULL */, void *stream);
 
+/* Asynchronous plans: enqueue and return at once; the totals (and the error count) land in engine-owned pinned host
+ * memory and are read with pg_plan_result once the stream has been synchronised.  For callers that pre-allocate
+ * worst-case buffers (10 rows / 15 variables per mix item, 515 rows / 517 variables per max_bound item) and do not
+ * want a host round trip between the plan and the emit call. */
+pg_status pg_max_bound_ragged_plan_async(pg_engine *e, const pg_scalar *d_max_range, uint64_t batch, uint32_t *d_num_bits,
+                                         uint64_t *d_row_off, uint64_t *d_var_off, void *stream);
+pg_status pg_scalar_mix_plan_async(pg_engine *e, const pg_scalar *d_v, uint64_t batch, uint64_t *d_row_off,
+                                   uint64_t *d_var_off, uint8_t *d_err_mask /* may be NULL */, void *stream);
+/* totals of the engine's most recent plan; PG_ERR_NON_EXISTING_INVERSE when that plan found failing items */
+pg_status pg_plan_result(pg_engine *e, pg_layout *out, uint64_t *err_count /* may be NULL */);
+
 /* ---- scalar gadgets, batched ----------------------------------------------
  * The stand-alone gadgets take EXISTING Variables: d_*_var are their indices, d_*_val their assignments (what
  * the reference reads from composer.variables).  Each emits, per item i and in order, the rows/variables of

@@ -87,6 +87,11 @@ SIGNATURES = {
                                       _P(LayoutC), _P(C.c_uint64), C.c_void_p]),
     "pg_is_non_zero_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                        C.c_uint64, C.c_uint64, C.c_uint64, _P(ColumnsC), C.c_void_p]),
+    "pg_max_bound_ragged_plan_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p]),
+    "pg_scalar_mix_plan_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]),
+    "pg_plan_result": (C.c_int, [C.c_void_p, _P(LayoutC), _P(C.c_uint64)]),
     "pg_scalar_mix_plan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      _P(LayoutC), _P(C.c_uint64), C.c_void_p]),
     "pg_composer_create": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, _P(C.c_void_p)]),

@@ -98,6 +98,8 @@ struct pg_engine {
     uint64_t *d_blk_rows = nullptr, *d_blk_vars = nullptr;
     uint32_t *d_err_count = nullptr;
     uint64_t scratch_items = 0;
+    // totals of the last plan, written by async copies into pinned host memory (read after a synchronisation)
+    struct PlanResult { uint64_t n_gates, n_vars; uint32_t errs, pad; } *h_plan = nullptr;
     // scratch of the inversion pre-pass (grow-only): running products, 32 B per element
     uint4 *d_prefix = nullptr;
     uint64_t inv_elems = 0;
@@ -137,9 +139,13 @@ pg_status scan_counts(pg_engine *e, uint64_t batch, uint64_t *d_row_off, uint64_
     hipLaunchKernelGGL(pg::scan_final_kernel, dim3(nblk), dim3(pg::kThreads), 0, st, e->d_rows, e->d_vars, batch,
                        e->d_blk_rows, e->d_blk_vars, d_row_off, d_var_off);
     PG_HIP_TRY(hipGetLastError());
-    PG_HIP_TRY(hipMemcpyAsync(n_rows, d_row_off + batch, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    PG_HIP_TRY(hipMemcpyAsync(n_vars, d_var_off + batch, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    PG_HIP_TRY(hipStreamSynchronize(st));
+    PG_HIP_TRY(hipMemcpyAsync(&e->h_plan->n_gates, d_row_off + batch, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    PG_HIP_TRY(hipMemcpyAsync(&e->h_plan->n_vars, d_var_off + batch, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    if (n_rows) {  // synchronous form
+        PG_HIP_TRY(hipStreamSynchronize(st));
+        *n_rows = e->h_plan->n_gates;
+        *n_vars = e->h_plan->n_vars;
+    }
     return PG_OK;
 }
 
@@ -236,13 +242,17 @@ pg_status scalar_args(const pg_variable *a_var, const pg_scalar *a_val, const pg
     return PG_OK;
 }
 
+// out == NULL: asynchronous form (results through pg_plan_result)
 template <class PlanKernel>
 pg_status error_plan(pg_engine *e, PlanKernel kernel, const pg_scalar *d_value, uint64_t batch, uint64_t *d_row_off,
                             uint64_t *d_var_off, uint8_t *d_err_mask, pg_layout *out, uint64_t *err_count, void *stream) {
-    if (!e || !out) return fail(PG_ERR_INVALID_ARGUMENT, "NULL argument");
-    std::memset(out, 0, sizeof *out);
+    if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (out) std::memset(out, 0, sizeof *out);
     if (err_count) *err_count = 0;
-    if (batch == 0) return PG_OK;
+    if (batch == 0) {
+        if (e->h_plan) *e->h_plan = pg_engine::PlanResult{0, 0, 0, 0};
+        return PG_OK;
+    }
     PG_TRY(check_scalars(d_value, "value array"));
     PG_TRY(check_u64s(d_row_off, "d_row_off"));
     PG_TRY(check_u64s(d_var_off, "d_var_off"));
@@ -253,9 +263,10 @@ pg_status error_plan(pg_engine *e, PlanKernel kernel, const pg_scalar *d_value, 
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(pg::kThreads), 0, st, reinterpret_cast<const uint4 *>(d_value), batch,
                        e->d_rows, e->d_vars, d_err_mask, e->d_err_count);
     PG_HIP_TRY(hipGetLastError());
-    uint32_t errs = 0;
-    PG_HIP_TRY(hipMemcpyAsync(&errs, e->d_err_count, sizeof errs, hipMemcpyDeviceToHost, st));
+    PG_HIP_TRY(hipMemcpyAsync(&e->h_plan->errs, e->d_err_count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if (!out) return scan_counts(e, batch, d_row_off, d_var_off, nullptr, nullptr, st);
     PG_TRY(scan_counts(e, batch, d_row_off, d_var_off, &out->n_gates, &out->n_vars, st));
+    const uint32_t errs = e->h_plan->errs;
     if (err_count) *err_count = errs;
     if (errs) return fail(PG_ERR_NON_EXISTING_INVERSE, std::to_string(errs) + " item(s) have no inverse (value = 0)");
     return PG_OK;
@@ -300,6 +311,11 @@ pg_status pg_engine_create(int device, pg_engine **out) {
         delete e;
         return fail(PG_ERR_HIP, "hipMalloc(pow2 table) failed");
     }
+    if (hipHostMalloc(reinterpret_cast<void **>(&e->h_plan), sizeof(pg_engine::PlanResult), hipHostMallocDefault) != hipSuccess) {
+        pg_engine_destroy(e);
+        return fail(PG_ERR_HIP, "hipHostMalloc(plan result) failed");
+    }
+    *e->h_plan = pg_engine::PlanResult{0, 0, 0, 0};
     // the pre-pass is the critical path of a call with small items: highest priority, so its waves are placed ahead of
     // the rows-only emit launch it runs beside
     int prio_lo = 0, prio_hi = 0;
@@ -333,6 +349,7 @@ void pg_engine_destroy(pg_engine *e) {
     if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_inv) (void)hipEventDestroy(e->ev_inv);
+    if (e->h_plan) (void)hipHostFree(e->h_plan);
     delete e;
 }
 
@@ -490,11 +507,14 @@ pg_status pg_max_bound_allocated_batch(pg_engine *e, const pg_scalar *max_range,
     return max_bound_common(e, max_range, d_witness_var, d_witness, batch, gate_base, var_base, out, d_result_vars, stream);
 }
 
-pg_status pg_max_bound_ragged_plan(pg_engine *e, const pg_scalar *d_max_range, uint64_t batch, uint32_t *d_num_bits,
-                                   uint64_t *d_row_off, uint64_t *d_var_off, pg_layout *out, void *stream) {
-    if (!e || !out) return fail(PG_ERR_INVALID_ARGUMENT, "NULL argument");
-    std::memset(out, 0, sizeof *out);
-    if (batch == 0) return PG_OK;
+static pg_status max_bound_ragged_plan_common(pg_engine *e, const pg_scalar *d_max_range, uint64_t batch, uint32_t *d_num_bits,
+                                              uint64_t *d_row_off, uint64_t *d_var_off, pg_layout *out, void *stream) {
+    if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (out) std::memset(out, 0, sizeof *out);
+    if (batch == 0) {
+        *e->h_plan = pg_engine::PlanResult{0, 0, 0, 0};
+        return PG_OK;
+    }
     PG_TRY(check_scalars(d_max_range, "d_max_range"));
     if (!d_num_bits || !aligned(d_num_bits, 4)) return fail(PG_ERR_INVALID_ARGUMENT, "d_num_bits NULL or misaligned");
     PG_TRY(check_u64s(d_row_off, "d_row_off"));
@@ -505,8 +525,31 @@ pg_status pg_max_bound_ragged_plan(pg_engine *e, const pg_scalar *d_max_range, u
     hipLaunchKernelGGL(pg::max_bound_plan_kernel, dim3(grid), dim3(pg::kThreads), 0, st,
                        reinterpret_cast<const uint4 *>(d_max_range), batch, e->d_pow2, d_num_bits, e->d_rows, e->d_vars);
     PG_HIP_TRY(hipGetLastError());
+    e->h_plan->errs = 0;
+    if (!out) return scan_counts(e, batch, d_row_off, d_var_off, nullptr, nullptr, st);
     PG_TRY(scan_counts(e, batch, d_row_off, d_var_off, &out->n_gates, &out->n_vars, st));
     return PG_OK;
+}
+
+pg_status pg_max_bound_ragged_plan(pg_engine *e, const pg_scalar *d_max_range, uint64_t batch, uint32_t *d_num_bits,
+                                   uint64_t *d_row_off, uint64_t *d_var_off, pg_layout *out, void *stream) {
+    if (!out) return fail(PG_ERR_INVALID_ARGUMENT, "NULL argument");
+    return max_bound_ragged_plan_common(e, d_max_range, batch, d_num_bits, d_row_off, d_var_off, out, stream);
+}
+
+pg_status pg_max_bound_ragged_plan_async(pg_engine *e, const pg_scalar *d_max_range, uint64_t batch, uint32_t *d_num_bits,
+                                         uint64_t *d_row_off, uint64_t *d_var_off, void *stream) {
+    return max_bound_ragged_plan_common(e, d_max_range, batch, d_num_bits, d_row_off, d_var_off, nullptr, stream);
+}
+
+pg_status pg_plan_result(pg_engine *e, pg_layout *out, uint64_t *err_count) {
+    if (!e || !out) return fail(PG_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::memset(out, 0, sizeof *out);
+    out->n_gates = e->h_plan->n_gates;
+    out->n_vars = e->h_plan->n_vars;
+    if (err_count) *err_count = e->h_plan->errs;
+    return e->h_plan->errs ? fail(PG_ERR_NON_EXISTING_INVERSE, std::to_string(e->h_plan->errs) + " item(s) have no inverse")
+                           : PG_OK;
 }
 
 pg_status pg_max_bound_ragged_batch(pg_engine *e, const pg_scalar *d_max_range, const pg_scalar *d_witness, uint64_t batch,
@@ -569,6 +612,7 @@ pg_status pg_maybe_equal_batch(pg_engine *e, const pg_variable *d_a_var, const p
 
 pg_status pg_is_non_zero_plan(pg_engine *e, const pg_scalar *d_value_assigned, uint64_t batch, uint64_t *d_row_off,
                               uint64_t *d_var_off, uint8_t *d_err_mask, pg_layout *out, uint64_t *err_count, void *stream) {
+    if (!out) return fail(PG_ERR_INVALID_ARGUMENT, "NULL argument");
     return error_plan(e, pg::is_non_zero_plan_kernel, d_value_assigned, batch, d_row_off, d_var_off, d_err_mask, out,
                       err_count, stream);
 }
@@ -591,7 +635,13 @@ pg_status pg_is_non_zero_batch(pg_engine *e, const pg_variable *d_var, const pg_
 
 pg_status pg_scalar_mix_plan(pg_engine *e, const pg_scalar *d_v, uint64_t batch, uint64_t *d_row_off, uint64_t *d_var_off,
                              uint8_t *d_err_mask, pg_layout *out, uint64_t *err_count, void *stream) {
+    if (!out) return fail(PG_ERR_INVALID_ARGUMENT, "NULL argument");
     return error_plan(e, pg::scalar_mix_plan_kernel, d_v, batch, d_row_off, d_var_off, d_err_mask, out, err_count, stream);
+}
+
+pg_status pg_scalar_mix_plan_async(pg_engine *e, const pg_scalar *d_v, uint64_t batch, uint64_t *d_row_off,
+                                   uint64_t *d_var_off, uint8_t *d_err_mask, void *stream) {
+    return error_plan(e, pg::scalar_mix_plan_kernel, d_v, batch, d_row_off, d_var_off, d_err_mask, nullptr, nullptr, stream);
 }
 
 pg_status pg_scalar_mix_batch(pg_engine *e, const pg_scalar *d_v, const pg_scalar *d_y, const pg_scalar *d_s,

@@ -365,3 +365,24 @@ class Engine:
                                            self._stream())
         if st != 0:
             raise PgError(st, "pg_scalar_mix_batch")
+
+    # ---- asynchronous plans (no host round trip between plan and emit; totals read back later) -----------------
+    def max_bound_ragged_plan_async(self, max_range: torch.Tensor, num_bits, row_off, var_off):
+        st = self._lib.pg_max_bound_ragged_plan_async(self._h, max_range.data_ptr(), max_range.shape[0], num_bits.data_ptr(),
+                                                      row_off.data_ptr(), var_off.data_ptr(), self._stream())
+        if st != 0:
+            raise PgError(st, "pg_max_bound_ragged_plan_async")
+
+    def scalar_mix_plan_async(self, v: torch.Tensor, row_off, var_off, err_mask=None):
+        st = self._lib.pg_scalar_mix_plan_async(self._h, v.data_ptr(), v.shape[0], row_off.data_ptr(), var_off.data_ptr(),
+                                                err_mask.data_ptr() if err_mask is not None else None, self._stream())
+        if st != 0:
+            raise PgError(st, "pg_scalar_mix_plan_async")
+
+    def plan_result(self):
+        """(Layout, err_count) of the most recent plan; call after synchronising the stream it ran on"""
+        lay, nerr = _lib.LayoutC(), C.c_uint64()
+        st = self._lib.pg_plan_result(self._h, C.byref(lay), C.byref(nerr))
+        if st not in (0, 1):
+            raise PgError(st, "pg_plan_result")
+        return self._layout(lay), int(nerr.value)

@@ -480,3 +480,40 @@ def test_fuzz_very_ragged_max_bound(engine):
         assert np.array_equal(u64(res), ora["result_vars"])
         assert nb.cpu().numpy().astype(np.uint64).tolist() == ora["num_bits"].tolist()
         assert engine.check_rows(cols) == -1
+
+
+def test_async_plans_match_sync_plans(engine):
+    """plan_async + emit + (later) plan_result == the synchronous plan: same offsets, same totals, same columns"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import plonk_gadgets_amd as pg
+    # scalar mix with some failing items
+    v, y, s, a, b = mix_inputs(700, 9, zeros=(3, 77, 699))
+    ins = [dev(x) for x in (v, y, s, a, b)]
+    _, roff, voff = engine.ragged_buffers(700)
+    lay, nerr = engine.scalar_mix_plan(ins[0], roff, voff)
+    ref_roff, ref_voff = roff.clone(), voff.clone()
+    ref = pg.Columns.allocate(lay.n_gates, lay.n_vars, "cuda:0")
+    engine.scalar_mix_emit(*ins, roff, voff, ref, None, 3, 5, 0)
+    roff.zero_(); voff.zero_()
+    big = pg.Columns.allocate(10 * 700, 15 * 700, "cuda:0")  # worst case
+    engine.scalar_mix_plan_async(ins[0], roff, voff)
+    engine.scalar_mix_emit(*ins, roff, voff, big, None, 3, 5, 0)
+    torch.cuda.synchronize()
+    lay2, nerr2 = engine.plan_result()
+    assert (lay2.n_gates, lay2.n_vars, nerr2) == (lay.n_gates, lay.n_vars, nerr) == (7000 - 6, 10500 - 6, 3)
+    assert torch.equal(roff, ref_roff) and torch.equal(voff, ref_voff)
+    for k in COLS:
+        n = lay.n_vars if k == "var_values" else lay.n_gates
+        assert torch.equal(getattr(big, k)[:n], getattr(ref, k)), k
+    # ragged max_bound
+    mr, wt = bench.c4_inputs(300, seed=5)
+    nb, roff, voff = engine.ragged_buffers(300)
+    lay = engine.max_bound_ragged_plan(dev(mr), nb, roff, voff)
+    ref_roff = roff.clone()
+    roff.zero_()
+    engine.max_bound_ragged_plan_async(dev(mr), nb, roff, voff)
+    torch.cuda.synchronize()
+    lay2, nerr2 = engine.plan_result()
+    assert (lay2.n_gates, lay2.n_vars, nerr2) == (lay.n_gates, lay.n_vars, 0) and torch.equal(roff, ref_roff)
