@@ -320,6 +320,9 @@ pg_status pg_engine_create(int device, pg_engine **out) {
     // the rows-only emit launch it runs beside
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+#if defined(PG_SIDE_STREAM_NORMAL_PRIORITY)
+    prio_hi = 0;
+#endif
     if (hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_inv, hipEventDisableTiming) != hipSuccess) {

@@ -20,9 +20,6 @@ namespace pg {
 template <class GD>
 __global__ __launch_bounds__(kThreads) void batch_invert_kernel(const typename GD::Args A, const EmitOut O, uint64_t n_elems,
                                                                uint32_t per_lane, uint4 *prefix) {
-    // this kernel is a long dependent chain of multiply-adds on one wave per SIMD and usually runs beside the
-    // rows-only emit launch: let its waves win the issue arbitration
-    __builtin_amdgcn_s_setprio(3);
     const uint64_t T = (uint64_t)gridDim.x * kThreads;
     const uint64_t gtid = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
     Fr acc = fr_one();

@@ -15,7 +15,10 @@ VDIR = os.path.join(ROOT, "tools", "variants")
 
 VARIANTS = {
     "base": [],
-    "sequential_prepass": ["-DPG_SEQUENTIAL_PREPASS"],
+    "prio0": ["-DPG_INV_SETPRIO=0"],
+    "prio1": ["-DPG_INV_SETPRIO=1"],
+    "prio0_normalstream": ["-DPG_INV_SETPRIO=0", "-DPG_SIDE_STREAM_NORMAL_PRIORITY"],
+    "sequential": ["-DPG_SEQUENTIAL_PREPASS"],
 }
 
 
