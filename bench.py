@@ -77,6 +77,13 @@ def cpu_baseline(workload: str, sample: int):
             "sample": f"{what}, {out['n_gates']} rows, oracle/gadgets.c single thread, {dt:.1f} s",
             "host_cores_available": os.cpu_count()}
     if workload == "c2":
+        # BASELINE config 1, exactly as specified: 1 000 x range_check(v, "64-bit") through the faithful port, one thread
+        c1 = synth.uniform_below(1000, 2**64 + 2**60, seed=synth.SEED)
+        t1 = time.perf_counter()
+        o1 = po.range_check_batch(synth.mont(0), synth.mont(2**64), c1, check=False, want_columns=False)
+        d1 = time.perf_counter() - t1
+        base["config_c1"] = {"value": o1["n_gates"] / d1, "unit": "constraints/s", "cores": 1, "kind": "port",
+                             "sample": f"1000 witnesses x range_check(min=0,max=2^64) (n=65), {o1['n_gates']} rows, {d1:.1f} s"}
         # best-case CPU beside the faithful port: oracle/fast.c (mont(2^i) table, flat arrays, closed-form offsets)
         threads = min(os.cpu_count() or 1, 16)
         fast = po.range_check_fast(synth.mont(0), synth.mont(2**254), synth.random_scalars(16384, seed=synth.SEED),
