@@ -13,12 +13,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "tools", "variants")
 
+# the build options that exist in the tree today (every one of them was measured; DESIGN.md section 3 has the numbers)
 VARIANTS = {
     "base": [],
-    "prio0": ["-DPG_INV_SETPRIO=0"],
-    "prio1": ["-DPG_INV_SETPRIO=1"],
-    "prio0_normalstream": ["-DPG_INV_SETPRIO=0", "-DPG_SIDE_STREAM_NORMAL_PRIORITY"],
-    "sequential": ["-DPG_SEQUENTIAL_PREPASS"],
+    "sequential_prepass": ["-DPG_SEQUENTIAL_PREPASS"],
+    "side_stream_normal_priority": ["-DPG_SIDE_STREAM_NORMAL_PRIORITY"],
+    "xcd_remap": ["-DPG_XCD_REMAP"],
+    "nt_stores": ["-DPG_NT_STORES"],
+    "rc_w16": ["-DPG_RC_W=16"],
+    "grid8": ["-DPG_GRID_BLOCKS_PER_CU=8"],
 }
 
 
