@@ -12,7 +12,7 @@ scalars = st.one_of(st.integers(0, Q - 1), st.integers(0, 2**64), st.sampled_fro
 small_bounds = st.integers(0, 2**40)
 
 
-@settings(max_examples=25, deadline=None)
+@settings(max_examples=25, deadline=None, derandomize=True)
 @given(mn=small_bounds, span=st.integers(1, 2**40), ws=st.lists(scalars, min_size=1, max_size=4))
 def test_range_check_three_statements_agree(mn, span, ws):
     mx = mn + span
@@ -32,7 +32,7 @@ def test_range_check_three_statements_agree(mn, span, ws):
     assert [m.variables[r] for r in res] == [int(mn <= w < mx) for w in ws]
 
 
-@settings(max_examples=20, deadline=None)
+@settings(max_examples=20, deadline=None, derandomize=True)
 @given(mx=st.one_of(st.integers(0, 2**254), st.integers(0, 2**20)), w1=scalars, w2=scalars)
 def test_max_bound_structure_is_witness_independent(mx, w1, w2):
     a = po.max_bound_batch(po.ints_to_mont_array([mx]), po.ints_to_mont_array([w1]))
@@ -46,7 +46,7 @@ def test_max_bound_structure_is_witness_independent(mx, w1, w2):
     assert out == int((mx - 1 - w1) % Q < 2**n)
 
 
-@settings(max_examples=30, deadline=None)
+@settings(max_examples=30, deadline=None, derandomize=True)
 @given(v=scalars, y=scalars, s=st.integers(0, 1), a=scalars, b=scalars, same=st.booleans())
 def test_scalar_mix_model_vs_c(v, y, s, a, b, same):
     if same:
