@@ -517,3 +517,55 @@ def test_async_plans_match_sync_plans(engine):
     torch.cuda.synchronize()
     lay2, nerr2 = engine.plan_result()
     assert (lay2.n_gates, lay2.n_vars, nerr2) == (lay.n_gates, lay.n_vars, 0) and torch.equal(roff, ref_roff)
+
+
+def test_back_to_back_calls_without_syncs(engine):
+    """40 calls of different gadgets and sizes enqueued back to back on one stream with no synchronisation in between:
+    the engine's side stream, its fork/join events and its grow-only scratch must keep every call's output intact"""
+    import plonk_gadgets_amd as pg
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(5)
+    jobs = []
+    for i in range(40):
+        kind = i % 4
+        batch = int(rng.integers(1, 400))
+        if kind == 0:
+            mn, mx = 50_000, 250_000
+            wit = mixed_witnesses_local(mn, mx, batch, seed=i)
+            cols, res = engine.range_check_batch(pg.BlsScalar.from_int(mn), pg.BlsScalar.from_int(mx), dev(wit), 3, 5)
+            jobs.append(("rc", (mn, mx, wit), cols, res))
+        elif kind == 1:
+            v, y, s, a, b = mix_inputs(batch, 100 + i, zeros=(0,) if i % 8 == 1 else ())
+            cols, res, err, nerr, lay = engine.scalar_mix_batch(dev(v), dev(y), dev(s), dev(a), dev(b), 3, 5, zero_var=0)
+            jobs.append(("mix", (v, y, s, a, b), cols, res))
+        elif kind == 2:
+            a, b = pair_inputs(batch, 200 + i, equal_every=3)
+            av, bv = np.arange(5, 5 + batch, dtype=np.uint64), np.arange(5 + batch, 5 + 2 * batch, dtype=np.uint64)
+            cols, res = engine.maybe_equal_batch(dev(av), dev(a), dev(bv), dev(b), 3, 5 + 2 * batch)
+            jobs.append(("me", (a, b), cols, res))
+        else:
+            mx = 2**64
+            wit = synth.uniform_below(batch, 2**64 + 2**62, seed=300 + i)
+            cols, res, _ = engine.max_bound_batch(pg.BlsScalar.from_int(mx), dev(wit), 3, 5)
+            jobs.append(("mb", (mx, wit), cols, res))
+    torch.cuda.synchronize()
+    for kind, inp, cols, res in jobs:
+        got = cols.to_numpy()
+        if kind == "rc":
+            ora = po.range_check_fast(synth.mont(inp[0]), synth.mont(inp[1]), inp[2], threads=4, var_base=5)
+        elif kind == "mix":
+            ora = po.scalar_mix_batch(*inp)
+        elif kind == "me":
+            ora, r, g0, v0, _, _ = oracle_two_input("maybe_equal", inp[0], inp[1], True)
+            ora = dict(ora, result_vars=r)
+        else:
+            ora = po.max_bound_batch(np.repeat(synth.scalars_from_ints([inp[0]]), len(inp[1]), axis=0), inp[1])
+        assert_cols(got, ora)
+        assert np.array_equal(u64(res).reshape(-1), np.asarray(ora["result_vars"]).reshape(-1)), kind
+
+
+def mixed_witnesses_local(mn, mx, n, seed):
+    inside = synth.scalars_from_ints([mn + int(v) % (mx - mn) for v in synth.splitmix64(n, seed)])
+    outside = synth.random_scalars(n, seed + 1)
+    pick = (synth.splitmix64(n, seed + 2) & np.uint64(1)).astype(bool)
+    return np.ascontiguousarray(np.where(pick[:, None], inside, outside))
