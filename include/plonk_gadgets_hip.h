@@ -277,6 +277,16 @@ pg_status pg_maybe_equal(pg_composer *c, const pg_allocated_scalar *a, const pg_
 pg_status pg_composer_range_check_batch(pg_composer *c, const pg_scalar *min_range, const pg_scalar *max_range,
                                         const pg_scalar *d_witness, uint64_t batch, pg_variable *d_result_vars);
 
+/* AllocatedScalar::allocate of a batch (src/allocated_scalar.rs:27): the loop  for s in d_scalars { add_input(s) };
+ * the Variables are *first_var, *first_var + 1, ...  (d_scalars: device, reduced) */
+pg_status pg_composer_add_input_batch(pg_composer *c, const pg_scalar *d_scalars, uint64_t batch, pg_variable *first_var);
+/* the loop  for i { range_check(composer, min, max, AllocatedScalar { var: d_witness_var[i], scalar: d_witness[i] }) }
+ * on witnesses allocated before (device arrays; every d_witness_var[i] must be a Variable of this composer -- the
+ * reference panics on an unknown one, here the row then fails pg_composer_check) */
+pg_status pg_composer_range_check_allocated_batch(pg_composer *c, const pg_scalar *min_range, const pg_scalar *max_range,
+                                                  const pg_variable *d_witness_var, const pg_scalar *d_witness,
+                                                  uint64_t batch, pg_variable *d_result_vars);
+
 /* copy rows [gate_first, gate_first + n_gates) of the live columns and variables [var_first, var_first + n_vars)
  * into caller-owned device buffers (any member of dst may be NULL); enqueued on the composer's stream */
 pg_status pg_composer_copy_out(pg_composer *c, uint64_t gate_first, uint64_t n_gates, uint64_t var_first, uint64_t n_vars,
@@ -303,7 +313,8 @@ pg_status pg_composer_materialize(pg_composer *c, const pg_full_columns *out);
 /* the copy permutation the composer's bookkeeping implies (dusk-plonk's
  * Permutation::compute_sigma_permutations).  d_sigma[4 * padded_n] (device): sigma of position (wire, gate) at
  * index wire * padded_n + gate, encoded the same way; wire 0..3 = left, right, output, fourth; rows >= circuit_size
- * map to themselves.  padded_n >= circuit_size (the prover pads to a power of two). */
+ * map to themselves.  padded_n >= circuit_size (the prover pads to a power of two).  Enqueued on the composer's
+ * stream (one host synchronisation inside, to size the sorted list); scratch is kept by the composer and only grows. */
 pg_status pg_composer_permutation(pg_composer *c, uint64_t padded_n, uint64_t *d_sigma);
 
 /* Satisfiability of the rows of ONE batch call whose wires all point into its own variables (the allocate-style

@@ -119,6 +119,9 @@ SIGNATURES = {
     "pg_is_non_zero": (C.c_int, [C.c_void_p, C.c_uint64, _P(Scalar)]),
     "pg_maybe_equal": (C.c_int, [C.c_void_p, _P(AllocatedScalarC), _P(AllocatedScalarC), _P(C.c_uint64)]),
     "pg_composer_range_check_batch": (C.c_int, [C.c_void_p, _P(Scalar), _P(Scalar), C.c_void_p, C.c_uint64, C.c_void_p]),
+    "pg_composer_add_input_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, _P(C.c_uint64)]),
+    "pg_composer_range_check_allocated_batch": (C.c_int, [C.c_void_p, _P(Scalar), _P(Scalar), C.c_void_p, C.c_void_p, C.c_uint64,
+                                                          C.c_void_p]),
     "pg_composer_copy_out": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _P(ColumnsC)]),
     "pg_composer_read_value": (C.c_int, [C.c_void_p, C.c_uint64, _P(Scalar)]),
     "pg_composer_check": (C.c_int, [C.c_void_p, _P(C.c_int64)]),

@@ -120,6 +120,25 @@ class StandardComposer:
              "pg_composer_range_check_batch")
         return res
 
+    def add_input_batch(self, scalars: torch.Tensor) -> int:
+        """for s in scalars: add_input(s) -- returns the first Variable (the others follow it)"""
+        assert scalars.is_cuda and scalars.dtype == torch.int64 and scalars.dim() == 2 and scalars.is_contiguous()
+        first = C.c_uint64()
+        _chk(self._lib.pg_composer_add_input_batch(self._h, scalars.data_ptr(), scalars.shape[0], C.byref(first)),
+             "pg_composer_add_input_batch")
+        return int(first.value)
+
+    def range_check_allocated_batch(self, min_range: BlsScalar, max_range: BlsScalar, witness_vars: torch.Tensor,
+                                    witness: torch.Tensor) -> torch.Tensor:
+        """for i: range_check(min, max, AllocatedScalar(witness_vars[i], witness[i])) on witnesses allocated before"""
+        assert witness.is_cuda and witness.dtype == torch.int64 and witness.dim() == 2 and witness.is_contiguous()
+        assert witness_vars.is_cuda and witness_vars.dtype == torch.int64 and witness_vars.shape == (witness.shape[0],)
+        res = torch.empty((witness.shape[0],), dtype=torch.int64, device=witness.device)
+        _chk(self._lib.pg_composer_range_check_allocated_batch(self._h, C.byref(min_range.c), C.byref(max_range.c),
+                                                               witness_vars.data_ptr(), witness.data_ptr(), witness.shape[0],
+                                                               res.data_ptr()), "pg_composer_range_check_allocated_batch")
+        return res
+
     # -- read-back ----------------------------------------------------------------------------------------
     def value(self, v: Variable) -> BlsScalar:
         out = _lib.Scalar()

@@ -3,14 +3,24 @@
 // dusk-plonk records, per gate, the four wire positions of the row under their Variables
 // (perm.add_variables_to_map) and at preprocess time turns every Variable's position list -- in recording order:
 // gate by gate, left/right/output/fourth inside a gate -- into one cycle of the copy permutation
-// (compute_sigma_permutations).  Recording per call is pointless on a GPU; the same sigma is obtained at the end
-// from the wire columns alone:
-//   1. key[p] = Variable at position p, value[p] = p, with p = 4*gate + wire (ascending p == recording order);
-//   2. stable LSD radix sort of (key, value) by key  -- rocprim::radix_sort_pairs (AMD's device primitive library;
-//      the only library call on this path);
-//   3. neighbours in the sorted order with equal keys are consecutive positions of one Variable; the last position
-//      of a Variable wraps to the first (first_of[var]);
-//   4. scatter sigma[wire][gate] = wire' * padded_n + gate'.
+// (compute_sigma_permutations).  Recording per call is pointless on a GPU; the same sigma is derived at the end from
+// the wire columns alone, in one pass over them and almost without sorting anything:
+//
+//   items   a batched gadget call leaves `batch` items of L rows / V Variables each (PermSeg).  One workgroup per item
+//           reads the item's 3L wires once (perm_item_kernel) and
+//             - links every position whose Variable belongs to the item: counting sort of the positions by Variable
+//               in LDS, successors staged in LDS, coalesced store of sigma;
+//             - links the cycle of zero_var, which sits on the fourth wire of (nearly) every row, by looking at the
+//               following row(s);
+//             - appends what is left (references to Variables created elsewhere, live fourth wires) to the sparse list;
+//   gaps    rows appended by single composer calls: zero chain as above, everything else to the sparse list
+//           (perm_gap_kernel);
+//   sparse  the list -- key = Variable << 33 | position -- is sorted (rocprim::radix_sort_keys, the only library call
+//           on this path) and neighbours with one Variable are linked (perm_sparse_link_kernel).  A Variable can only
+//           be referenced after it was created, so the sparse positions of an item's Variable all come after the
+//           item's rows: its cycle is local positions, then sparse positions, spliced by perm_splice_kernel.
+//
+// Positions are ordered p = 4*gate + wire (== recording order); sigma is encoded wire * padded_n + gate.
 #pragma once
 
 #include <cstring>
@@ -21,43 +31,282 @@
 
 namespace pg {
 
-__global__ __launch_bounds__(kThreads) void perm_keys_kernel(const ComposerCols C, uint64_t n, uint64_t zero_var, uint32_t *keys,
-                                                            uint64_t *vals) {
-    for (uint64_t p = (uint64_t)blockIdx.x * kThreads + threadIdx.x; p < 4 * n; p += (uint64_t)gridDim.x * kThreads) {
-        const uint64_t gate = p >> 2;
-        const uint32_t wire = (uint32_t)(p & 3);
-        keys[p] = (uint32_t)(wire == 3 ? zero_var : C.w[wire][gate]);
-        vals[p] = p;
+// footprint of batched calls: items of L rows / V Variables; item i owns rows [gate_base + i L, +L) and Variables
+// [var_base + i V, +V), all created by the item itself
+struct PermSeg {
+    uint64_t gate_base, gate_end, var_base, var_end;
+    uint32_t L, V;
+};
+
+struct PermCtx {
+    ComposerCols C;
+    uint64_t n, padded_n, zero_var;
+    const PermSeg *segs;
+    uint32_t n_segs;
+    const FourthWire *fw;
+    uint32_t n_fw;
+    uint64_t fw_lo, fw_span;  // live fourth wires only on gates [fw_lo, fw_lo + fw_span]
+    uint32_t pos_bits;        // bits of a position 4 * gate + wire; sparse key = Variable << pos_bits | position
+};
+
+constexpr uint32_t kPermIters = 16;                               // gates per thread of the gap kernel
+constexpr uint64_t kPermChunk = (uint64_t)kThreads * kPermIters;  // gates per workgroup of the gap kernel
+constexpr uint32_t kPermLocalLdsLimit = 64 * 1024 - 256;
+constexpr uint32_t kPermNone = 0xFFFF, kPermDone = 0xFFFE;
+
+__device__ __forceinline__ uint64_t perm_encode(uint64_t gate, uint32_t wire, uint64_t padded_n) { return wire * padded_n + gate; }
+__device__ __forceinline__ uint64_t perm_encode_pos(uint64_t p, uint64_t padded_n) { return (p & 3) * padded_n + (p >> 2); }
+
+__device__ __forceinline__ uint64_t perm_fourth_var(const PermCtx &X, uint64_t g) {
+    if (g - X.fw_lo > X.fw_span) return X.zero_var;
+    for (uint32_t k = 0; k < X.n_fw; k++)
+        if (X.fw[k].gate == g) return X.fw[k].w_4;
+    return X.zero_var;
+}
+
+__device__ __forceinline__ uint32_t perm_zero_mask(const PermCtx &X, uint64_t g) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        if (X.C.w[k][g] == X.zero_var) m |= 1u << k;
+    if (perm_fourth_var(X, g) == X.zero_var) m |= 8u;
+    return m;
+}
+
+// first position of zero_var in gate g or later, wrapping past the end (the caller holds one, so there is one)
+__device__ uint64_t perm_next_zero_from(const PermCtx &X, uint64_t g) {
+    for (uint64_t tries = 0; tries <= X.n; tries++, g++) {
+        if (g >= X.n) g = 0;
+        const uint32_t m = perm_zero_mask(X, g);
+        if (m) return perm_encode(g, (uint32_t)__ffs((int)m) - 1, X.padded_n);
+    }
+    return 0;
+}
+
+__device__ __forceinline__ int perm_home_seg(const PermCtx &X, uint64_t var) {
+    uint32_t lo = 0, hi = X.n_segs;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (X.segs[mid].var_end <= var) lo = mid + 1; else hi = mid;
+    }
+    return lo < X.n_segs && X.segs[lo].var_base <= var ? (int)lo : -1;
+}
+
+struct PermSparse {
+    uint64_t *keys;               // Variable << 33 | position, in any order
+    unsigned long long *count;    // entries wanted so far (may pass cap: the host then grows the list and runs again)
+    uint64_t cap;
+};
+
+__device__ __forceinline__ void perm_sparse_put(const PermCtx &X, const PermSparse &Q, uint64_t at, uint64_t var, uint64_t gate,
+                                                uint32_t wire) {
+    if (at < Q.cap) Q.keys[at] = var << X.pos_bits | (4 * gate + wire);
+}
+
+// rows [g_begin, g_end) appended by single composer calls: zero chain + sparse list
+__global__ __launch_bounds__(kThreads) void perm_gap_kernel(const PermCtx X, uint64_t g_begin, uint64_t g_end, const PermSparse Q,
+                                                           uint64_t *sigma) {
+    __shared__ uint64_t s_warp[4];
+    __shared__ uint64_t s_base;
+    for (uint32_t it = 0; it < kPermIters; it++) {
+        const uint64_t g = g_begin + (uint64_t)blockIdx.x * kPermChunk + (uint64_t)it * kThreads + threadIdx.x;
+        uint64_t var[4];
+        uint32_t zero = 0, sparse = 0;
+        if (g < g_end) {
+#pragma unroll
+            for (int w = 0; w < 3; w++) var[w] = X.C.w[w][g];
+            var[3] = perm_fourth_var(X, g);
+#pragma unroll
+            for (uint32_t w = 0; w < 4; w++) {
+                if (var[w] == X.zero_var) zero |= 1u << w; else sparse |= 1u << w;
+            }
+            if (zero) {
+                uint64_t succ = perm_next_zero_from(X, g + 1);
+                for (uint32_t m = zero; m;) {  // wires from the highest down: each links to the one found before
+                    const uint32_t w = 31 - __clz((int)m);
+                    m &= ~(1u << w);
+                    sigma[perm_encode(g, w, X.padded_n)] = succ;
+                    succ = perm_encode(g, w, X.padded_n);
+                }
+            }
+        }
+        uint64_t tot;
+        uint64_t at = block_exclusive_scan(__popc(sparse), s_warp, tot);
+        if (threadIdx.x == 0) s_base = tot ? atomicAdd(Q.count, (unsigned long long)tot) : 0;
+        __syncthreads();
+        at += s_base;
+        for (uint32_t w = 0; w < 4; w++)
+            if (sparse >> w & 1) perm_sparse_put(X, Q, at++, var[w], g, w);
+        __syncthreads();
     }
 }
 
-__global__ void perm_patch_fourth_kernel(const FourthWire *fw, uint32_t n_fw, uint32_t *keys) {
-    if (threadIdx.x < n_fw) keys[4 * fw[threadIdx.x].gate + 3] = (uint32_t)fw[threadIdx.x].w_4;
-}
+// one workgroup per item of a batched segment.  Dynamic LDS: cnt[V] off[V+1] (u32), lw[3L] pos[3L] sig[4L] (u16), zm[L] (u8)
+__host__ __device__ inline uint32_t perm_local_lds_bytes(uint32_t L, uint32_t V) { return 4 * (2 * V + 1) + 2 * 10 * L + L + 16; }
 
-// heads of the runs of equal keys publish the Variable's first position
-__global__ __launch_bounds__(kThreads) void perm_heads_kernel(const uint32_t *keys, const uint64_t *vals, uint64_t P,
-                                                             uint64_t *first_of) {
-    for (uint64_t j = (uint64_t)blockIdx.x * kThreads + threadIdx.x; j < P; j += (uint64_t)gridDim.x * kThreads)
-        if (j == 0 || keys[j - 1] != keys[j]) first_of[keys[j]] = vals[j];
-}
-
-__device__ __forceinline__ uint64_t perm_encode(uint64_t p, uint64_t padded_n) { return (p & 3) * padded_n + (p >> 2); }
-
-__global__ __launch_bounds__(kThreads) void perm_link_kernel(const uint32_t *keys, const uint64_t *vals, uint64_t P,
-                                                            const uint64_t *first_of, uint64_t padded_n, uint64_t *sigma) {
-    for (uint64_t j = (uint64_t)blockIdx.x * kThreads + threadIdx.x; j < P; j += (uint64_t)gridDim.x * kThreads) {
-        const uint64_t succ = (j + 1 < P && keys[j + 1] == keys[j]) ? vals[j + 1] : first_of[keys[j]];
-        sigma[perm_encode(vals[j], padded_n)] = perm_encode(succ, padded_n);
+__global__ __launch_bounds__(kThreads) void perm_item_kernel(const PermCtx X, const PermSeg S, uint64_t batch, const PermSparse Q,
+                                                            uint64_t *sigma) {
+    extern __shared__ uint32_t perm_lds[];
+    __shared__ uint64_t s_warp[4];
+    const uint32_t L = S.L, V = S.V, n3 = 3 * L, tid = threadIdx.x;
+    uint32_t *cnt = perm_lds, *off = cnt + V;
+    uint16_t *lw = reinterpret_cast<uint16_t *>(off + V + 1), *pos = lw + n3, *sig = pos + n3;
+    uint8_t *zm = reinterpret_cast<uint8_t *>(sig + 4 * L);
+    for (uint64_t item = blockIdx.x; item < batch; item += gridDim.x) {
+        const uint64_t g0 = S.gate_base + item * L, v0 = S.var_base + item * V;
+        for (uint32_t id = tid; id < V; id += kThreads) cnt[id] = 0;
+        __syncthreads();
+        for (uint32_t r = tid; r < L; r += kThreads) {
+            uint32_t zero = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 3; w++) {
+                const uint64_t var = X.C.w[w][g0 + r], rel = var - v0;
+                uint32_t id = kPermNone;
+                if (var == X.zero_var) zero |= 1u << w;
+                else if (rel < (uint64_t)V) atomicAdd(&cnt[id = (uint32_t)rel], 1u);
+                else perm_sparse_put(X, Q, atomicAdd(Q.count, 1ull), var, g0 + r, w);
+                lw[3 * r + w] = (uint16_t)id;
+                sig[4 * r + w] = (uint16_t)kPermNone;
+            }
+            const uint64_t var4 = perm_fourth_var(X, g0 + r);
+            if (var4 == X.zero_var) zero |= 8u;
+            else perm_sparse_put(X, Q, atomicAdd(Q.count, 1ull), var4, g0 + r, 3);
+            sig[4 * r + 3] = (uint16_t)kPermNone;
+            zm[r] = (uint8_t)zero;
+        }
+        __syncthreads();
+        {  // off = exclusive scan of cnt; cnt becomes the scatter cursor
+            const uint32_t per = (V + kThreads - 1) / kThreads, b = tid * per, e = b + per < V ? b + per : V;
+            uint64_t sum = 0, tot;
+            for (uint32_t id = b; id < e; id++) sum += cnt[id];
+            uint32_t run = (uint32_t)block_exclusive_scan(sum, s_warp, tot);
+            for (uint32_t id = b; id < e; id++) {
+                off[id] = run;
+                run += cnt[id];
+                cnt[id] = 0;
+            }
+            if (tid == 0) off[V] = (uint32_t)tot;
+        }
+        __syncthreads();
+        for (uint32_t j = tid; j < n3; j += kThreads) {
+            const uint32_t id = lw[j];
+            if (id != kPermNone) pos[off[id] + atomicAdd(&cnt[id], 1u)] = (uint16_t)j;
+        }
+        __syncthreads();
+        for (uint32_t id = tid; id < V; id += kThreads) {
+            const uint32_t b = off[id], k = off[id + 1] - b;
+            for (uint32_t i = 1; i < k; i++) {  // the atomics scattered in any order: restore position order
+                const uint16_t x = pos[b + i];
+                uint32_t h = i;
+                while (h > 0 && pos[b + h - 1] > x) {
+                    pos[b + h] = pos[b + h - 1];
+                    h--;
+                }
+                pos[b + h] = x;
+            }
+            for (uint32_t i = 0; i < k; i++) {  // 3 r + w -> 4 r + w
+                const uint32_t a = pos[b + i], z = pos[b + (i + 1 == k ? 0 : i + 1)];
+                sig[a + a / 3] = (uint16_t)(z + z / 3);
+            }
+        }
+        for (uint32_t r = tid; r < L; r += kThreads) {  // zero chain
+            const uint32_t zero = zm[r];
+            if (!zero) continue;
+            uint32_t nr = r + 1;
+            while (nr < L && zm[nr] == 0) nr++;
+            uint32_t succ = nr < L ? 4 * nr + (uint32_t)__ffs((int)zm[nr]) - 1 : kPermDone;
+            for (uint32_t m = zero; m;) {
+                const uint32_t w = 31 - __clz((int)m);
+                m &= ~(1u << w);
+                if (succ == kPermDone) sigma[perm_encode(g0 + r, w, X.padded_n)] = perm_next_zero_from(X, g0 + L);
+                sig[4 * r + w] = (uint16_t)succ;
+                succ = 4 * r + w;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t w = 0; w < 4; w++)
+            for (uint32_t r = tid; r < L; r += kThreads) {
+                const uint32_t s = sig[4 * r + w];
+                if (s < kPermDone) sigma[perm_encode(g0 + r, w, X.padded_n)] = perm_encode(g0 + (s >> 2), s & 3, X.padded_n);
+            }
+        __syncthreads();
     }
 }
 
-// rows >= circuit size keep the identity
+// the sorted sparse list: neighbours with one Variable are consecutive positions of it; the last one wraps to the
+// first unless the Variable belongs to a batched item (perm_splice_kernel closes that cycle)
+__global__ __launch_bounds__(kThreads) void perm_sparse_link_kernel(const PermCtx X, const uint64_t *keys, uint64_t nS,
+                                                                   uint64_t *sigma) {
+    const uint64_t pos_mask = (1ull << X.pos_bits) - 1;
+    for (uint64_t j = (uint64_t)blockIdx.x * kThreads + threadIdx.x; j < nS; j += (uint64_t)gridDim.x * kThreads) {
+        const uint64_t key = keys[j], v = key >> X.pos_bits;
+        uint64_t succ;
+        if (j + 1 < nS && keys[j + 1] >> X.pos_bits == v) succ = keys[j + 1];
+        else {
+            if (perm_home_seg(X, v) >= 0) continue;
+            uint64_t h = j;
+            while (h > 0 && keys[h - 1] >> X.pos_bits == v) h--;
+            succ = keys[h];
+        }
+        sigma[perm_encode_pos(key & pos_mask, X.padded_n)] = perm_encode_pos(succ & pos_mask, X.padded_n);
+    }
+}
+
+// one wave per sparse run whose Variable belongs to a batched item: the item's rows are searched for its local positions
+// (already one closed cycle, ascending) and the two lists are joined: local first..last -> sparse first..last -> local first
+__global__ __launch_bounds__(kThreads) void perm_splice_kernel(const PermCtx X, const uint64_t *keys, uint64_t nS, uint64_t *sigma) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t pos_mask = (1ull << X.pos_bits) - 1;
+    const uint64_t waves = (uint64_t)gridDim.x * (kThreads / 64);
+    for (uint64_t j = (uint64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6); j < nS; j += waves) {
+        const uint64_t v = keys[j] >> X.pos_bits;
+        if (j > 0 && keys[j - 1] >> X.pos_bits == v) continue;
+        const int si = perm_home_seg(X, v);
+        if (si < 0) continue;
+        const PermSeg s = X.segs[si];
+        const uint64_t g0 = s.gate_base + (v - s.var_base) / s.V * s.L;
+        uint64_t lo = ~0ull, hi = 0;
+        bool found = false;
+        for (uint32_t w = 0; w < 3; w++)
+            for (uint32_t r = lane; r < s.L; r += 64)
+                if (X.C.w[w][g0 + r] == v) {
+                    const uint64_t p = 4 * (g0 + r) + w;
+                    lo = p < lo ? p : lo;
+                    hi = p > hi ? p : hi;
+                    found = true;
+                }
+        for (int d = 32; d; d >>= 1) {
+            const uint64_t olo = __shfl_xor(lo, d, 64), ohi = __shfl_xor(hi, d, 64);
+            lo = olo < lo ? olo : lo;
+            hi = ohi > hi ? ohi : hi;
+        }
+        found = __any(found);
+        if (lane) continue;
+        uint64_t e = j;
+        while (e + 1 < nS && keys[e + 1] >> X.pos_bits == v) e++;
+        const uint64_t first = perm_encode_pos(keys[j] & pos_mask, X.padded_n), last = perm_encode_pos(keys[e] & pos_mask, X.padded_n);
+        if (!found) sigma[last] = first;
+        else {
+            sigma[perm_encode_pos(hi, X.padded_n)] = first;
+            sigma[last] = perm_encode_pos(lo, X.padded_n);
+        }
+    }
+}
+
+// rows >= circuit size keep the identity: 16-byte stores over the four runs [wire * padded_n + n, (wire + 1) * padded_n)
 __global__ __launch_bounds__(kThreads) void perm_identity_kernel(uint64_t *sigma, uint64_t n, uint64_t padded_n) {
-    const uint64_t pad = padded_n - n;
-    for (uint64_t t = (uint64_t)blockIdx.x * kThreads + threadIdx.x; t < 4 * pad; t += (uint64_t)gridDim.x * kThreads) {
-        const uint64_t wire = t / pad, gate = n + t % pad;
-        sigma[wire * padded_n + gate] = wire * padded_n + gate;
+    typedef unsigned long long __attribute__((ext_vector_type(2))) u64x2;
+    for (uint32_t wire = 0; wire < 4; wire++) {
+        uint64_t lo = wire * padded_n + n, hi = (wire + 1) * padded_n;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (lo & 1) sigma[lo] = lo;
+            if (hi & 1) sigma[hi - 1] = hi - 1;
+        }
+        lo += lo & 1;
+        hi -= hi & 1;
+        for (uint64_t i = lo + 2 * ((uint64_t)blockIdx.x * kThreads + threadIdx.x); i < hi; i += 2 * (uint64_t)gridDim.x * kThreads)
+            *reinterpret_cast<u64x2 *>(sigma + i) = u64x2{i, i + 1};
     }
 }
 

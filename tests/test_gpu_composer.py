@@ -317,3 +317,128 @@ def test_scalar_decomposition_reference_unit_test(engine):
     dev = pg.StandardComposer(engine)
     with pytest.raises(pg.PgError, match="num_bits"):
         pg.scalar_decomposition_gadget(dev, 257, pg.AllocatedScalar.allocate(dev, S(5)))
+
+
+def _sigma_properties(dev, padded):
+    """size-independent check of sigma, on the device: it is a permutation of the 4 * padded positions, it only links
+    positions of one Variable, and walking a Variable's cycle the position 4 * gate + wire (= recording order) goes down
+    exactly once (or the position maps to itself) -- i.e. every Variable's positions form ONE cycle in ascending order"""
+    n = dev.circuit_size()
+    sig = dev.permutation(padded).view(-1)
+    P = 4 * padded
+    assert torch.equal(torch.sort(sig).values, torch.arange(P, device=sig.device, dtype=sig.dtype))
+    exp = dev.export()
+    w4 = dev.materialize()["w_4"]
+    wires = torch.full((4, padded), -1, dtype=torch.int64, device=sig.device)
+    for k, name in enumerate(("w_l", "w_r", "w_o")):
+        wires[k, :n] = torch.from_numpy(exp[name].view(np.int64)).to(sig.device)
+    wires[3, :n] = w4.view(torch.int64)
+    # padding rows: distinct pseudo-variables, each mapping to itself
+    pad = torch.arange(P, device=sig.device, dtype=torch.int64).view(4, padded)[:, n:]
+    wires[:, n:] = -2 - pad
+    flat = wires.view(-1)
+    assert torch.equal(flat[sig], flat)
+    gate, wire = torch.arange(P, device=sig.device) % padded, torch.arange(P, device=sig.device) // padded
+    order = 4 * gate + wire
+    succ_order = 4 * (sig % padded) + sig // padded
+    wraps = int((succ_order <= order).sum())
+    assert wraps == int(torch.unique(flat).numel())
+
+
+def test_permutation_two_segments_and_later_references(engine):
+    """two batched calls with different ladders, single calls before, between and after them that reference result
+    Variables of both (the cycle of such a Variable is spliced: local positions, then the sorted ones), a Variable
+    referenced many times, and a constrain_to_constant row -- sigma vs the oracle's per-gate bookkeeping"""
+    from oracle import pyoracle as po
+    dev, ora = pg.StandardComposer(engine, 1 << 16, 1 << 16), po.Composer()
+    x = dev.add_input(S(9))
+    ox = ora.add_input(synth.mont(9))
+    assert x == ox
+    segs = [(0, 2**16, synth.uniform_below(37, 2**16 + 2**14, seed=3)), (50_000, 250_000, synth.scalars_from_ints([7, 60_000, 250_001] * 5))]
+    res_all = []
+    for k, (mn, mx, wit) in enumerate(segs):
+        res = dev.range_check_batch(S(mn), S(mx), torch.from_numpy(wit.view(np.int64)).to("cuda:0")).cpu().numpy().view(np.uint64)
+        ores = [int(ora.L.range_check(ora.c, po.fr(synth.mont(mn)), po.fr(synth.mont(mx)), ora.allocate(w))) for w in wit]
+        assert list(res) == ores
+        res_all.append(ores)
+        # between the segments: results of this batch, and x again and again
+        for r in ores[:5] + ores[-2:]:
+            y = pg.conditionally_select_one(dev, x, int(r))
+            assert y == int(ora.L.conditionally_select_one(ora.c, ox, int(r)))
+            dev.boolean_gate(int(r))
+            ora.L.composer_boolean_gate(ora.c, int(r))
+    # after both: one result of the FIRST batch again, twice, and its neighbour never
+    r0 = res_all[0][3]
+    for _ in range(2):
+        pg.conditionally_select_zero(dev, r0, res_all[1][0])
+        ora.L.conditionally_select_zero(ora.c, r0, res_all[1][0])
+    dev.constrain_to_constant(res_all[1][1], S(0), None)
+    ora.L.composer_constrain_to_constant(ora.c, res_all[1][1], po.fr(synth.mont(0)), None)
+    same(dev, ora)
+    n = dev.circuit_size()
+    for padded in (n, 1 << (n - 1).bit_length()):
+        assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded))
+    _sigma_properties(dev, 1 << (n - 1).bit_length())
+    # asking twice reuses the composer's scratch and gives the same answer
+    assert torch.equal(dev.permutation(n), dev.permutation(n))
+
+
+def test_permutation_properties_at_scale(engine):
+    """2^13 x range_check(0, 2^254) = 8.4 M rows, 33.8 M wire positions: the size-independent properties of sigma"""
+    batch = 1 << 13
+    dev = pg.StandardComposer(engine, 3 + batch * 1031 + 8, 5 + batch * 1034 + 8)
+    wit = torch.from_numpy(synth.uniform_below(batch, 2**254 + 2**250, seed=4).view(np.int64)).to("cuda:0")
+    res = dev.range_check_batch(S(0), S(2**254), wit)
+    pg.conditionally_select_one(dev, int(res[5]), int(res[batch - 1]))
+    n = dev.circuit_size()
+    _sigma_properties(dev, 1 << (n - 1).bit_length())
+
+
+def _allocated_batch_case(engine, batch=40, seed=8):
+    """allocate a batch, then range_check on the allocated witnesses (the reference's order when the caller allocates),
+    twice over the same Variables with different ranges, on the device composer and on the oracle"""
+    from oracle import pyoracle as po
+    dev, ora = pg.StandardComposer(engine, 1 << 19, 1 << 19), po.Composer()
+    wit = synth.uniform_below(batch, 2**16 + 2**14, seed=seed)
+    d_wit = torch.from_numpy(wit.view(np.int64)).to("cuda:0")
+    first = dev.add_input_batch(d_wit)
+    allocs = [ora.allocate(w) for w in wit]
+    assert first == int(allocs[0].var) and dev.num_variables() == ora.num_vars
+    wv = torch.arange(first, first + batch, dtype=torch.int64, device="cuda:0")
+    for mn, mx in ((0, 2**16), (1000, 70_000)):
+        res = dev.range_check_allocated_batch(S(mn), S(mx), wv, d_wit).cpu().numpy().view(np.uint64)
+        ores = [int(ora.L.range_check(ora.c, po.fr(synth.mont(mn)), po.fr(synth.mont(mx)), a)) for a in allocs]
+        assert list(res) == ores
+    pg.conditionally_select_one(dev, first + 1, int(res[0]))
+    ora.L.conditionally_select_one(ora.c, first + 1, int(res[0]))
+    return dev, ora
+
+
+def test_allocated_batch_on_the_composer(engine):
+    """pg_composer_add_input_batch + pg_composer_range_check_allocated_batch: columns, satisfiability and sigma -- every
+    item references a Variable created before the batch, i.e. positions inside the items go through the sorted list"""
+    dev, ora = _allocated_batch_case(engine)
+    same(dev, ora)
+    assert dev.check() == -1 and ora.check() == -1
+    n = dev.circuit_size()
+    padded = 1 << (n - 1).bit_length()
+    assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded))
+    _sigma_properties(dev, padded)
+
+
+def test_permutation_sparse_list_regrows():
+    """PG_PERM_SLACK=0: the sorted list is sized for the rows of single calls only, the witness references inside the
+    items overflow it, and the pass runs a second time with the reported size (own process: the knob is read once)"""
+    import os
+    import subprocess
+    import sys
+    code = ("import numpy as np, plonk_gadgets_amd as pg, tests.test_gpu_composer as t\n"
+            "dev, ora = t._allocated_batch_case(pg.Engine(0), batch=300, seed=9)\n"
+            "n = dev.circuit_size(); padded = 1 << (n - 1).bit_length()\n"
+            "assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded))\n"
+            "assert np.array_equal(dev.permutation(n).cpu().numpy().view(np.uint64), ora.sigma(n))\n"
+            "print('regrow ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PG_PERM_SLACK="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "regrow ok" in out.stdout, out.stdout + out.stderr

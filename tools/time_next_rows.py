@@ -1,0 +1,42 @@
+"""Times the 'next' rows of SURVEY section 8f on a large batched circuit: f1 pg_composer_materialize, f2
+pg_composer_permutation, and pg_composer_check, on a composer holding `batch` x range_check(0, 2^254).
+usage: python tools/time_next_rows.py [log2_batch ...]"""
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+import plonk_gadgets_amd as pg
+from plonk_gadgets_amd import synth
+
+
+def main():
+    eng = pg.Engine(0)
+    S = pg.BlsScalar.from_int
+    for lg in [int(a) for a in sys.argv[1:]] or [12, 14, 16]:
+        batch = 1 << lg
+        rows, nvars = 3 + batch * 1031, 5 + batch * 1034
+        dev = pg.StandardComposer(eng, rows + 8, nvars + 8)
+        wit = torch.from_numpy(synth.uniform_below(batch, 2**254 + 2**250, seed=1).view(np.int64)).to("cuda:0")
+        torch.cuda.synchronize()
+        t = time.perf_counter(); dev.range_check_batch(S(0), S(2**254), wit); torch.cuda.synchronize(); t_emit = time.perf_counter() - t
+        n = dev.circuit_size()
+        padded = 1 << (n - 1).bit_length()
+        out = {"batch": batch, "rows": n, "padded": padded, "emit_ms": round(t_emit * 1e3, 2)}
+        for name, fn in (("check", dev.check), ("materialize", dev.materialize), ("permutation", lambda: dev.permutation(padded))):
+            best = 1e9
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t = time.perf_counter(); r = fn(); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t)
+                del r
+            out[name + "_ms"] = round(best * 1e3, 2)
+            out[name + "_rows_per_s"] = float("%.3g" % (n / best))
+        print(json.dumps(out), flush=True)
+        del dev, wit
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
