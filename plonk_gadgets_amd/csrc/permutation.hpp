@@ -51,6 +51,7 @@ struct PermCtx {
 
 constexpr uint32_t kPermIters = 16;                               // gates per thread of the gap kernel
 constexpr uint64_t kPermChunk = (uint64_t)kThreads * kPermIters;  // gates per workgroup of the gap kernel
+constexpr uint32_t kPermRowsPerThread = 5;  // item kernel: rows loaded per thread before any is processed
 constexpr uint32_t kPermLocalLdsLimit = 64 * 1024 - 256;
 constexpr uint32_t kPermNone = 0xFFFF, kPermDone = 0xFFFE;
 
@@ -156,23 +157,35 @@ __global__ __launch_bounds__(kThreads) void perm_item_kernel(const PermCtx X, co
         const uint64_t g0 = S.gate_base + item * L, v0 = S.var_base + item * V;
         for (uint32_t id = tid; id < V; id += kThreads) cnt[id] = 0;
         __syncthreads();
-        for (uint32_t r = tid; r < L; r += kThreads) {
-            uint32_t zero = 0;
+        for (uint32_t rb = 0; rb < L; rb += kPermRowsPerThread * kThreads) {  // 15 loads in flight per thread
+            uint64_t var[kPermRowsPerThread][3];
 #pragma unroll
-            for (uint32_t w = 0; w < 3; w++) {
-                const uint64_t var = X.C.w[w][g0 + r], rel = var - v0;
-                uint32_t id = kPermNone;
-                if (var == X.zero_var) zero |= 1u << w;
-                else if (rel < (uint64_t)V) atomicAdd(&cnt[id = (uint32_t)rel], 1u);
-                else perm_sparse_put(X, Q, atomicAdd(Q.count, 1ull), var, g0 + r, w);
-                lw[3 * r + w] = (uint16_t)id;
-                sig[4 * r + w] = (uint16_t)kPermNone;
+            for (uint32_t u = 0; u < kPermRowsPerThread; u++) {
+                const uint32_t r = rb + u * kThreads + tid;
+#pragma unroll
+                for (uint32_t w = 0; w < 3; w++) var[u][w] = r < L ? X.C.w[w][g0 + r] : 0;
             }
-            const uint64_t var4 = perm_fourth_var(X, g0 + r);
-            if (var4 == X.zero_var) zero |= 8u;
-            else perm_sparse_put(X, Q, atomicAdd(Q.count, 1ull), var4, g0 + r, 3);
-            sig[4 * r + 3] = (uint16_t)kPermNone;
-            zm[r] = (uint8_t)zero;
+#pragma unroll
+            for (uint32_t u = 0; u < kPermRowsPerThread; u++) {
+                const uint32_t r = rb + u * kThreads + tid;
+                if (r >= L) continue;
+                uint32_t zero = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < 3; w++) {
+                    const uint64_t rel = var[u][w] - v0;
+                    uint32_t id = kPermNone;
+                    if (var[u][w] == X.zero_var) zero |= 1u << w;
+                    else if (rel < (uint64_t)V) atomicAdd(&cnt[id = (uint32_t)rel], 1u);
+                    else perm_sparse_put(X, Q, atomicAdd(Q.count, 1ull), var[u][w], g0 + r, w);
+                    lw[3 * r + w] = (uint16_t)id;
+                    sig[4 * r + w] = (uint16_t)kPermNone;
+                }
+                const uint64_t var4 = perm_fourth_var(X, g0 + r);
+                if (var4 == X.zero_var) zero |= 8u;
+                else perm_sparse_put(X, Q, atomicAdd(Q.count, 1ull), var4, g0 + r, 3);
+                sig[4 * r + 3] = (uint16_t)kPermNone;
+                zm[r] = (uint8_t)zero;
+            }
         }
         __syncthreads();
         {  // off = exclusive scan of cnt; cnt becomes the scatter cursor
@@ -294,9 +307,11 @@ __global__ __launch_bounds__(kThreads) void perm_splice_kernel(const PermCtx X, 
     }
 }
 
-// rows >= circuit size keep the identity: 16-byte stores over the four runs [wire * padded_n + n, (wire + 1) * padded_n)
+// rows >= circuit size keep the identity: 16-byte stores over the four runs [wire * padded_n + n, (wire + 1) * padded_n),
+// each workgroup writing contiguous 1 MiB pieces
 __global__ __launch_bounds__(kThreads) void perm_identity_kernel(uint64_t *sigma, uint64_t n, uint64_t padded_n) {
     typedef unsigned long long __attribute__((ext_vector_type(2))) u64x2;
+    constexpr uint64_t kPiece = 131072;  // entries
     for (uint32_t wire = 0; wire < 4; wire++) {
         uint64_t lo = wire * padded_n + n, hi = (wire + 1) * padded_n;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -305,8 +320,10 @@ __global__ __launch_bounds__(kThreads) void perm_identity_kernel(uint64_t *sigma
         }
         lo += lo & 1;
         hi -= hi & 1;
-        for (uint64_t i = lo + 2 * ((uint64_t)blockIdx.x * kThreads + threadIdx.x); i < hi; i += 2 * (uint64_t)gridDim.x * kThreads)
-            *reinterpret_cast<u64x2 *>(sigma + i) = u64x2{i, i + 1};
+        for (uint64_t base = lo + (uint64_t)blockIdx.x * kPiece; base < hi; base += (uint64_t)gridDim.x * kPiece) {
+            const uint64_t end = base + kPiece < hi ? base + kPiece : hi;
+            for (uint64_t i = base + 2 * threadIdx.x; i < end; i += 2 * kThreads) *reinterpret_cast<u64x2 *>(sigma + i) = u64x2{i, i + 1};
+        }
     }
 }
 
