@@ -123,28 +123,50 @@ __global__ __launch_bounds__(kThreads) void check_kernel(const ComposerCols C, u
 }
 
 // ---- the rest of a prover-ready row ------------------------------------
-// constant selector column: the same scalar on every row
-__global__ __launch_bounds__(kThreads) void fill_scalar_kernel(uint4 *dst, uint64_t n_rows, const Fr value) {
-    FrVec t;
-    t.f = value;
-    const uint4 v = t.v[threadIdx.x & 1];
-    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < 2 * n_rows; i += (uint64_t)gridDim.x * kThreads)
-        store16(dst + i, v);
-}
-__global__ __launch_bounds__(kThreads) void fill_u64_kernel(uint64_t *dst, uint64_t n, uint64_t value) {
-    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kThreads) dst[i] = value;
-}
-__global__ void patch_fourth_kernel(uint4 *q_4, uint64_t *w_4, const FourthWire *fw, uint32_t n_fw) {
-    if (threadIdx.x < n_fw) {
-        put_fr(q_4, fw[threadIdx.x].gate, fw[threadIdx.x].q_4);
-        w_4[fw[threadIdx.x].gate] = fw[threadIdx.x].w_4;
+// constant columns (the selectors this path never switches on, q_arith = 1, the value column of a fourth wire that is
+// zero_var on every row): up to 7 columns per launch, each workgroup writing contiguous 1 MiB pieces of each
+struct ConstCols {
+    uint4 *p[7];
+    uint32_t n, one_mask;  // column k holds 1 (Montgomery R) if bit k of one_mask is set, else 0
+};
+__global__ __launch_bounds__(kThreads) void fill_columns_kernel(const ConstCols K, uint64_t n_rows) {
+    constexpr uint64_t kPiece = 65536;
+    FrVec one;
+    one.f = fr_one();
+    const uint4 v1 = one.v[threadIdx.x & 1], v0 = make_uint4(0, 0, 0, 0);
+    for (uint64_t base = (uint64_t)blockIdx.x * kPiece; base < 2 * n_rows; base += (uint64_t)gridDim.x * kPiece) {
+        const uint64_t end = base + kPiece < 2 * n_rows ? base + kPiece : 2 * n_rows;
+        for (uint32_t k = 0; k < K.n; k++) {
+            const uint4 v = K.one_mask >> k & 1 ? v1 : v0;
+            for (uint64_t i = base + threadIdx.x; i < end; i += kThreads) store16(K.p[k] + i, v);
+        }
     }
 }
-// wire VALUE column: out[i] = variables[w[i]] (what the prover interpolates); 16 B per lane
+__global__ __launch_bounds__(kThreads) void fill_u64_kernel(uint64_t *dst, uint64_t n, uint64_t value) {
+    constexpr uint64_t kPiece = 131072;
+    for (uint64_t base = (uint64_t)blockIdx.x * kPiece; base < n; base += (uint64_t)gridDim.x * kPiece) {
+        const uint64_t end = base + kPiece < n ? base + kPiece : n;
+        for (uint64_t i = base + threadIdx.x; i < end; i += kThreads) dst[i] = value;
+    }
+}
+// rows with a live fourth wire: q_4, w_4 and the value of w_4 (each may be NULL)
+__global__ void patch_fourth_kernel(uint4 *q_4, uint64_t *w_4, uint4 *w_4_value, const uint4 *vars, const FourthWire *fw,
+                                    uint32_t n_fw) {
+    if (threadIdx.x < n_fw) {
+        const FourthWire f = fw[threadIdx.x];
+        if (q_4) put_fr(q_4, f.gate, f.q_4);
+        if (w_4) w_4[f.gate] = f.w_4;
+        if (w_4_value) put_fr(w_4_value, f.gate, get_fr(vars, f.w_4));
+    }
+}
+// wire VALUE column: out[i] = variables[w[i]] (what the prover interpolates); 16 B per lane, contiguous pieces
 __global__ __launch_bounds__(kThreads) void gather_wire_values_kernel(const uint64_t *w, const uint4 *vars, uint64_t n_rows,
                                                                      uint4 *out) {
-    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < 2 * n_rows; i += (uint64_t)gridDim.x * kThreads)
-        store16(out + i, vars[2 * w[i >> 1] + (i & 1)]);
+    constexpr uint64_t kPiece = 32768;
+    for (uint64_t base = (uint64_t)blockIdx.x * kPiece; base < 2 * n_rows; base += (uint64_t)gridDim.x * kPiece) {
+        const uint64_t end = base + kPiece < 2 * n_rows ? base + kPiece : 2 * n_rows;
+        for (uint64_t i = base + threadIdx.x; i < end; i += kThreads) store16(out + i, vars[2 * w[i >> 1] + (i & 1)]);
+    }
 }
 // dense public-input vector from the sparse store (construct_dense_pi_vec)
 __global__ void scatter_pi_kernel(uint4 *dense, const uint64_t *pi_gate, const uint4 *pi_val, uint32_t n_pi) {
