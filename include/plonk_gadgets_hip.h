@@ -100,6 +100,10 @@ void pg_scalar_add(const pg_scalar *a, const pg_scalar *b, pg_scalar *out);
 void pg_scalar_sub(const pg_scalar *a, const pg_scalar *b, pg_scalar *out);
 void pg_scalar_neg(const pg_scalar *a, pg_scalar *out);
 void pg_scalar_mul(const pg_scalar *a, const pg_scalar *b, pg_scalar *out);
+/* BlsScalar::invert (used at src/scalar.rs:73,121): PG_ERR_NON_EXISTING_INVERSE and *out = 0 for zero.  The same
+ * division-step inversion the device pre-pass runs; pg_scalar_invert_fermat is a^(q-2), its independent cross-check. */
+pg_status pg_scalar_invert(const pg_scalar *a, pg_scalar *out);
+pg_status pg_scalar_invert_fermat(const pg_scalar *a, pg_scalar *out);
 uint64_t pg_bits_count(const pg_scalar *s);                    /* src/range.rs:173-181 */
 uint64_t pg_num_bits_closest_power_of_two(const pg_scalar *s); /* src/range.rs:185-189 */
 

@@ -57,6 +57,8 @@ SIGNATURES = {
     "pg_scalar_sub": (None, [_P(Scalar), _P(Scalar), _P(Scalar)]),
     "pg_scalar_neg": (None, [_P(Scalar), _P(Scalar)]),
     "pg_scalar_mul": (None, [_P(Scalar), _P(Scalar), _P(Scalar)]),
+    "pg_scalar_invert": (C.c_int, [_P(Scalar), _P(Scalar)]),
+    "pg_scalar_invert_fermat": (C.c_int, [_P(Scalar), _P(Scalar)]),
     "pg_bits_count": (C.c_uint64, [_P(Scalar)]),
     "pg_num_bits_closest_power_of_two": (C.c_uint64, [_P(Scalar)]),
     "pg_range_check_layout": (C.c_int, [_P(Scalar), _P(Scalar), C.c_uint64, _P(LayoutC)]),

@@ -197,13 +197,16 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
     if constexpr (GD::kInv > 0) {
         const uint64_t elems = batch * GD::kInv;
         PG_TRY(ensure_inv_scratch(e, elems));
-#ifndef PG_INV_WAVES_PER_SIMD
-#define PG_INV_WAVES_PER_SIMD 1
+#ifndef PG_INV_LANES_PER_CU  // one wave per SIMD
+#define PG_INV_LANES_PER_CU 256
 #endif
-        const uint64_t lanes_wanted = (uint64_t)e->num_cus * 4 * 64 * PG_INV_WAVES_PER_SIMD;
+#ifndef PG_INV_MAX_PER_LANE
+#define PG_INV_MAX_PER_LANE 32
+#endif
+        const uint64_t lanes_wanted = (uint64_t)e->num_cus * PG_INV_LANES_PER_CU;
         uint64_t per_lane = (elems + lanes_wanted - 1) / lanes_wanted;
         if (per_lane < 1) per_lane = 1;
-        if (per_lane > 32) per_lane = 32;
+        if (per_lane > PG_INV_MAX_PER_LANE) per_lane = PG_INV_MAX_PER_LANE;
         const uint64_t lanes = (elems + per_lane - 1) / per_lane;
         const uint32_t blocks = (uint32_t)((lanes + pg::kThreads - 1) / pg::kThreads);
 #if defined(PG_SEQUENTIAL_PREPASS)  // A/B build: the pre-pass on the caller's stream, ahead of the emit kernel
@@ -377,6 +380,18 @@ void pg_scalar_add(const pg_scalar *a, const pg_scalar *b, pg_scalar *out) { fro
 void pg_scalar_sub(const pg_scalar *a, const pg_scalar *b, pg_scalar *out) { from_fr(pg::fr_sub(to_fr(a), to_fr(b)), out); }
 void pg_scalar_neg(const pg_scalar *a, pg_scalar *out) { from_fr(pg::fr_neg(to_fr(a)), out); }
 void pg_scalar_mul(const pg_scalar *a, const pg_scalar *b, pg_scalar *out) { from_fr(pg::fr_mul(to_fr(a), to_fr(b)), out); }
+pg_status pg_scalar_invert(const pg_scalar *a, pg_scalar *out) {
+    if (!a || !out) return fail(PG_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!is_reduced(to_fr(a))) return fail(PG_ERR_INVALID_ARGUMENT, "scalar is not a reduced BlsScalar");
+    from_fr(pg::fr_invert_or_zero(to_fr(a)), out);
+    return pg::fr_is_zero(to_fr(a)) ? fail(PG_ERR_NON_EXISTING_INVERSE, "zero has no inverse") : PG_OK;
+}
+pg_status pg_scalar_invert_fermat(const pg_scalar *a, pg_scalar *out) {
+    if (!a || !out) return fail(PG_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!is_reduced(to_fr(a))) return fail(PG_ERR_INVALID_ARGUMENT, "scalar is not a reduced BlsScalar");
+    from_fr(pg::fr_invert_fermat(to_fr(a)), out);
+    return pg::fr_is_zero(to_fr(a)) ? fail(PG_ERR_NON_EXISTING_INVERSE, "zero has no inverse") : PG_OK;
+}
 uint64_t pg_bits_count(const pg_scalar *s) { return pg::bits_count(to_fr(s)); }
 uint64_t pg_num_bits_closest_power_of_two(const pg_scalar *s) { return pg::num_bits_closest_power_of_two(to_fr(s)); }
 

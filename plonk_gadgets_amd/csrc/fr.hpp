@@ -219,10 +219,9 @@ PG_HD uint32_t raw_bit_length(const Fr &c) {
     return 0;
 }
 
-// a^(q-2): plain square-and-multiply over the fixed exponent.  Returns 0 for 0
-// (CtOption::unwrap_or(zero) at scalar.rs:122; the caller tests for zero where
-// the reference distinguishes, scalar.rs:73-80).
-PG_HD Fr fr_invert_or_zero(const Fr &a) {
+// a^(q-2): plain square-and-multiply over the fixed exponent (383 multiplications).  Kept as the independent
+// cross-check of fr_invert_or_zero (tests) -- the product path uses the divstep inversion below.
+PG_HD Fr fr_invert_fermat(const Fr &a) {
     const uint64_t E[4] = {0xfffffffeffffffffull, PG_Q1, PG_Q2, PG_Q3};  // q - 2
     Fr res = fr_one();
     bool started = false;
@@ -236,6 +235,159 @@ PG_HD Fr fr_invert_or_zero(const Fr &a) {
         }
     }
     return res;
+}
+
+// ---- inversion by division steps (Bernstein-Yang "safegcd", the 32-bit formulation with 30 steps per batch) ------
+// 20 batches of 30 branch-free division steps on (f, g) = (q, a) reduce g to 0 and f to +-1; every batch is
+// summarised by a 2x2 integer matrix that is then applied to the full-width (f, g) and, modulo q, to (d, e) with
+// d a = f, e a = g (mod q), so that at the end a^-1 = +-d.  600 steps cover any 256-bit input (590 suffice); the
+// count is fixed, the loop bodies have no data-dependent branches.  Cost: ~20 x (30 x 13 32-bit ops + ~100
+// 32x32->64 multiply-adds), about a tenth of the 383 Montgomery multiplications of the Fermat power -- which matters
+// because the batch inversion pre-pass (invert.hpp) is one sequential chain per lane.
+// Numbers are 9 signed limbs of 30 bits.
+struct Signed30 {
+    int32_t v[9];
+};
+#define PG_M30 0x3fffffff
+// q in 30-bit limbs; q^-1 mod 2^30 = 1 (q = 1 mod 2^32)
+#define PG_Q30 {0x1, 0x3ffffffc, 0x3fe5bfef, 0x2f6900bf, 0x21d80553, 0x27602026, 0x17d48333, 0x29d4ca67, 0x73ed}
+
+PG_HD void raw_to_signed30(const Fr &a, Signed30 &r) {
+    r.v[0] = (int32_t)(a.l[0] & PG_M30);
+    r.v[1] = (int32_t)((a.l[0] >> 30) & PG_M30);
+    r.v[2] = (int32_t)(((a.l[0] >> 60) | (a.l[1] << 4)) & PG_M30);
+    r.v[3] = (int32_t)((a.l[1] >> 26) & PG_M30);
+    r.v[4] = (int32_t)(((a.l[1] >> 56) | (a.l[2] << 8)) & PG_M30);
+    r.v[5] = (int32_t)((a.l[2] >> 22) & PG_M30);
+    r.v[6] = (int32_t)(((a.l[2] >> 52) | (a.l[3] << 12)) & PG_M30);
+    r.v[7] = (int32_t)((a.l[3] >> 18) & PG_M30);
+    r.v[8] = (int32_t)(a.l[3] >> 48);
+}
+PG_HD Fr signed30_to_raw(const Signed30 &r) {  // r normalised: limbs in [0, 2^30), value < 2^256
+    const uint64_t v0 = (uint32_t)r.v[0], v1 = (uint32_t)r.v[1], v2 = (uint32_t)r.v[2], v3 = (uint32_t)r.v[3], v4 = (uint32_t)r.v[4],
+                   v5 = (uint32_t)r.v[5], v6 = (uint32_t)r.v[6], v7 = (uint32_t)r.v[7], v8 = (uint32_t)r.v[8];
+    return Fr{{v0 | v1 << 30 | v2 << 60, v2 >> 4 | v3 << 26 | v4 << 56, v4 >> 8 | v5 << 22 | v6 << 52, v6 >> 12 | v7 << 18 | v8 << 48}};
+}
+
+// 30 division steps on the low limbs; t = {u, v, q, r} with 2^30 (f', g') = (u f + v g, q f + r g)
+// zeta = -(delta + 1/2) of the paper, so that its sign bit is the branch condition
+PG_HD int32_t divsteps_30(int32_t zeta, uint32_t f, uint32_t g, int32_t t[4]) {
+    uint32_t u = 1, v = 0, q = 0, r = 1;
+#pragma unroll
+    for (int i = 0; i < 30; i++) {
+        uint32_t c1 = (uint32_t)(zeta >> 31);  // delta > 0
+        const uint32_t c2 = 0u - (g & 1u);     // g odd
+        const uint32_t x = (f ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;  // +-(f, u, v)
+        g += x & c2;
+        q += y & c2;
+        r += z & c2;
+        c1 &= c2;  // swap: delta > 0 and g odd
+        zeta = (int32_t)((uint32_t)zeta ^ c1) - 1;
+        f += g & c1;
+        u += q & c1;
+        v += r & c1;
+        g >>= 1;
+        u <<= 1;
+        v <<= 1;
+    }
+    t[0] = (int32_t)u; t[1] = (int32_t)v; t[2] = (int32_t)q; t[3] = (int32_t)r;
+    return zeta;
+}
+
+// (f, g) <- t (f, g) / 2^30, exact
+PG_HD void update_fg_30(Signed30 &f, Signed30 &g, const int32_t t[4]) {
+    const int64_t u = t[0], v = t[1], q = t[2], r = t[3];
+    int64_t cf = u * f.v[0] + v * g.v[0], cg = q * f.v[0] + r * g.v[0];
+    cf >>= 30;
+    cg >>= 30;
+#pragma unroll
+    for (int i = 1; i < 9; i++) {
+        cf += u * f.v[i] + v * g.v[i];
+        cg += q * f.v[i] + r * g.v[i];
+        f.v[i - 1] = (int32_t)cf & PG_M30;
+        g.v[i - 1] = (int32_t)cg & PG_M30;
+        cf >>= 30;
+        cg >>= 30;
+    }
+    f.v[8] = (int32_t)cf;
+    g.v[8] = (int32_t)cg;
+}
+
+// (d, e) <- t (d, e) / 2^30 mod q: a multiple of q is added first so that the division is exact; d, e stay in (-2q, q)
+PG_HD void update_de_30(Signed30 &d, Signed30 &e, const int32_t t[4]) {
+    const int32_t Q30[9] = PG_Q30;
+    const int64_t u = t[0], v = t[1], q = t[2], r = t[3];
+    const int32_t sd = d.v[8] >> 31, se = e.v[8] >> 31;
+    int32_t md = (t[0] & sd) + (t[1] & se), me = (t[2] & sd) + (t[3] & se);
+    int64_t cd = u * d.v[0] + v * e.v[0], ce = q * d.v[0] + r * e.v[0];
+    md -= (int32_t)(((uint32_t)cd + (uint32_t)md) & PG_M30);  // q^-1 mod 2^30 = 1
+    me -= (int32_t)(((uint32_t)ce + (uint32_t)me) & PG_M30);
+    cd += (int64_t)Q30[0] * md;
+    ce += (int64_t)Q30[0] * me;
+    cd >>= 30;
+    ce >>= 30;
+#pragma unroll
+    for (int i = 1; i < 9; i++) {
+        cd += u * d.v[i] + v * e.v[i] + (int64_t)Q30[i] * md;
+        ce += q * d.v[i] + r * e.v[i] + (int64_t)Q30[i] * me;
+        d.v[i - 1] = (int32_t)cd & PG_M30;
+        e.v[i - 1] = (int32_t)ce & PG_M30;
+        cd >>= 30;
+        ce >>= 30;
+    }
+    d.v[8] = (int32_t)cd;
+    e.v[8] = (int32_t)ce;
+}
+
+// r in (-2q, q) -> [0, q), negated first if `negate` is all ones
+PG_HD void normalize_30(Signed30 &r, int32_t negate) {
+    const int32_t Q30[9] = PG_Q30;
+    int32_t add = r.v[8] >> 31;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = ((r.v[i] + (Q30[i] & add)) ^ negate) - negate;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        r.v[i + 1] += r.v[i] >> 30;
+        r.v[i] &= PG_M30;
+    }
+    add = r.v[8] >> 31;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] += Q30[i] & add;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        r.v[i + 1] += r.v[i] >> 30;
+        r.v[i] &= PG_M30;
+    }
+}
+
+// Montgomery form in, Montgomery form out: the steps run on the residue a = xR and give (xR)^-1 = x^-1 R^-1; one
+// Montgomery multiplication by R^3 turns that into x^-1 R.  Returns 0 for 0 (CtOption::unwrap_or(zero) at
+// scalar.rs:122; the caller tests for zero where the reference distinguishes, scalar.rs:73-80): with g = 0 the steps
+// leave d = 0.
+PG_HD Fr fr_invert_or_zero(const Fr &a) {
+#ifdef PG_INVERT_FERMAT  // A/B build (tools/ab_emit.py)
+    return fr_invert_fermat(a);
+#endif
+    const int32_t Q30[9] = PG_Q30;
+    Signed30 d, e, f, g;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        d.v[i] = 0;
+        e.v[i] = i == 0;
+        f.v[i] = Q30[i];
+    }
+    raw_to_signed30(a, g);
+    int32_t zeta = -1;
+#pragma unroll 1
+    for (int it = 0; it < 20; it++) {
+        int32_t t[4];
+        zeta = divsteps_30(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
+        update_de_30(d, e, t);
+        update_fg_30(f, g, t);
+    }
+    normalize_30(d, f.v[8] >> 31);
+    const Fr r3{{0xc62c1807439b73afull, 0x1b3e0d188cf06990ull, 0x73d13c71c7b5f418ull, 0x6e2a5bb9c8db33e9ull}};  // R^3 mod q
+    return fr_mul(signed30_to_raw(d), r3);
 }
 
 // 2^by mod q in Montgomery form, by repeated doubling (BlsScalar::pow_of_2, range.rs:187)

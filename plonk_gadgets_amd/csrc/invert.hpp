@@ -1,11 +1,11 @@
 // invert.hpp -- batched field inversion pre-pass (Montgomery's trick), gfx950.
 //
 // Every gadget on this path that inverts (maybe_equal: (a-b)^-1, scalar.rs:121-122; is_non_zero: value^-1,
-// scalar.rs:73) would pay a Fermat exponentiation, ~383 Montgomery multiplications, per item.  The pre-pass
+// scalar.rs:73) would pay a full inversion (fr_invert_or_zero: 600 division steps) per item.  The pre-pass
 // computes all of a call's inverses first: every lane owns up to G elements (strided, so loads coalesce), multiplies
 // them up keeping the running products in a scratch array, inverts ONE product, and unwinds:
 //     inv(x_k) = inv(x_0..x_k) * (x_0..x_{k-1}),   inv(x_0..x_{k-1}) = inv(x_0..x_k) * x_k
-// 3 multiplications per element + 383 / G.  Zero elements are skipped and come out as zero (the reference's
+// 3 multiplications per element + one inversion per G.  Zero elements are skipped and come out as zero (the reference's
 // unwrap_or(zero) at scalar.rs:122).  Each inverse goes straight to its final slot in the call's variable table
 // (GD::inv_slot; NULL when the item has no such variable -- an is_non_zero item that stopped at its error), which the
 // emit kernel leaves alone: the two kernels write disjoint bytes, so they run concurrently on two streams and the

@@ -68,6 +68,11 @@ class BlsScalar:
     def __sub__(self, o): return self._bin(o, "pg_scalar_sub")
     def __mul__(self, o): return self._bin(o, "pg_scalar_mul")
 
+    def invert(self):
+        """BlsScalar::invert: None for zero (the reference's CtOption)"""
+        out = _lib.Scalar()
+        return BlsScalar(out) if _lib.load().pg_scalar_invert(C.byref(self.c), C.byref(out)) == 0 else None
+
     def __neg__(self):
         out = _lib.Scalar()
         _lib.load().pg_scalar_neg(C.byref(self.c), C.byref(out))

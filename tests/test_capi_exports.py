@@ -64,3 +64,28 @@ def test_engine_fails_loudly_without_gpu():
     from plonk_gadgets_amd import _lib
     h = C.c_void_p()
     assert _lib.load().pg_engine_create(0, C.byref(h)) == 3  # PG_ERR_NO_DEVICE
+
+
+def test_host_inversion_matches_fermat_and_pow():
+    """pg_scalar_invert (division steps, the routine the device pre-pass runs) against a^(q-2) in the library and
+    against Python's pow, on edge values and 3000 random scalars; zero -> PG_ERR_NON_EXISTING_INVERSE and 0"""
+    import ctypes as C
+    import random
+    import plonk_gadgets_amd as pg
+    from plonk_gadgets_amd import _lib
+    Q = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    L = _lib.load()
+    rnd = random.Random(11)
+    vals = [1, 2, 3, Q - 1, Q - 2, (Q + 1) // 2, 2**254, 2**255 % Q, 2**32, 2**30 - 1, 2**30, 2**60 + 1]
+    vals += [rnd.randrange(1, Q) for _ in range(3000)] + [rnd.randrange(1, 2**64) for _ in range(200)]
+    out = _lib.Scalar()
+    for x in vals:
+        s = pg.BlsScalar.from_int(x)
+        assert s.invert().to_int() == pow(x, -1, Q), hex(x)
+        assert (s * s.invert()).to_int() == 1
+    for x in vals[:300]:
+        s = pg.BlsScalar.from_int(x)
+        assert L.pg_scalar_invert_fermat(C.byref(s.c), C.byref(out)) == 0 and pg.BlsScalar(out) == s.invert()
+    z = pg.BlsScalar.from_int(0)
+    assert z.invert() is None
+    assert L.pg_scalar_invert(C.byref(z.c), C.byref(out)) == 1 and pg.BlsScalar(out).to_int() == 0

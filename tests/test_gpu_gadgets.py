@@ -569,3 +569,23 @@ def mixed_witnesses_local(mn, mx, n, seed):
     outside = synth.random_scalars(n, seed + 1)
     pick = (synth.splitmix64(n, seed + 2) & np.uint64(1)).astype(bool)
     return np.ascontiguousarray(np.where(pick[:, None], inside, outside))
+
+
+def test_device_inversion_edge_values(engine):
+    """the device's division-step inversion on values chosen around its 30-bit limb boundaries and the ends of the
+    field (and a zero in between): is_non_zero's inverse variable must equal the oracle's a^(q-2), bit for bit"""
+    from oracle import pyoracle as po
+    Q = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    ints = [1, 2, 3, Q - 1, Q - 2, (Q + 1) // 2, (Q - 1) // 2, 2**30 - 1, 2**30, 2**30 + 1, 2**60 - 1, 2**60, 2**90, 2**120 - 1,
+            2**150, 2**180 + 2**30, 2**210 - 1, 2**240, 2**254, 2**255 % Q, 0, 2**32, 2**64 - 1, 2**128, 2**192 + 5, 7**80 % Q]
+    ints += [(3**k) % Q for k in range(1, 300, 7)] + [Q - (5**k) % Q for k in range(1, 300, 11)]
+    vals = synth.scalars_from_ints(ints)
+    c = po.Composer()
+    vars_ = [c.add_input(v) for v in vals]
+    g0, v0 = c.n, c.num_vars
+    errs = [int(c.L.is_non_zero(c.c, vars_[i], po.fr(vals[i]))) for i in range(len(ints))]
+    exp = c.export(g0, v0)
+    cols, err, nerr = engine.is_non_zero_batch(dev(np.array(vars_, np.uint64)), dev(vals), g0, v0, zero_var=0)
+    torch.cuda.synchronize()
+    assert_cols(cols.to_numpy(), exp)
+    assert err.cpu().numpy().tolist() == errs and nerr == 1

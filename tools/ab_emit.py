@@ -17,6 +17,12 @@ VDIR = os.path.join(ROOT, "tools", "variants")
 VARIANTS = {
     "base": [],
     "sequential_prepass": ["-DPG_SEQUENTIAL_PREPASS"],
+    "invert_fermat": ["-DPG_INVERT_FERMAT"],
+    "sequential_fermat": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_INVERT_FERMAT"],
+    "inv_lanes512": ["-DPG_INV_LANES_PER_CU=512"],
+    "inv_lanes128_cap64": ["-DPG_INV_LANES_PER_CU=128", "-DPG_INV_MAX_PER_LANE=64"],
+    "inv_cap16": ["-DPG_INV_MAX_PER_LANE=16"],
+    "inv_cap8": ["-DPG_INV_MAX_PER_LANE=8"],
     "side_stream_normal_priority": ["-DPG_SIDE_STREAM_NORMAL_PRIORITY"],
     "xcd_remap": ["-DPG_XCD_REMAP"],
     "nt_stores": ["-DPG_NT_STORES"],
@@ -25,10 +31,12 @@ VARIANTS = {
 }
 
 
-def build():
+def build(only=None):
     from plonk_gadgets_amd import build as b
     os.makedirs(VDIR, exist_ok=True)
     for name, flags in VARIANTS.items():
+        if only and name not in only:
+            continue
         out = os.path.join(VDIR, f"lib_{name}.so")
         b.build(force=True, extra_flags=flags, out=out)
         print("built", out)
@@ -189,7 +197,7 @@ def run(log2_chunk=18, rounds=4):
 
 if __name__ == "__main__":
     if sys.argv[1] == "build":
-        build()
+        build(sys.argv[2:])
     elif sys.argv[1] == "run_c3":
         run_c3(*(int(x) for x in sys.argv[2:]))
     elif sys.argv[1] == "run_c4":
