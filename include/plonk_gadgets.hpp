@@ -61,6 +61,8 @@ class BlsScalar {
     BlsScalar operator-(const BlsScalar &o) const { BlsScalar r; pg_scalar_sub(&s, &o.s, &r.s); return r; }
     BlsScalar operator*(const BlsScalar &o) const { BlsScalar r; pg_scalar_mul(&s, &o.s, &r.s); return r; }
     BlsScalar operator-() const { BlsScalar r; pg_scalar_neg(&s, &r.s); return r; }
+    // BlsScalar::invert(): false (and *out = 0) for zero, the reference's CtOption::is_none
+    bool invert(BlsScalar *out) const { return pg_scalar_invert(&s, &out->s) == PG_OK; }
     bool operator==(const BlsScalar &o) const {
         return s.l[0] == o.s.l[0] && s.l[1] == o.s.l[1] && s.l[2] == o.s.l[2] && s.l[3] == o.s.l[3];
     }

@@ -337,10 +337,22 @@ static void panics_become_exceptions(Engine &e) {
     CHECK(threw);
 }
 
+// BlsScalar::invert as the gadgets use it (src/scalar.rs:73,121): x * x^-1 == 1, zero has none
+static void scalar_invert() {
+    BlsScalar inv;
+    for (uint64_t v : {1ull, 2ull, 7ull, 1ull << 30, (1ull << 60) + 1, ~0ull}) {
+        CHECK(BlsScalar::from(v).invert(&inv));
+        CHECK(BlsScalar::from(v) * inv == BlsScalar::one());
+    }
+    CHECK((-BlsScalar::one()).invert(&inv) && inv == -BlsScalar::one());
+    CHECK(!BlsScalar::zero().invert(&inv) && inv == BlsScalar::zero());
+}
+
 int main() {
     Engine e(0);
     struct { const char *name; std::function<void()> fn; } tests[] = {
         {"counting_scalar_bits", [&] { counting_scalar_bits(); }},
+        {"scalar_invert", [&] { scalar_invert(); }},
         {"scalar_decomposition_test", [&] { scalar_decomposition_test(e); }},
         {"max_bound_test", [&] { max_bound_test(e); }},
         {"range_check_test", [&] { range_check_test(e); }},
