@@ -291,6 +291,30 @@ pg_status pg_composer_range_check_allocated_batch(pg_composer *c, const pg_scala
                                                   const pg_variable *d_witness_var, const pg_scalar *d_witness,
                                                   uint64_t batch, pg_variable *d_result_vars);
 
+/* the other uniform gadgets as batched appends, each the loop over i of the reference call named:
+ *   max_bound:            allocate(d_witness[i]); max_bound(composer, max_range, w)        src/range.rs:82-113
+ *   max_bound_allocated:  max_bound(composer, max_range, AllocatedScalar { d_witness_var[i], d_witness[i] })
+ *   scalar_decomposition: scalar_decomposition_gadget(composer, num_bits, AllocatedScalar { .. })   src/range.rs:119-158
+ *                         (bit Variables of item i: first new Variable + i * (num_bits + 260) + [0, num_bits))
+ *   conditionally_select_zero / _one, maybe_equal: on EXISTING Variables (device index arrays); their assignments
+ *                         are read from the composer's own variable table, as the reference reads composer.variables
+ * *num_bits (may be NULL) is the u64 max_bound returns. */
+pg_status pg_composer_max_bound_batch(pg_composer *c, const pg_scalar *max_range, const pg_scalar *d_witness, uint64_t batch,
+                                      pg_variable *d_result_vars, uint64_t *num_bits);
+pg_status pg_composer_max_bound_allocated_batch(pg_composer *c, const pg_scalar *max_range, const pg_variable *d_witness_var,
+                                                const pg_scalar *d_witness, uint64_t batch, pg_variable *d_result_vars,
+                                                uint64_t *num_bits);
+pg_status pg_composer_scalar_decomposition_batch(pg_composer *c, uint64_t num_bits, const pg_variable *d_witness_var,
+                                                 const pg_scalar *d_witness, uint64_t batch, pg_variable *d_result_vars);
+pg_status pg_composer_conditionally_select_zero_batch(pg_composer *c, const pg_variable *d_x_var,
+                                                      const pg_variable *d_select_var, uint64_t batch,
+                                                      pg_variable *d_result_vars);
+pg_status pg_composer_conditionally_select_one_batch(pg_composer *c, const pg_variable *d_y_var,
+                                                     const pg_variable *d_selector_var, uint64_t batch,
+                                                     pg_variable *d_result_vars);
+pg_status pg_composer_maybe_equal_batch(pg_composer *c, const pg_variable *d_a_var, const pg_variable *d_b_var, uint64_t batch,
+                                        pg_variable *d_result_vars);
+
 /* copy rows [gate_first, gate_first + n_gates) of the live columns and variables [var_first, var_first + n_vars)
  * into caller-owned device buffers (any member of dst may be NULL); enqueued on the composer's stream */
 pg_status pg_composer_copy_out(pg_composer *c, uint64_t gate_first, uint64_t n_gates, uint64_t var_first, uint64_t n_vars,

@@ -139,6 +139,51 @@ class StandardComposer:
                                                                res.data_ptr()), "pg_composer_range_check_allocated_batch")
         return res
 
+    def max_bound_batch(self, max_range: BlsScalar, witness: torch.Tensor):
+        """for w in witness: allocate(w); max_bound(max_range, w) -> (result Variables, num_bits)"""
+        assert witness.is_cuda and witness.dtype == torch.int64 and witness.dim() == 2 and witness.is_contiguous()
+        res = torch.empty((witness.shape[0],), dtype=torch.int64, device=witness.device)
+        nb = C.c_uint64()
+        _chk(self._lib.pg_composer_max_bound_batch(self._h, C.byref(max_range.c), witness.data_ptr(), witness.shape[0],
+                                                   res.data_ptr(), C.byref(nb)), "pg_composer_max_bound_batch")
+        return res, int(nb.value)
+
+    def max_bound_allocated_batch(self, max_range: BlsScalar, witness_vars: torch.Tensor, witness: torch.Tensor):
+        assert witness.is_cuda and witness.dtype == torch.int64 and witness.dim() == 2 and witness.is_contiguous()
+        assert witness_vars.is_cuda and witness_vars.dtype == torch.int64 and witness_vars.shape == (witness.shape[0],)
+        res = torch.empty((witness.shape[0],), dtype=torch.int64, device=witness.device)
+        nb = C.c_uint64()
+        _chk(self._lib.pg_composer_max_bound_allocated_batch(self._h, C.byref(max_range.c), witness_vars.data_ptr(),
+                                                             witness.data_ptr(), witness.shape[0], res.data_ptr(), C.byref(nb)),
+             "pg_composer_max_bound_allocated_batch")
+        return res, int(nb.value)
+
+    def scalar_decomposition_batch(self, num_bits: int, witness_vars: torch.Tensor, witness: torch.Tensor) -> torch.Tensor:
+        """for i: scalar_decomposition_gadget(num_bits, AllocatedScalar(witness_vars[i], witness[i])) -> is_equal Variables"""
+        assert witness.is_cuda and witness.dtype == torch.int64 and witness.dim() == 2 and witness.is_contiguous()
+        assert witness_vars.is_cuda and witness_vars.dtype == torch.int64 and witness_vars.shape == (witness.shape[0],)
+        res = torch.empty((witness.shape[0],), dtype=torch.int64, device=witness.device)
+        _chk(self._lib.pg_composer_scalar_decomposition_batch(self._h, num_bits, witness_vars.data_ptr(), witness.data_ptr(),
+                                                              witness.shape[0], res.data_ptr()),
+             "pg_composer_scalar_decomposition_batch")
+        return res
+
+    def _two_input_batch(self, fn: str, a_vars: torch.Tensor, b_vars: torch.Tensor) -> torch.Tensor:
+        assert a_vars.is_cuda and a_vars.dtype == torch.int64 and a_vars.dim() == 1 and a_vars.is_contiguous()
+        assert b_vars.is_cuda and b_vars.dtype == torch.int64 and b_vars.shape == a_vars.shape and b_vars.is_contiguous()
+        res = torch.empty_like(a_vars)
+        _chk(getattr(self._lib, fn)(self._h, a_vars.data_ptr(), b_vars.data_ptr(), a_vars.shape[0], res.data_ptr()), fn)
+        return res
+
+    def conditionally_select_zero_batch(self, x_vars: torch.Tensor, select_vars: torch.Tensor) -> torch.Tensor:
+        return self._two_input_batch("pg_composer_conditionally_select_zero_batch", x_vars, select_vars)
+
+    def conditionally_select_one_batch(self, y_vars: torch.Tensor, selector_vars: torch.Tensor) -> torch.Tensor:
+        return self._two_input_batch("pg_composer_conditionally_select_one_batch", y_vars, selector_vars)
+
+    def maybe_equal_batch(self, a_vars: torch.Tensor, b_vars: torch.Tensor) -> torch.Tensor:
+        return self._two_input_batch("pg_composer_maybe_equal_batch", a_vars, b_vars)
+
     # -- read-back ----------------------------------------------------------------------------------------
     def value(self, v: Variable) -> BlsScalar:
         out = _lib.Scalar()

@@ -53,7 +53,7 @@ constexpr uint32_t kPermIters = 16;                               // gates per t
 constexpr uint64_t kPermChunk = (uint64_t)kThreads * kPermIters;  // gates per workgroup of the gap kernel
 constexpr uint32_t kPermRowsPerThread = 5;  // item kernel: rows loaded per thread before any is processed
 constexpr uint32_t kPermLocalLdsLimit = 64 * 1024 - 256;
-constexpr uint32_t kPermNone = 0xFFFF, kPermDone = 0xFFFE;
+constexpr uint32_t kPermNone = 0xFFFF, kPermDone = 0xFFFE, kPermForeign = 0xFFFD;
 
 __device__ __forceinline__ uint64_t perm_encode(uint64_t gate, uint32_t wire, uint64_t padded_n) { return wire * padded_n + gate; }
 __device__ __forceinline__ uint64_t perm_encode_pos(uint64_t p, uint64_t padded_n) { return (p & 3) * padded_n + (p >> 2); }
@@ -149,6 +149,8 @@ __global__ __launch_bounds__(kThreads) void perm_item_kernel(const PermCtx X, co
                                                             uint64_t *sigma) {
     extern __shared__ uint32_t perm_lds[];
     __shared__ uint64_t s_warp[4];
+    __shared__ uint32_t s_foreign, s_rank;
+    __shared__ unsigned long long s_base;
     const uint32_t L = S.L, V = S.V, n3 = 3 * L, tid = threadIdx.x;
     uint32_t *cnt = perm_lds, *off = cnt + V;
     uint16_t *lw = reinterpret_cast<uint16_t *>(off + V + 1), *pos = lw + n3, *sig = pos + n3;
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(kThreads) void perm_item_kernel(const PermCtx X, co
     for (uint64_t item = blockIdx.x; item < batch; item += gridDim.x) {
         const uint64_t g0 = S.gate_base + item * L, v0 = S.var_base + item * V;
         for (uint32_t id = tid; id < V; id += kThreads) cnt[id] = 0;
+        if (tid == 0) s_foreign = s_rank = 0;
         __syncthreads();
         for (uint32_t rb = 0; rb < L; rb += kPermRowsPerThread * kThreads) {  // 15 loads in flight per thread
             uint64_t var[kPermRowsPerThread][3];
@@ -176,7 +179,10 @@ __global__ __launch_bounds__(kThreads) void perm_item_kernel(const PermCtx X, co
                     uint32_t id = kPermNone;
                     if (var[u][w] == X.zero_var) zero |= 1u << w;
                     else if (rel < (uint64_t)V) atomicAdd(&cnt[id = (uint32_t)rel], 1u);
-                    else perm_sparse_put(X, Q, atomicAdd(Q.count, 1ull), var[u][w], g0 + r, w);
+                    else {
+                        id = kPermForeign;
+                        atomicAdd(&s_foreign, 1u);
+                    }
                     lw[3 * r + w] = (uint16_t)id;
                     sig[4 * r + w] = (uint16_t)kPermNone;
                 }
@@ -188,6 +194,15 @@ __global__ __launch_bounds__(kThreads) void perm_item_kernel(const PermCtx X, co
             }
         }
         __syncthreads();
+        if (s_foreign) {  // references to Variables created elsewhere: one reservation in the sparse list per workgroup
+            if (tid == 0) s_base = atomicAdd(Q.count, (unsigned long long)s_foreign);
+            __syncthreads();
+            for (uint32_t j = tid; j < n3; j += kThreads)
+                if (lw[j] == kPermForeign) {
+                    const uint32_t r = j / 3, w = j - 3 * r;
+                    perm_sparse_put(X, Q, s_base + atomicAdd(&s_rank, 1u), X.C.w[w][g0 + r], g0 + r, w);
+                }
+        }
         {  // off = exclusive scan of cnt; cnt becomes the scatter cursor
             const uint32_t per = (V + kThreads - 1) / kThreads, b = tid * per, e = b + per < V ? b + per : V;
             uint64_t sum = 0, tot;
@@ -203,7 +218,7 @@ __global__ __launch_bounds__(kThreads) void perm_item_kernel(const PermCtx X, co
         __syncthreads();
         for (uint32_t j = tid; j < n3; j += kThreads) {
             const uint32_t id = lw[j];
-            if (id != kPermNone) pos[off[id] + atomicAdd(&cnt[id], 1u)] = (uint16_t)j;
+            if (id < kPermForeign) pos[off[id] + atomicAdd(&cnt[id], 1u)] = (uint16_t)j;
         }
         __syncthreads();
         for (uint32_t id = tid; id < V; id += kThreads) {
@@ -266,43 +281,55 @@ __global__ __launch_bounds__(kThreads) void perm_sparse_link_kernel(const PermCt
     }
 }
 
-// one wave per sparse run whose Variable belongs to a batched item: the item's rows are searched for its local positions
-// (already one closed cycle, ascending) and the two lists are joined: local first..last -> sparse first..last -> local first
+// sparse runs whose Variable belongs to a batched item: every lane tests one entry (run head with a home segment?), the
+// wave then takes the hits one by one, searches the item's rows for the Variable's local positions (already one closed
+// cycle, ascending) and joins the two lists: local first..last -> sparse first..last -> local first
 __global__ __launch_bounds__(kThreads) void perm_splice_kernel(const PermCtx X, const uint64_t *keys, uint64_t nS, uint64_t *sigma) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t pos_mask = (1ull << X.pos_bits) - 1;
     const uint64_t waves = (uint64_t)gridDim.x * (kThreads / 64);
-    for (uint64_t j = (uint64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6); j < nS; j += waves) {
-        const uint64_t v = keys[j] >> X.pos_bits;
-        if (j > 0 && keys[j - 1] >> X.pos_bits == v) continue;
-        const int si = perm_home_seg(X, v);
-        if (si < 0) continue;
-        const PermSeg s = X.segs[si];
-        const uint64_t g0 = s.gate_base + (v - s.var_base) / s.V * s.L;
-        uint64_t lo = ~0ull, hi = 0;
-        bool found = false;
-        for (uint32_t w = 0; w < 3; w++)
-            for (uint32_t r = lane; r < s.L; r += 64)
-                if (X.C.w[w][g0 + r] == v) {
-                    const uint64_t p = 4 * (g0 + r) + w;
-                    lo = p < lo ? p : lo;
-                    hi = p > hi ? p : hi;
-                    found = true;
-                }
-        for (int d = 32; d; d >>= 1) {
-            const uint64_t olo = __shfl_xor(lo, d, 64), ohi = __shfl_xor(hi, d, 64);
-            lo = olo < lo ? olo : lo;
-            hi = ohi > hi ? ohi : hi;
+    for (uint64_t jb = ((uint64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) * 64; jb < nS; jb += waves * 64) {
+        const uint64_t jm = jb + lane;
+        int my_seg = -1;
+        if (jm < nS) {
+            const uint64_t vm = keys[jm] >> X.pos_bits;
+            if (jm == 0 || keys[jm - 1] >> X.pos_bits != vm) my_seg = perm_home_seg(X, vm);
         }
-        found = __any(found);
-        if (lane) continue;
-        uint64_t e = j;
-        while (e + 1 < nS && keys[e + 1] >> X.pos_bits == v) e++;
-        const uint64_t first = perm_encode_pos(keys[j] & pos_mask, X.padded_n), last = perm_encode_pos(keys[e] & pos_mask, X.padded_n);
-        if (!found) sigma[last] = first;
-        else {
-            sigma[perm_encode_pos(hi, X.padded_n)] = first;
-            sigma[last] = perm_encode_pos(lo, X.padded_n);
+        uint64_t hits = __ballot(my_seg >= 0);
+        while (hits) {
+            const uint32_t src = (uint32_t)__ffsll((long long)hits) - 1;
+            hits &= hits - 1;
+            const uint64_t j = jb + src;
+            const uint64_t v = keys[j] >> X.pos_bits;
+            const PermSeg s = X.segs[__shfl(my_seg, (int)src, 64)];
+            const uint64_t g0 = s.gate_base + (v - s.var_base) / s.V * s.L;
+            uint64_t lo = ~0ull, hi = 0;
+            bool found = false;
+            for (uint32_t w = 0; w < 3; w++)
+                for (uint32_t r = lane; r < s.L; r += 64)
+                    if (X.C.w[w][g0 + r] == v) {
+                        const uint64_t p = 4 * (g0 + r) + w;
+                        lo = p < lo ? p : lo;
+                        hi = p > hi ? p : hi;
+                        found = true;
+                    }
+            for (int d = 32; d; d >>= 1) {
+                const uint64_t olo = __shfl_xor(lo, d, 64), ohi = __shfl_xor(hi, d, 64);
+                lo = olo < lo ? olo : lo;
+                hi = ohi > hi ? ohi : hi;
+            }
+            found = __any(found);
+            if (lane == 0) {
+                uint64_t e = j;
+                while (e + 1 < nS && keys[e + 1] >> X.pos_bits == v) e++;
+                const uint64_t first = perm_encode_pos(keys[j] & pos_mask, X.padded_n),
+                               last = perm_encode_pos(keys[e] & pos_mask, X.padded_n);
+                if (!found) sigma[last] = first;
+                else {
+                    sigma[perm_encode_pos(hi, X.padded_n)] = first;
+                    sigma[last] = perm_encode_pos(lo, X.padded_n);
+                }
+            }
         }
     }
 }

@@ -427,8 +427,8 @@ def test_allocated_batch_on_the_composer(engine):
 
 
 def test_permutation_sparse_list_regrows():
-    """PG_PERM_SLACK=0: the sorted list is sized for the rows of single calls only, the witness references inside the
-    items overflow it, and the pass runs a second time with the reported size (own process: the knob is read once)"""
+    """PG_PERM_FIRST_CAP=16: the sorted list starts far too short, the witness references inside the items overflow it,
+    and the pass runs a second time with the reported size (own process: the knob is read once)"""
     import os
     import subprocess
     import sys
@@ -439,6 +439,58 @@ def test_permutation_sparse_list_regrows():
             "assert np.array_equal(dev.permutation(n).cpu().numpy().view(np.uint64), ora.sigma(n))\n"
             "print('regrow ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PG_PERM_SLACK="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env = dict(os.environ, PG_PERM_FIRST_CAP="16", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "regrow ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_every_uniform_gadget_as_a_batched_append(engine):
+    """one circuit built twice -- on the device composer through the batched appends (max_bound, max_bound on allocated
+    witnesses, scalar_decomposition, conditionally_select_zero/one, maybe_equal) with single calls in between, and on
+    the oracle through the reference's loops: same columns, satisfied, same sigma (the small items are linked
+    several per workgroup; every item of the scalar gadgets references Variables created before its batch)"""
+    from oracle import pyoracle as po
+    import ctypes as C
+    batch = 77
+    dev, ora = pg.StandardComposer(engine, 1 << 17, 1 << 17), po.Composer()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:0")
+    wit = synth.uniform_below(batch, 2**16 + 2**14, seed=21)
+    wit2 = wit.copy()
+    wit2[1::3] = synth.uniform_below(batch, 2**16, seed=22)[1::3]      # a third differ from wit
+    bits = synth.scalars_from_ints([int(x) & 1 for x in synth.splitmix64(batch, 23)])
+    firsts = [dev.add_input_batch(t(a)) for a in (wit, wit2, bits)]
+    allocs = [[ora.allocate(w) for w in a] for a in (wit, wit2, bits)]
+    assert firsts == [int(a[0].var) for a in allocs]
+    wv, wv2, sv = (torch.arange(f, f + batch, dtype=torch.int64, device="cuda:0") for f in firsts)
+
+    def both(dev_res, ora_res):
+        assert list(dev_res.cpu().numpy().view(np.uint64)) == [int(r) for r in ora_res]
+        return [int(r) for r in ora_res]
+
+    nb = C.c_uint64()
+    r, n1 = dev.max_bound_batch(S(2**16), t(wit))
+    mb = both(r, [ora.L.max_bound(ora.c, po.fr(synth.mont(2**16)), ora.allocate(w), C.byref(nb)) for w in wit])
+    assert n1 == nb.value
+    y = pg.conditionally_select_one(dev, mb[0], mb[1])
+    assert y == int(ora.L.conditionally_select_one(ora.c, mb[0], mb[1]))
+    r, n2 = dev.max_bound_allocated_batch(S(1000), wv, t(wit))
+    mba = both(r, [ora.L.max_bound(ora.c, po.fr(synth.mont(1000)), a, C.byref(nb)) for a in allocs[0]])
+    assert n2 == nb.value
+    dec = both(dev.scalar_decomposition_batch(10, wv2, t(wit2)),
+               [ora.L.scalar_decomposition_gadget(ora.c, 10, a, None) for a in allocs[1]])
+    sz = both(dev.conditionally_select_zero_batch(wv, sv),
+              [ora.L.conditionally_select_zero(ora.c, int(a.var), int(s.var)) for a, s in zip(allocs[0], allocs[2])])
+    so = both(dev.conditionally_select_one_batch(wv2, sv),
+              [ora.L.conditionally_select_one(ora.c, int(a.var), int(s.var)) for a, s in zip(allocs[1], allocs[2])])
+    dev.boolean_gate(firsts[2] + 3)
+    ora.L.composer_boolean_gate(ora.c, firsts[2] + 3)
+    me = both(dev.maybe_equal_batch(wv, wv2), [ora.L.maybe_equal(ora.c, a, b) for a, b in zip(allocs[0], allocs[1])])
+    assert [dev.value(v).to_int() for v in me[:6]] == [int((wit[i] == wit2[i]).all()) for i in range(6)]
+    pg.conditionally_select_zero(dev, me[-1], dec[-1])
+    ora.L.conditionally_select_zero(ora.c, me[-1], dec[-1])
+    same(dev, ora)
+    assert dev.check() == -1 and ora.check() == -1
+    n = dev.circuit_size()
+    padded = 1 << (n - 1).bit_length()
+    assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded))
+    _sigma_properties(dev, padded)

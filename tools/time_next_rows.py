@@ -36,6 +36,23 @@ def main():
         print(json.dumps(out), flush=True)
         del dev, wit
         torch.cuda.empty_cache()
+    # small items: 2^22 x maybe_equal on Variables allocated before (3 rows / 3 Variables per item, linked several
+    # hundred items per workgroup; both inputs of every item go through the sorted list)
+    batch = 1 << 22
+    dev = pg.StandardComposer(eng, 3 + 3 * batch + 8, 5 + 5 * batch + 8)
+    a = torch.from_numpy(synth.random_scalars(batch, 5).view(np.int64)).to("cuda:0")
+    fa, fb = dev.add_input_batch(a), dev.add_input_batch(a)
+    av = torch.arange(fa, fa + batch, dtype=torch.int64, device="cuda:0")
+    dev.maybe_equal_batch(av, av + batch)
+    n = dev.circuit_size()
+    padded = 1 << (n - 1).bit_length()
+    best = 1e9
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t = time.perf_counter(); r = dev.permutation(padded); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t)
+        del r
+    print(json.dumps({"gadget": "maybe_equal", "batch": batch, "rows": n, "permutation_ms": round(best * 1e3, 2),
+                      "permutation_rows_per_s": float("%.3g" % (n / best))}), flush=True)
 
 
 if __name__ == "__main__":
