@@ -494,3 +494,26 @@ def test_every_uniform_gadget_as_a_batched_append(engine):
     padded = 1 << (n - 1).bit_length()
     assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded))
     _sigma_properties(dev, padded)
+
+
+def test_batched_appends_fail_cleanly(engine):
+    """capacity errors and NULL arrays on the batched appends leave the composer as it was"""
+    dev = pg.StandardComposer(engine, gate_capacity=64, var_capacity=64)
+    wit = torch.from_numpy(synth.uniform_below(8, 2**16, seed=1).view(np.int64)).to("cuda:0")
+    before = (dev.circuit_size(), dev.num_variables())
+    with pytest.raises(pg.PgError, match="capacity"):
+        dev.max_bound_batch(S(2**16), wit)
+    with pytest.raises(pg.PgError, match="capacity"):
+        dev.add_input_batch(torch.zeros((100, 4), dtype=torch.int64, device="cuda:0"))
+    first = dev.add_input_batch(wit)
+    v = torch.arange(first, first + 8, dtype=torch.int64, device="cuda:0")
+    with pytest.raises(pg.PgError, match="capacity"):
+        dev.conditionally_select_one_batch(v.repeat(4), v.repeat(4))      # 128 rows
+    lib = dev._lib
+    assert lib.pg_composer_maybe_equal_batch(dev._h, None, v.data_ptr(), 8, None) == 2      # PG_ERR_INVALID_ARGUMENT
+    assert lib.pg_composer_scalar_decomposition_batch(dev._h, 300, v.data_ptr(), wit.data_ptr(), 8, None) == 2  # > 256 bits
+    assert (dev.circuit_size(), dev.num_variables()) == (before[0], before[1] + 8)
+    res = dev.maybe_equal_batch(v, v)
+    assert [dev.value(int(r)).to_int() for r in res] == [1] * 8 and dev.check() == -1
+    n = dev.circuit_size()
+    _sigma_properties(dev, 1 << (n - 1).bit_length())
