@@ -315,6 +315,23 @@ pg_status pg_composer_conditionally_select_one_batch(pg_composer *c, const pg_va
 pg_status pg_composer_maybe_equal_batch(pg_composer *c, const pg_variable *d_a_var, const pg_variable *d_b_var, uint64_t batch,
                                         pg_variable *d_result_vars);
 
+/* ragged batched appends: the composer plans the call itself (one host synchronisation for the totals), keeps the
+ * per-item offsets for the permutation, and emits.
+ *   max_bound_ragged: for i { allocate(d_witness[i]); max_bound(composer, d_max_range[i], w) } -- one public bound per
+ *                     item; d_num_bits_out (device u32[batch], may be NULL) receives the u64 each call returns
+ *   is_non_zero:      for i { is_non_zero(composer, d_var[i], value of d_var[i]) }; an item whose value is 0 stops after
+ *                     its first variable + row (src/scalar.rs:69-79); returns PG_ERR_NON_EXISTING_INVERSE when any did
+ *                     (everything is appended all the same, like a loop that records the error and carries on);
+ *                     d_err_mask (device u8[batch]) and err_count may be NULL
+ *   scalar_mix:       the fused item of pg_scalar_mix_batch (BASELINE config 3) */
+pg_status pg_composer_max_bound_ragged_batch(pg_composer *c, const pg_scalar *d_max_range, const pg_scalar *d_witness,
+                                             uint64_t batch, pg_variable *d_result_vars, uint32_t *d_num_bits_out);
+pg_status pg_composer_is_non_zero_batch(pg_composer *c, const pg_variable *d_var, uint64_t batch, uint8_t *d_err_mask,
+                                        uint64_t *err_count);
+pg_status pg_composer_scalar_mix_batch(pg_composer *c, const pg_scalar *d_v, const pg_scalar *d_y, const pg_scalar *d_s,
+                                       const pg_scalar *d_a, const pg_scalar *d_b, uint64_t batch,
+                                       pg_variable *d_result_vars, uint8_t *d_err_mask, uint64_t *err_count);
+
 /* copy rows [gate_first, gate_first + n_gates) of the live columns and variables [var_first, var_first + n_vars)
  * into caller-owned device buffers (any member of dst may be NULL); enqueued on the composer's stream */
 pg_status pg_composer_copy_out(pg_composer *c, uint64_t gate_first, uint64_t n_gates, uint64_t var_first, uint64_t n_vars,

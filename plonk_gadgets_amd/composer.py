@@ -184,6 +184,41 @@ class StandardComposer:
     def maybe_equal_batch(self, a_vars: torch.Tensor, b_vars: torch.Tensor) -> torch.Tensor:
         return self._two_input_batch("pg_composer_maybe_equal_batch", a_vars, b_vars)
 
+    def max_bound_ragged_batch(self, max_range: torch.Tensor, witness: torch.Tensor):
+        """for i: allocate(witness[i]); max_bound(max_range[i], w) -> (result Variables, num_bits per item)"""
+        for x in (max_range, witness):
+            assert x.is_cuda and x.dtype == torch.int64 and x.dim() == 2 and x.is_contiguous()
+        assert max_range.shape == witness.shape
+        res = torch.empty((witness.shape[0],), dtype=torch.int64, device=witness.device)
+        nb = torch.empty((witness.shape[0],), dtype=torch.int32, device=witness.device)
+        _chk(self._lib.pg_composer_max_bound_ragged_batch(self._h, max_range.data_ptr(), witness.data_ptr(), witness.shape[0],
+                                                          res.data_ptr(), nb.data_ptr()), "pg_composer_max_bound_ragged_batch")
+        return res, nb
+
+    def is_non_zero_batch(self, vars_: torch.Tensor):
+        """for i: is_non_zero(vars[i], its value) -> (error mask, error count); items whose value is 0 stop early and are
+        reported here instead of raising (the reference returns Err(NonExistingInverse) for them)"""
+        assert vars_.is_cuda and vars_.dtype == torch.int64 and vars_.dim() == 1 and vars_.is_contiguous()
+        err = torch.zeros((vars_.shape[0],), dtype=torch.uint8, device=vars_.device)
+        nerr = C.c_uint64()
+        st = self._lib.pg_composer_is_non_zero_batch(self._h, vars_.data_ptr(), vars_.shape[0], err.data_ptr(), C.byref(nerr))
+        if st not in (0, 1):
+            _chk(st, "pg_composer_is_non_zero_batch")
+        return err, int(nerr.value)
+
+    def scalar_mix_batch(self, v, y, s, a, b):
+        """the fused item of BASELINE config 3 -> (result Variables [batch, 2], error mask, error count)"""
+        for x in (v, y, s, a, b):
+            assert x.is_cuda and x.dtype == torch.int64 and x.dim() == 2 and x.is_contiguous() and x.shape == v.shape
+        res = torch.empty((v.shape[0], 2), dtype=torch.int64, device=v.device)
+        err = torch.zeros((v.shape[0],), dtype=torch.uint8, device=v.device)
+        nerr = C.c_uint64()
+        st = self._lib.pg_composer_scalar_mix_batch(self._h, v.data_ptr(), y.data_ptr(), s.data_ptr(), a.data_ptr(), b.data_ptr(),
+                                                    v.shape[0], res.data_ptr(), err.data_ptr(), C.byref(nerr))
+        if st not in (0, 1):
+            _chk(st, "pg_composer_scalar_mix_batch")
+        return res, err, int(nerr.value)
+
     # -- read-back ----------------------------------------------------------------------------------------
     def value(self, v: Variable) -> BlsScalar:
         out = _lib.Scalar()

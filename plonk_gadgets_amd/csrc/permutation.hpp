@@ -31,12 +31,30 @@
 
 namespace pg {
 
-// footprint of batched calls: items of L rows / V Variables; item i owns rows [gate_base + i L, +L) and Variables
-// [var_base + i V, +V), all created by the item itself
+// footprint of a batched call: `items` items, each owning a run of rows and a run of Variables it created itself.
+// Uniform calls: L rows / V Variables per item.  Ragged calls (per-item public bounds, is_non_zero items that stop at
+// their error): row_off / var_off are the call's exclusive prefix sums (items + 1 entries, relative to the bases) and
+// L, V the largest item.  `group` consecutive items are linked by one workgroup as if they were one item.
 struct PermSeg {
     uint64_t gate_base, gate_end, var_base, var_end;
     uint32_t L, V;
+    uint64_t items;
+    const uint64_t *row_off, *var_off;
+    uint32_t group;
 };
+__device__ __forceinline__ uint64_t perm_rows_before(const PermSeg &s, uint64_t i) { return s.row_off ? s.row_off[i] : i * s.L; }
+__device__ __forceinline__ uint64_t perm_vars_before(const PermSeg &s, uint64_t i) { return s.var_off ? s.var_off[i] : i * s.V; }
+// item owning Variable v of the segment
+__device__ __forceinline__ uint64_t perm_item_of_var(const PermSeg &s, uint64_t v) {
+    const uint64_t rel = v - s.var_base;
+    if (!s.var_off) return rel / s.V;
+    uint64_t lo = 0, hi = s.items;  // last i with var_off[i] <= rel
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (s.var_off[mid] <= rel) lo = mid; else hi = mid;
+    }
+    return lo;
+}
 
 struct PermCtx {
     ComposerCols C;
@@ -145,18 +163,21 @@ __global__ __launch_bounds__(kThreads) void perm_gap_kernel(const PermCtx X, uin
 // one workgroup per item of a batched segment.  Dynamic LDS: cnt[V] off[V+1] (u32), lw[3L] pos[3L] sig[4L] (u16), zm[L] (u8)
 __host__ __device__ inline uint32_t perm_local_lds_bytes(uint32_t L, uint32_t V) { return 4 * (2 * V + 1) + 2 * 10 * L + L + 16; }
 
-__global__ __launch_bounds__(kThreads) void perm_item_kernel(const PermCtx X, const PermSeg S, uint64_t batch, const PermSparse Q,
+__global__ __launch_bounds__(kThreads) void perm_item_kernel(const PermCtx X, const PermSeg S, uint64_t groups, const PermSparse Q,
                                                             uint64_t *sigma) {
     extern __shared__ uint32_t perm_lds[];
     __shared__ uint64_t s_warp[4];
     __shared__ uint32_t s_foreign, s_rank;
     __shared__ unsigned long long s_base;
-    const uint32_t L = S.L, V = S.V, n3 = 3 * L, tid = threadIdx.x;
-    uint32_t *cnt = perm_lds, *off = cnt + V;
-    uint16_t *lw = reinterpret_cast<uint16_t *>(off + V + 1), *pos = lw + n3, *sig = pos + n3;
-    uint8_t *zm = reinterpret_cast<uint8_t *>(sig + 4 * L);
-    for (uint64_t item = blockIdx.x; item < batch; item += gridDim.x) {
-        const uint64_t g0 = S.gate_base + item * L, v0 = S.var_base + item * V;
+    const uint32_t Lmax = S.L * S.group, Vmax = S.V * S.group, tid = threadIdx.x;
+    uint32_t *cnt = perm_lds, *off = cnt + Vmax;
+    uint16_t *lw = reinterpret_cast<uint16_t *>(off + Vmax + 1), *pos = lw + 3 * Lmax, *sig = pos + 3 * Lmax;
+    uint8_t *zm = reinterpret_cast<uint8_t *>(sig + 4 * Lmax);
+    for (uint64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const uint64_t ib = grp * S.group, ie = ib + S.group < S.items ? ib + S.group : S.items;
+        const uint64_t rb0 = perm_rows_before(S, ib), vb0 = perm_vars_before(S, ib);
+        const uint64_t g0 = S.gate_base + rb0, v0 = S.var_base + vb0;
+        const uint32_t L = (uint32_t)(perm_rows_before(S, ie) - rb0), V = (uint32_t)(perm_vars_before(S, ie) - vb0), n3 = 3 * L;
         for (uint32_t id = tid; id < V; id += kThreads) cnt[id] = 0;
         if (tid == 0) s_foreign = s_rank = 0;
         __syncthreads();
@@ -302,11 +323,13 @@ __global__ __launch_bounds__(kThreads) void perm_splice_kernel(const PermCtx X, 
             const uint64_t j = jb + src;
             const uint64_t v = keys[j] >> X.pos_bits;
             const PermSeg s = X.segs[__shfl(my_seg, (int)src, 64)];
-            const uint64_t g0 = s.gate_base + (v - s.var_base) / s.V * s.L;
+            const uint64_t ib = perm_item_of_var(s, v) / s.group * s.group, ie = ib + s.group < s.items ? ib + s.group : s.items;
+            const uint64_t rb0 = perm_rows_before(s, ib), g0 = s.gate_base + rb0;
+            const uint32_t sL = (uint32_t)(perm_rows_before(s, ie) - rb0);
             uint64_t lo = ~0ull, hi = 0;
             bool found = false;
             for (uint32_t w = 0; w < 3; w++)
-                for (uint32_t r = lane; r < s.L; r += 64)
+                for (uint32_t r = lane; r < sL; r += 64)
                     if (X.C.w[w][g0 + r] == v) {
                         const uint64_t p = 4 * (g0 + r) + w;
                         lo = p < lo ? p : lo;

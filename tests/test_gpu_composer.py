@@ -517,3 +517,57 @@ def test_batched_appends_fail_cleanly(engine):
     assert [dev.value(int(r)).to_int() for r in res] == [1] * 8 and dev.check() == -1
     n = dev.circuit_size()
     _sigma_properties(dev, 1 << (n - 1).bit_length())
+
+
+def test_ragged_batched_appends(engine):
+    """max_bound with one public bound per item, is_non_zero (two items stop at their error) and the fused mix as batched
+    appends, with single calls around them, against the reference's loops on the oracle: same columns, same first
+    unsatisfied row, same sigma (ragged items are linked through the call's prefix sums)"""
+    from oracle import pyoracle as po
+    import ctypes as C
+    batch = 61
+    dev, ora = pg.StandardComposer(engine, 1 << 17, 1 << 17), po.Composer()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:0")
+    rnd = synth.splitmix64(batch, 31)
+    bounds = synth.scalars_from_ints([(1 << (3 + int(r) % 250)) + int(r) % 7 for r in rnd])
+    wit = synth.scalars_from_ints([int(r) % (1 << (2 + int(r >> np.uint64(8)) % 253)) for r in synth.splitmix64(batch, 32)])
+    nb = C.c_uint64()
+    res, nbits = dev.max_bound_ragged_batch(t(bounds), t(wit))
+    ores, onb = [], []
+    for bnd, w in zip(bounds, wit):
+        ores.append(int(ora.L.max_bound(ora.c, po.fr(bnd), ora.allocate(w), C.byref(nb))))
+        onb.append(nb.value)
+    assert list(res.cpu().numpy().view(np.uint64)) == ores and nbits.cpu().numpy().tolist() == onb
+    assert len(set(onb)) > 20      # really ragged
+    y = pg.conditionally_select_one(dev, ores[0], ores[-1])
+    assert y == int(ora.L.conditionally_select_one(ora.c, ores[0], ores[-1]))
+
+    vals = synth.random_scalars(batch, 33)
+    vals[[4, 40]] = 0
+    first = dev.add_input_batch(t(vals))
+    ovars = [ora.add_input(v) for v in vals]
+    assert first == ovars[0]
+    err, nerr = dev.is_non_zero_batch(torch.arange(first, first + batch, dtype=torch.int64, device="cuda:0"))
+    oerr = [int(ora.L.is_non_zero(ora.c, ovars[i], po.fr(vals[i]))) for i in range(batch)]
+    assert err.cpu().numpy().tolist() == oerr and nerr == 2
+
+    v, yv, s, a, b = (synth.random_scalars(batch, 34 + k) for k in range(5))
+    v[[0, 17]] = 0
+    s = synth.scalars_from_ints([int(x) & 1 for x in synth.splitmix64(batch, 39)])
+    b[::2] = a[::2]
+    res2, err2, nerr2 = dev.scalar_mix_batch(t(v), t(yv), t(s), t(a), t(b))
+    ores2, oerr2 = [], []
+    for i in range(batch):
+        vv, yy, ss = ora.add_input(v[i]), ora.add_input(yv[i]), ora.add_input(s[i])
+        aa, bb = ora.allocate(a[i]), ora.allocate(b[i])
+        oerr2.append(int(ora.L.is_non_zero(ora.c, vv, po.fr(v[i]))))
+        ores2.append([int(ora.L.conditionally_select_one(ora.c, yy, ss)), int(ora.L.maybe_equal(ora.c, aa, bb))])
+    assert res2.cpu().numpy().view(np.uint64).tolist() == ores2 and err2.cpu().numpy().tolist() == oerr2 and nerr2 == 2
+    pg.conditionally_select_zero(dev, ores2[3][1], ores[5])
+    ora.L.conditionally_select_zero(ora.c, ores2[3][1], ores[5])
+    same(dev, ora)
+    assert dev.check() == ora.check()
+    n = dev.circuit_size()
+    padded = 1 << (n - 1).bit_length()
+    assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded))
+    _sigma_properties(dev, padded)
