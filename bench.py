@@ -268,6 +268,8 @@ def main():
 
     kernel_ms = [a.elapsed_time(b) for a, b in events]
     avg_launch_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+    if os.environ.get("PG_BENCH_VERBOSE") and rank == 0:
+        print("launch ms:", " ".join("%.2f" % t for t in kernel_ms), file=sys.stderr)
     constraints = world * rows_per_launch * n_chunks * args.steps
     value = constraints / elapsed
     achieved = algo_bytes_per_launch / avg_launch_s / 1e9
