@@ -89,3 +89,16 @@ def test_host_inversion_matches_fermat_and_pow():
     z = pg.BlsScalar.from_int(0)
     assert z.invert() is None
     assert L.pg_scalar_invert(C.byref(z.c), C.byref(out)) == 1 and pg.BlsScalar(out).to_int() == 0
+
+
+def test_generated_rust_declarations_cover_the_header():
+    """bindings/rust/ffi.rs (tools/gen_rust_ffi.py; not compiled here -- no Rust toolchain) is current and declares
+    every function of the header exactly once"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_ffi as g
+    text, names = g.generate()
+    assert sorted(names) == declared_functions() and len(set(names)) == len(names)
+    assert open(os.path.join(ROOT, "bindings", "rust", "ffi.rs")).read() == text, "run python tools/gen_rust_ffi.py"
+    for n in names:
+        assert len(re.findall(r"\bpub fn %s\(" % n, text)) == 1
