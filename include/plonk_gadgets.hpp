@@ -152,6 +152,10 @@ class StandardComposer {
         pg_throw(pg_composer_read_value(h, v.index, &r.s), "read_value");
         return r;
     }
+    // what dusk-plonk's preprocessing consumes next: the remaining columns of a prover-ready row and
+    // the copy permutation; device buffers of circuit_size() / 4 * padded_n entries
+    void materialize(const pg_full_columns &out) { pg_throw(pg_composer_materialize(h, &out), "materialize"); }
+    void permutation(uint64_t padded_n, uint64_t *d_sigma) { pg_throw(pg_composer_permutation(h, padded_n, d_sigma), "permutation"); }
 };
 
 // src/allocated_scalar.rs:17-30
@@ -165,6 +169,70 @@ struct AllocatedScalar {
     }
     pg_allocated_scalar c() const { return pg_allocated_scalar{var.index, scalar.s}; }
 };
+
+// The loops a caller of the reference writes around the gadgets -- for w in witnesses { allocate; gadget } -- as single
+// appends at the composer's end.  Arrays are DEVICE pointers (scalars: reduced Montgomery limbs; Variables: u64);
+// result arrays may be NULL.  Same rows, Variables and numbering as the loop of single calls.
+namespace Batched {
+// for s in scalars { AllocatedScalar::allocate(composer, s) } -> the first Variable, the others follow
+inline Variable allocate(StandardComposer &c, const pg_scalar *d_scalars, uint64_t batch) {
+    Variable first;
+    pg_throw(pg_composer_add_input_batch(c.h, d_scalars, batch, &first.index), "Batched::allocate");
+    return first;
+}
+inline void range_check(StandardComposer &c, const BlsScalar &min_range, const BlsScalar &max_range, const pg_scalar *d_witness,
+                        uint64_t batch, pg_variable *d_result_vars) {
+    pg_throw(pg_composer_range_check_batch(c.h, &min_range.s, &max_range.s, d_witness, batch, d_result_vars), "Batched::range_check");
+}
+inline void range_check_allocated(StandardComposer &c, const BlsScalar &min_range, const BlsScalar &max_range,
+                                  const pg_variable *d_witness_var, const pg_scalar *d_witness, uint64_t batch,
+                                  pg_variable *d_result_vars) {
+    pg_throw(pg_composer_range_check_allocated_batch(c.h, &min_range.s, &max_range.s, d_witness_var, d_witness, batch, d_result_vars),
+             "Batched::range_check_allocated");
+}
+inline uint64_t max_bound(StandardComposer &c, const BlsScalar &max_range, const pg_scalar *d_witness, uint64_t batch,
+                          pg_variable *d_result_vars) {
+    uint64_t num_bits = 0;
+    pg_throw(pg_composer_max_bound_batch(c.h, &max_range.s, d_witness, batch, d_result_vars, &num_bits), "Batched::max_bound");
+    return num_bits;
+}
+inline uint64_t max_bound_allocated(StandardComposer &c, const BlsScalar &max_range, const pg_variable *d_witness_var,
+                                    const pg_scalar *d_witness, uint64_t batch, pg_variable *d_result_vars) {
+    uint64_t num_bits = 0;
+    pg_throw(pg_composer_max_bound_allocated_batch(c.h, &max_range.s, d_witness_var, d_witness, batch, d_result_vars, &num_bits),
+             "Batched::max_bound_allocated");
+    return num_bits;
+}
+// one public bound per item
+inline void max_bound_ragged(StandardComposer &c, const pg_scalar *d_max_range, const pg_scalar *d_witness, uint64_t batch,
+                             pg_variable *d_result_vars, uint32_t *d_num_bits) {
+    pg_throw(pg_composer_max_bound_ragged_batch(c.h, d_max_range, d_witness, batch, d_result_vars, d_num_bits), "Batched::max_bound_ragged");
+}
+inline void scalar_decomposition(StandardComposer &c, uint64_t num_bits, const pg_variable *d_witness_var, const pg_scalar *d_witness,
+                                 uint64_t batch, pg_variable *d_result_vars) {
+    pg_throw(pg_composer_scalar_decomposition_batch(c.h, num_bits, d_witness_var, d_witness, batch, d_result_vars),
+             "Batched::scalar_decomposition");
+}
+inline void conditionally_select_zero(StandardComposer &c, const pg_variable *d_x, const pg_variable *d_select, uint64_t batch,
+                                      pg_variable *d_result_vars) {
+    pg_throw(pg_composer_conditionally_select_zero_batch(c.h, d_x, d_select, batch, d_result_vars), "Batched::conditionally_select_zero");
+}
+inline void conditionally_select_one(StandardComposer &c, const pg_variable *d_y, const pg_variable *d_selector, uint64_t batch,
+                                     pg_variable *d_result_vars) {
+    pg_throw(pg_composer_conditionally_select_one_batch(c.h, d_y, d_selector, batch, d_result_vars), "Batched::conditionally_select_one");
+}
+inline void maybe_equal(StandardComposer &c, const pg_variable *d_a, const pg_variable *d_b, uint64_t batch, pg_variable *d_result_vars) {
+    pg_throw(pg_composer_maybe_equal_batch(c.h, d_a, d_b, batch, d_result_vars), "Batched::maybe_equal");
+}
+// Ok, or Error::NonExistingInverse when some item's value was zero (all items are appended either way, the failing
+// ones as far as the reference gets before it returns the error); *err_count = how many
+inline Result is_non_zero(StandardComposer &c, const pg_variable *d_var, uint64_t batch, uint8_t *d_err_mask, uint64_t *err_count) {
+    const pg_status st = pg_composer_is_non_zero_batch(c.h, d_var, batch, d_err_mask, err_count);
+    if (st == PG_ERR_NON_EXISTING_INVERSE) return Result{Error::NonExistingInverse};
+    pg_throw(st, "Batched::is_non_zero");
+    return Result{};
+}
+}  // namespace Batched
 
 namespace RangeGadgets {
 // src/range.rs:27-32

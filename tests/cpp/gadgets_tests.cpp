@@ -337,6 +337,91 @@ static void panics_become_exceptions(Engine &e) {
     CHECK(threw);
 }
 
+// ---- batched appends == the loops they stand for ------------------------------------------------------------
+template <class T>
+static T *to_device(const std::vector<T> &v) {
+    T *d = nullptr;
+    (void)hipMalloc(reinterpret_cast<void **>(&d), v.size() * sizeof(T) + 16);
+    (void)hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    return d;
+}
+static std::vector<uint64_t> sigma_of(StandardComposer &c, uint64_t padded) {
+    uint64_t *d = nullptr;
+    (void)hipMalloc(reinterpret_cast<void **>(&d), 4 * padded * 8);
+    c.permutation(padded, d);
+    pg_throw(pg_composer_sync(c.h), "sync");
+    std::vector<uint64_t> h(4 * padded);
+    (void)hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return h;
+}
+
+// One circuit built twice on the device: through the batched appends, and through loops of the reference-signature
+// single calls.  Columns, Variables, satisfiability and the copy permutation must agree -- the first composer's sigma
+// comes from the per-item linking, the second's from the sorted list, two different routes to the same cycles.
+static void batched_appends_equal_loops(Engine &e) {
+    const uint64_t batch = 45;
+    std::vector<pg_scalar> wit, sel;
+    for (uint64_t i = 0; i < batch; i++) {
+        wit.push_back((i % 4 == 3 ? random_scalar() : BlsScalar::from(40000 + 7919 * i)).s);
+        sel.push_back(BlsScalar::from(i & 1).s);
+    }
+    const BlsScalar mn = BlsScalar::from(50000), mx = BlsScalar::from(250000), bound = BlsScalar::pow_of_2(20);
+    StandardComposer a(e, 1 << 17, 1 << 17), b(e, 1 << 17, 1 << 17);
+    pg_scalar *d_wit = to_device(wit), *d_sel = to_device(sel);
+    std::vector<uint64_t> zeros(batch, 0);
+    uint64_t *d_res = to_device(zeros), *d_res2 = to_device(zeros);
+
+    // batched
+    Batched::range_check(a, mn, mx, d_wit, batch, d_res);
+    const Variable fw = Batched::allocate(a, d_wit, batch), fs = Batched::allocate(a, d_sel, batch);
+    std::vector<uint64_t> wv, sv;
+    for (uint64_t i = 0; i < batch; i++) { wv.push_back(fw.index + i); sv.push_back(fs.index + i); }
+    uint64_t *d_wv = to_device(wv), *d_sv = to_device(sv);
+    const uint64_t nb = Batched::max_bound_allocated(a, bound, d_wv, d_wit, batch, d_res2);
+    Batched::conditionally_select_one(a, d_wv, d_sv, batch, nullptr);
+    Batched::maybe_equal(a, d_res, d_res2, batch, nullptr);
+    uint64_t errs = 0;
+    CHECK(Batched::is_non_zero(a, d_wv, batch, nullptr, &errs).is_ok() && errs == 0);
+    CHECK(Batched::is_non_zero(a, d_sv, batch, nullptr, &errs).is_err() && errs == (batch + 1) / 2);
+
+    // the loops
+    std::vector<Variable> r1, r2;
+    for (uint64_t i = 0; i < batch; i++)
+        r1.push_back(range_check(b, mn, mx, AllocatedScalar::allocate(b, BlsScalar(wit[i]))));
+    std::vector<AllocatedScalar> aw, as;
+    for (uint64_t i = 0; i < batch; i++) aw.push_back(AllocatedScalar::allocate(b, BlsScalar(wit[i])));
+    for (uint64_t i = 0; i < batch; i++) as.push_back(AllocatedScalar::allocate(b, BlsScalar(sel[i])));
+    CHECK(aw[0].var == fw && as[0].var == fs);
+    uint64_t nb2 = 0;
+    for (uint64_t i = 0; i < batch; i++) {
+        auto [v, n] = max_bound(b, bound, aw[i]);
+        r2.push_back(v);
+        nb2 = n;
+    }
+    CHECK(nb == nb2);
+    for (uint64_t i = 0; i < batch; i++) conditionally_select_one(b, aw[i].var, as[i].var);
+    for (uint64_t i = 0; i < batch; i++)
+        maybe_equal(b, AllocatedScalar{r1[i], b.value(r1[i])}, AllocatedScalar{r2[i], b.value(r2[i])});
+    for (uint64_t i = 0; i < batch; i++) CHECK(is_non_zero(b, aw[i].var, aw[i].scalar).is_ok());
+    uint64_t loop_errs = 0;
+    for (uint64_t i = 0; i < batch; i++) loop_errs += is_non_zero(b, as[i].var, as[i].scalar).is_err();
+    CHECK(loop_errs == errs);
+
+    std::vector<uint64_t> res(batch);
+    (void)hipMemcpy(res.data(), d_res, batch * 8, hipMemcpyDeviceToHost);
+    for (uint64_t i = 0; i < batch; i++) CHECK(res[i] == r1[i].index);
+    CHECK(a.circuit_size() == b.circuit_size() && a.num_variables() == b.num_variables());
+    const Columns ca = download(a), cb = download(b);
+    CHECK(same_structure(ca, cb));
+    CHECK(ca.vars.size() == cb.vars.size() && std::memcmp(ca.vars.data(), cb.vars.data(), ca.vars.size() * 32) == 0);
+    CHECK(a.check() == b.check());
+    uint64_t padded = 1;
+    while (padded < a.circuit_size()) padded <<= 1;
+    CHECK(sigma_of(a, padded) == sigma_of(b, padded));
+    for (void *p : {(void *)d_wit, (void *)d_sel, (void *)d_res, (void *)d_res2, (void *)d_wv, (void *)d_sv}) (void)hipFree(p);
+}
+
 // BlsScalar::invert as the gadgets use it (src/scalar.rs:73,121): x * x^-1 == 1, zero has none
 static void scalar_invert() {
     BlsScalar inv;
@@ -353,6 +438,7 @@ int main() {
     struct { const char *name; std::function<void()> fn; } tests[] = {
         {"counting_scalar_bits", [&] { counting_scalar_bits(); }},
         {"scalar_invert", [&] { scalar_invert(); }},
+        {"batched_appends_equal_loops", [&] { batched_appends_equal_loops(e); }},
         {"scalar_decomposition_test", [&] { scalar_decomposition_test(e); }},
         {"max_bound_test", [&] { max_bound_test(e); }},
         {"range_check_test", [&] { range_check_test(e); }},
