@@ -120,6 +120,12 @@ pg_status pg_range_check_batch(pg_engine *e, const pg_scalar *min_range, const p
                                const pg_scalar *d_witness, uint64_t batch, uint64_t gate_base, uint64_t var_base,
                                const pg_columns *out, pg_variable *d_result_vars /* may be NULL */, void *stream);
 
+/* The rows of pg_range_check_batch WITHOUT the witnesses: selectors and wire indices are a function of the public
+ * bounds and of the numbering alone, so a process that is sent only another process's variable table (32 B per
+ * variable instead of 184 B per row on top) regenerates the rest locally.  out->var_values is not written and may be
+ * NULL.  The result Variable of item i is var_base + (i + 1) * vars_per_item - 1. */
+pg_status pg_range_check_structure_batch(pg_engine *e, const pg_scalar *min_range, const pg_scalar *max_range, uint64_t batch,
+                                         uint64_t gate_base, uint64_t var_base, const pg_columns *out, void *stream);
 
 /* pg_range_check_allocated_batch: the gadget alone, on witnesses that are ALREADY allocated --
  *     result[i] = range_check(composer, min, max, AllocatedScalar { var: d_witness_var[i], scalar: d_witness[i] });

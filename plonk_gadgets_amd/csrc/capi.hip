@@ -433,6 +433,32 @@ static pg_status range_check_common(pg_engine *e, const pg_scalar *min_range, co
     return launch<pg::RangeCheckGD>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream);
 }
 
+pg_status pg_range_check_structure_batch(pg_engine *e, const pg_scalar *min_range, const pg_scalar *max_range, uint64_t batch,
+                                         uint64_t gate_base, uint64_t var_base, const pg_columns *out, void *stream) {
+    if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
+    pg_layout lay;
+    PG_TRY(pg_range_check_layout(min_range, max_range, batch, &lay));
+    if (batch == 0) return PG_OK;
+    if (!out) return fail(PG_ERR_INVALID_ARGUMENT, "columns are NULL");
+    pg_columns c = *out;
+    if (!c.var_values) c.var_values = c.q_m;  // never written: only has to pass the pointer checks
+    PG_TRY(check_columns(&c));
+    if (lay.num_bits < 2 || lay.num_bits > 255) return fail(PG_ERR_INVALID_ARGUMENT, "ladder length out of range");
+    if ((batch + pg::RangeCheckGD::W - 1) / pg::RangeCheckGD::W > 0xffffffffull) return fail(PG_ERR_INVALID_ARGUMENT, "batch too large for one call");
+    PG_HIP_TRY(hipSetDevice(e->device));
+    pg::RangeCheckGD::Args A{};
+    A.min_range = to_fr(min_range);
+    A.max_range = to_fr(max_range);
+    A.n = (uint32_t)lay.num_bits;
+    A.pow2 = e->d_pow2;
+    const pg::EmitOut O = make_out(&c, batch, pg::RangeCheckGD::W, gate_base, var_base, 0, nullptr, nullptr);
+    const uint32_t max_blocks = (uint32_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
+    hipLaunchKernelGGL((pg::emit_kernel<pg::RangeCheckGD, true>), dim3(O.tiles < max_blocks ? O.tiles : max_blocks), dim3(pg::kThreads),
+                       0, static_cast<hipStream_t>(stream), A, O);
+    PG_HIP_TRY(hipGetLastError());
+    return PG_OK;
+}
+
 pg_status pg_range_check_batch(pg_engine *e, const pg_scalar *min_range, const pg_scalar *max_range,
                                const pg_scalar *d_witness, uint64_t batch, uint64_t gate_base, uint64_t var_base,
                                const pg_columns *out, pg_variable *d_result_vars, void *stream) {

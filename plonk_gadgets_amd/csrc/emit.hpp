@@ -118,8 +118,13 @@ __device__ __forceinline__ uint32_t find_item(const uint32_t *off, uint32_t Wt, 
 // Nothing this kernel writes depends on a field inversion: the variables that hold inverses (z of maybe_equal, inv of
 // is_non_zero) are written, at their final slots, by the inversion pre-pass (invert.hpp), which runs concurrently on
 // the engine's side stream; the variable sweep here skips exactly those slots (GD::is_inv_slot).
-template <class GD>
+//
+// kStructureOnly: selectors and wire indices alone -- for a gadget whose rows do not read the item record they are a
+// function of the public inputs and the numbering, not of the witnesses, so a rank can regenerate another rank's rows
+// instead of receiving them (distributed.VariablesOnlyPipeline); the item phase and the variable sweep are compiled out.
+template <class GD, bool kStructureOnly = false>
 __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(const typename GD::Args A, const EmitOut O) {
+    static_assert(!kStructureOnly || !(GD::kRagged || GD::kRecInRows), "rows of this gadget depend on its inputs");
     constexpr int W = GD::W;
     __shared__ uint4 s_table[kTableEntries * 2];
     __shared__ typename GD::ItemRec s_item[W];
@@ -163,7 +168,9 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
         }
 
         // ---- item phase: one lane per item --------------------------------
-        if (tid < Wt) GD::item(A, O, w0 + tid, s_table, s_item[tid]);
+        if constexpr (!kStructureOnly) {
+            if (tid < Wt) GD::item(A, O, w0 + tid, s_table, s_item[tid]);
+        }
         if constexpr (GD::kRagged || GD::kRecInRows) __syncthreads();
 
         const uint32_t total_rows = GD::kRagged ? s_roff[Wt] : Wt * G;
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
         if constexpr (!(GD::kRagged || GD::kRecInRows)) __syncthreads();  // item records visible
 
         // ---- variable sweep: one scalar (2 x 16 B) per lane ----------------
-        {
+        if constexpr (!kStructureOnly) {
             uint32_t it = 0, k = tid;
             if constexpr (!GD::kRagged) { it = k / V; k -= it * V; }
             for (uint32_t s = tid; s < total_vars; s += kThreads) {

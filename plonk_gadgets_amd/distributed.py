@@ -203,6 +203,75 @@ class GatherPipeline:
                 consume(self.gathered[kb], kk)
 
 
+class VariablesOnlyPipeline:
+    """The same stream of chunks as GatherPipeline, but only what depends on the witnesses travels (SURVEY.md section
+    8e): a rank emits its own chunk in full, regenerates the selectors and wire indices of the other ranks' chunks
+    locally (engine.range_check_structure_batch: a function of the public bounds and the numbering alone) and
+    all-gathers just the variable tables -- 32 B per variable instead of 184 B per row + 32 B per variable, i.e. 33 KB
+    of the 223 KB a 256-bit range_check item weighs.  Per chunk and rank: (world - 1) extra structure launches (local
+    HBM writes at ~7 TB/s) against a 6.7 x smaller transfer over the ~1 TB/s a GPU can ingest from its xGMI links.
+
+    `consume(parts, chunk_index)`: parts[r] is a Columns view of rank r's chunk (all nine arrays complete)."""
+
+    def __init__(self, engine, min_range, max_range, chunk: int, group=None):
+        self.engine, self.mn, self.mx, self.chunk, self.group = engine, min_range, max_range, chunk, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.lay = engine.range_check_layout(min_range, max_range, chunk)
+        G, V = self.lay.n_gates, self.lay.n_vars
+        dev = engine.device
+        # per double-buffer slot: rows of every rank's chunk, one gathered variable table, this rank's own table
+        self.rows = [[Columns.allocate(G, 0, dev) for _ in range(self.world)] for _ in range(2)]
+        self._vflat = [torch.empty(self.world * V * 4, dtype=torch.int64, device=dev) for _ in range(2)]
+        self.vars = [v.view(self.world, V, 4) for v in self._vflat]
+        self.own = [torch.empty((V, 4), dtype=torch.int64, device=dev) for _ in range(2)]
+        self.res = torch.empty((chunk,), dtype=torch.int64, device=dev)
+
+    def bytes_on_the_links_per_chunk(self) -> int:
+        return self.lay.n_vars * 32
+
+    def _parts(self, b):
+        out = []
+        for r in range(self.world):
+            c = self.rows[b][r]
+            out.append(Columns(c.q_m, c.q_l, c.q_r, c.q_o, c.q_c, c.w_l, c.w_r, c.w_o, self.vars[b][r]))
+        return out
+
+    def run(self, witness_local: torch.Tensor, total_per_rank: int, gate_base: int = 0, var_base: int = 0, consume=None):
+        """numbering as in GatherPipeline.run: rank r's item i is item r * total_per_rank + i of the whole batch"""
+        assert total_per_rank % self.chunk == 0
+        G, V = self.lay.gates_per_item, self.lay.vars_per_item
+        pending = None
+        for k in range(total_per_rank // self.chunk):
+            b = k & 1
+            for r in range(self.world):
+                first = r * total_per_rank + k * self.chunk
+                c = self.rows[b][r]
+                if r == self.rank:
+                    mine = Columns(c.q_m, c.q_l, c.q_r, c.q_o, c.q_c, c.w_l, c.w_r, c.w_o, self.own[b])
+                    self.engine.range_check_batch(self.mn, self.mx, witness_local[k * self.chunk:(k + 1) * self.chunk],
+                                                  gate_base + first * G, var_base + first * V, out=mine, result_vars=self.res)
+                else:
+                    self.engine.range_check_structure_batch(self.mn, self.mx, self.chunk, gate_base + first * G,
+                                                            var_base + first * V, c)
+            if pending is not None:
+                work, kb, kk = pending
+                work.wait()
+                if consume is not None:
+                    consume(self._parts(kb), kk)
+            if dist.is_initialized():
+                work = dist.all_gather_into_tensor(self._vflat[b], self.own[b].view(-1), group=self.group, async_op=True)
+            else:
+                self.vars[b][0].copy_(self.own[b])
+                work = _Done()
+            pending = (work, b, k)
+        if pending is not None:
+            work, kb, kk = pending
+            work.wait()
+            if consume is not None:
+                consume(self._parts(kb), kk)
+
+
 class _Done:
     def wait(self):
         return True

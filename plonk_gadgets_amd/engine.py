@@ -130,6 +130,16 @@ class Engine:
             raise PgError(st, "pg_range_check_batch")
         return out, result_vars
 
+    def range_check_structure_batch(self, min_range: BlsScalar, max_range: BlsScalar, batch: int, gate_base: int,
+                                    var_base: int, out: Columns):
+        """selectors and wire indices of range_check_batch's rows -- no witnesses, `out.var_values` is left alone"""
+        cols = out.as_c()
+        st = self._lib.pg_range_check_structure_batch(self._h, C.byref(min_range.c), C.byref(max_range.c), batch, gate_base,
+                                                      var_base, C.byref(cols), self._stream())
+        if st != 0:
+            raise PgError(st, "pg_range_check_structure_batch")
+        return out
+
     # ---- helpers -------------------------------------------------------------
     def _layout(self, lay: "_lib.LayoutC") -> Layout:
         return Layout(*[int(getattr(lay, f)) for f in ("num_bits", "gates_per_item", "vars_per_item", "n_gates", "n_vars")])

@@ -45,6 +45,16 @@ class OracleEngine:
         return out, res
 
 
+    def range_check_structure_batch(self, mn, mx, batch, gate_base, var_base, out):
+        """rows of the oracle for ANY witnesses (zeros here): only the selector and wire columns are copied"""
+        from oracle import pyoracle as po
+        ora = po.range_check_batch(mn.limbs(), mx.limbs(), np.zeros((batch, 4), dtype=np.uint64))
+        shift = np.uint64((var_base - 5) % 2**64)
+        for k in COLS[:-1]:
+            a = ora[k] + shift if k.startswith("w_") else ora[k]
+            getattr(out, k).copy_(torch.from_numpy(a.view(np.int64)))
+        return out
+
     # ---- ragged max_bound stand-ins (plan = per-item ladder bits and prefix sums, emit = oracle rows relocated) ----
     def ragged_buffers(self, batch):
         return (torch.empty((batch,), dtype=torch.int32), torch.empty((batch + 1,), dtype=torch.int64),
@@ -117,6 +127,13 @@ def worker(rank, world, port, total, q):
         pipe.run(wl, per_rank, 3, 5, consume=lambda g, k: seen.append((k, g.clone())))
         out["pipe"] = [(k, g.numpy().view(np.uint64).copy()) for k, g in seen]
         out["pipe_lay"] = (pipe.lay.n_gates, pipe.lay.n_vars)
+        # the same chunks with only the variable tables on the wire, the other rank's rows regenerated locally
+        vpipe = pd.VariablesOnlyPipeline(eng, mn, mx, chunk)
+        vseen = []
+        vpipe.run(wl, per_rank, 3, 5, consume=lambda parts, k: vseen.append(
+            (k, [{n: getattr(p, n).numpy().view(np.uint64).copy() for n in COLS} for p in parts])))
+        out["vpipe"] = vseen
+        out["vpipe_bytes"] = (vpipe.bytes_on_the_links_per_chunk(), pipe.bytes_per_chunk())
         # ragged max_bound: uneven shards (rank 0: 3 items, rank 1: 2), per-item bounds
         bounds, rwit = ragged_inputs()
         lo2, hi2 = (0, 3) if rank == 0 else (3, 5)
@@ -184,6 +201,20 @@ def test_sharded_gather_matches_single_process(total):
                     else:
                         exp = ora[name][first * G:(first + 2) * G].reshape(-1)
                     assert np.array_equal(sec, exp), (r, k, src, name)
+        # variables-only pipeline: every part complete and equal to the oracle, from a fraction of the bytes
+        assert [k for k, _ in got[r]["vpipe"]] == [0, 1]
+        for k, parts in got[r]["vpipe"]:
+            assert len(parts) == world
+            for src in range(world):
+                first = src * 4 + k * 2
+                for name in COLS:
+                    if name == "var_values":
+                        exp = ora[name][first * V:(first + 2) * V]
+                    else:
+                        exp = ora[name][first * G:(first + 2) * G]
+                    assert np.array_equal(parts[src][name], exp), (r, k, src, name)
+        on_links, packed = got[r]["vpipe_bytes"]
+        assert on_links == 2 * V * 32 and packed >= 2 * (G * 184 + V * 32)
 
 
 def test_shard_range_partitions():

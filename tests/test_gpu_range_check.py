@@ -290,3 +290,23 @@ def test_fuzz_ladder_lengths(engine):
         except AssertionError as e:
             raise AssertionError(f"trial {trial}: min={mn:#x} max={mx:#x} n={ora['num_bits']} batch={batch}: {e}")
     assert len(seen) >= 25 and {2, 252, 255} & seen
+
+
+def test_structure_only_rows(engine):
+    """pg_range_check_structure_batch: the selectors and wire indices of the full call, bit for bit, from the public
+    bounds and the numbering alone; the variable table is not touched"""
+    import plonk_gadgets_amd as pg
+    for mn, mx, batch in ((50_000, 250_000, 77), (0, 2**254, 40)):
+        wit = torch.from_numpy(synth.random_scalars(batch, 3).view(np.int64)).to("cuda:0")
+        full, _ = engine.range_check_batch(pg.BlsScalar.from_int(mn), pg.BlsScalar.from_int(mx), wit, 1234, 56789)
+        lay = engine.range_check_layout(pg.BlsScalar.from_int(mn), pg.BlsScalar.from_int(mx), batch)
+        only = pg.Columns.allocate(lay.n_gates, lay.n_vars, "cuda:0")
+        only.var_values.fill_(-7)
+        engine.range_check_structure_batch(pg.BlsScalar.from_int(mn), pg.BlsScalar.from_int(mx), batch, 1234, 56789, only)
+        torch.cuda.synchronize()
+        for k in ("q_m", "q_l", "q_r", "q_o", "q_c", "w_l", "w_r", "w_o"):
+            assert torch.equal(getattr(full, k), getattr(only, k)), k
+        assert bool((only.var_values == -7).all())
+        rows_only = pg.Columns.allocate(lay.n_gates, 0, "cuda:0")          # no variable table at all
+        engine.range_check_structure_batch(pg.BlsScalar.from_int(mn), pg.BlsScalar.from_int(mx), batch, 1234, 56789, rows_only)
+        assert torch.equal(rows_only.w_o, full.w_o) and torch.equal(rows_only.q_c, full.q_c)
