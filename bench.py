@@ -280,9 +280,10 @@ def main():
     if not args.no_fill and rank == 0:
         nbytes = cols.q_m.numel() * 8
         fill = {"bytes_per_launch": nbytes,
-                "what": "pg::fill_kernel, 16 B/lane streaming stores over one selector column's buffer, written as 1 "
-                        "linear stream / as 5 concurrent parts (the emitters' shape)"}
-        for streams in (1, 5):
+                "what": "16 B/lane streaming stores over one selector column's buffer: short-lived workgroups of 16 KiB "
+                        "(oneshot), long-lived ones writing 1 linear stream / 5 concurrent parts (the emitters' shape), "
+                        "and torch's own fill_ kernel"}
+        for streams in (0, 1, 5):
             eng.fill_bytes(cols.q_m, streams)
             torch.cuda.synchronize(dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -292,7 +293,17 @@ def main():
                 eng.fill_bytes(cols.q_m, streams)
             e1.record(stream)
             torch.cuda.synchronize(dev)
-            fill["gbps_%d_stream%s" % (streams, "" if streams == 1 else "s")] = nbytes * reps / (e0.elapsed_time(e1) / 1e3) / 1e9
+            key = "gbps_oneshot" if streams == 0 else "gbps_%d_stream%s" % (streams, "" if streams == 1 else "s")
+            fill[key] = nbytes * reps / (e0.elapsed_time(e1) / 1e3) / 1e9
+        cols.q_m.fill_(1)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(5):
+            cols.q_m.fill_(1)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        fill["gbps_torch_fill"] = nbytes * 5 / (e0.elapsed_time(e1) / 1e3) / 1e9
         fill["gbps"] = max(v for k, v in fill.items() if k.startswith("gbps_"))
 
     # ---- N > 1: gather-inclusive rate of the chunked all-gather pipeline (bounded sample) -----------------

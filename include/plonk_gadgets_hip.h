@@ -378,9 +378,10 @@ pg_status pg_check_rows(pg_engine *e, const pg_columns *cols, uint64_t n_gates, 
                         pg_variable zero_var, int64_t *first_bad, void *stream);
 
 /* ---- diagnostics ----------------------------------------------------------
- * pg_fill_bytes: a bare streaming fill (16 B per lane, same store form and grid shape as the emitters) used by
- * bench.py to measure the practical HBM write ceiling on the same box.  The buffer is written
- * as `streams` (1..16) equal parts advanced together, like the emitters' concurrent columns. */
+ * pg_fill_bytes: a bare streaming fill (16 B per lane, same store form as the emitters) that bench.py times on the same
+ * box as a comparison point.  streams = 1..16: the buffer is written as that many equal parts
+ * advanced together by long-lived workgroups, like the emitters' concurrent columns; streams = 0: one short-lived
+ * workgroup per 16 KiB. */
 pg_status pg_fill_bytes(pg_engine *e, void *d_dst /* 16-byte aligned */, uint64_t bytes /* multiple of 16 */,
                         uint32_t streams, uint64_t pattern, void *stream);
 

@@ -717,7 +717,15 @@ pg_status pg_fill_bytes(pg_engine *e, void *d_dst, uint64_t bytes, uint32_t stre
     if (!d_dst || !aligned(d_dst, 16) || (bytes & 15)) return fail(PG_ERR_INVALID_ARGUMENT, "dst/bytes not 16-byte aligned");
     if (bytes == 0) return PG_OK;
     PG_HIP_TRY(hipSetDevice(e->device));
-    if (streams < 1 || streams > 16) return fail(PG_ERR_INVALID_ARGUMENT, "streams must be in [1, 16]");
+    if (streams == 0) {  // short-lived workgroups, 16 KiB each
+        const uint64_t blocks = (bytes / 16 + 4 * pg::kThreads - 1) / (4 * pg::kThreads);
+        if (blocks > 0x7fffffffull) return fail(PG_ERR_INVALID_ARGUMENT, "buffer too large for one launch");
+        hipLaunchKernelGGL(pg::fill_oneshot_kernel, dim3((uint32_t)blocks), dim3(pg::kThreads), 0, static_cast<hipStream_t>(stream),
+                           static_cast<uint4 *>(d_dst), bytes / 16, pattern);
+        PG_HIP_TRY(hipGetLastError());
+        return PG_OK;
+    }
+    if (streams < 1 || streams > 16) return fail(PG_ERR_INVALID_ARGUMENT, "streams must be in [0, 16]");
     const uint64_t pieces = (bytes / 16 / streams + 65535) / 65536, cap = (uint64_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
     hipLaunchKernelGGL(pg::fill_kernel, dim3((uint32_t)(pieces < cap ? pieces : cap)), dim3(pg::kThreads), 0,
                        static_cast<hipStream_t>(stream), static_cast<uint4 *>(d_dst), bytes / 16, streams, pattern);

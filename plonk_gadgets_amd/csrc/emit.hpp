@@ -284,6 +284,16 @@ __global__ __launch_bounds__(kThreads) void fill_kernel(uint4 *dst, uint64_t n16
         for (uint64_t i = part * streams + threadIdx.x; i < n16; i += kThreads) store16(dst + i, v);
 }
 
+// the same fill as short-lived workgroups: one 16 KiB block per workgroup (four 16-byte stores per lane), no loop --
+// at any moment the resident workgroups cover one moving window of a few tens of MiB
+__global__ __launch_bounds__(kThreads) void fill_oneshot_kernel(uint4 *dst, uint64_t n16, uint64_t pattern) {
+    const uint4 v = make_uint4((uint32_t)pattern, (uint32_t)(pattern >> 32), (uint32_t)~pattern, (uint32_t)(~pattern >> 32));
+    const uint64_t base = (uint64_t)blockIdx.x * (4 * kThreads) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (base + k * kThreads < n16) store16(dst + base + k * kThreads, v);
+}
+
 // ---- exclusive prefix sums for ragged batches ---------------------------
 // counts[i] (rows, vars of item i) -> off[i], off[batch] = total.  Three small
 // kernels: per-block sums, scan of the block sums (one block), final scan.
