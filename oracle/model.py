@@ -114,6 +114,21 @@ class Composer:
         self._row(a, a, a, self.zero_var, 1, 0, 0, -1, 0, 0, None)
         return a
 
+    def sigma(self, padded_n: int) -> list:
+        """Permutation::compute_sigma_permutations [dusk-plonk 0.8, restated]: the positions recorded under one Variable,
+        in recording order, form one cycle; position (wire, gate) is encoded wire * padded_n + gate; rows past the
+        circuit keep the identity.  4 * padded_n entries."""
+        out = list(range(4 * padded_n))
+        for lst in self.perm:
+            for i, (w, g) in enumerate(lst):
+                w2, g2 = lst[(i + 1) % len(lst)]
+                out[w * padded_n + g] = w2 * padded_n + g2
+        return out
+
+    def dense_pi(self) -> list:
+        """construct_dense_pi_vec: one scalar per row, zero where no public input was given"""
+        return [self.pi.get(i, 0) for i in range(self.n)]
+
     def check(self) -> int:
         """index of the first unsatisfied row, or -1"""
         v = self.variables

@@ -242,6 +242,19 @@ class Composer:
         self.L.composer_sigma(self.c, padded_n, out.ctypes.data)
         return out.reshape(4, padded_n)
 
+    def full_columns(self) -> dict:
+        """the columns beyond the eight live ones: q_4, q_arith, w_4 and the dense public-input vector"""
+        n = self.n
+        out = {}
+        for name, col in (("q_4", 5), ("q_arith", 6)):
+            p = self.L.composer_selector(self.c, col)
+            out[name] = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(n, 4)).copy()
+        out["w_4"] = np.ctypeslib.as_array(self.L.composer_wire(self.c, 3), shape=(n,)).copy()
+        pi = np.zeros((n, 4), dtype=np.uint64)
+        self.L.composer_dense_pi(self.c, pi.ctypes.data)
+        out["dense_pi"] = pi
+        return out
+
     def export(self, gate_base: int = 0, var_base: int = 0) -> dict:
         n, nv = self.n, self.num_vars
         out = {}

@@ -34,6 +34,24 @@ def limbs(xs):
     return np.array([model.mont_limbs(x) for x in xs], dtype=np.uint64).reshape(-1, 4)
 
 
+class ModelOps:
+    """tests/refcases.py:full_circuit on the big-int model"""
+
+    def __init__(self, m):
+        self.m = m
+
+    def add_input(self, v): return self.m.add_input(v)
+    def allocate(self, v): return model.AllocatedScalar.allocate(self.m, v)
+    def range_check_loop(self, mn, mx, ws): return [model.range_check(self.m, mn, mx, self.allocate(w)) for w in ws]
+    def max_bound(self, mx, a): return model.max_bound(self.m, mx, a)[0]
+    def maybe_equal(self, a, b): return model.maybe_equal(self.m, a, b)
+    def is_non_zero(self, var, value): model.is_non_zero(self.m, var, value)
+    def conditionally_select_one(self, y, s): return model.conditionally_select_one(self.m, y, s)
+    def conditionally_select_zero(self, x, s): return model.conditionally_select_zero(self.m, x, s)
+    def constrain_to_constant(self, a, c, pi): self.m.constrain_to_constant(a, c, pi)
+    def boolean_gate(self, a): self.m.boolean_gate(a)
+
+
 def main():
     # 1. the reference's 8 range_check cases, one batch (all share min/max except case 7 -> its own file)
     for name, cases in (("range_check_ref_50k_250k", [c for c in RANGE_CHECK_CASES if c[0] == 50_000]),
@@ -91,6 +109,25 @@ def main():
     np.savez_compressed(os.path.join(HERE, "maybe_equal_ref.npz"), **pack(m, {
         "a": limbs([c[0] for c in MAYBE_EQUAL_CASES]), "b": limbs([c[1] for c in MAYBE_EQUAL_CASES]),
         "result_vars": res, "expected": [int(c[2]) for c in MAYBE_EQUAL_CASES]}))
+    # 6. one whole composer: every gadget once, a public input, from row 0 (the initial rows with their live fourth wire
+    #    included), with what the prover consumes next: constant columns, fourth wire, dense PI, sigma.
+    #    The circuit is spelled out in tests/refcases.py:full_circuit so that the C oracle and the device composer can
+    #    replay it call for call.
+    from tests.refcases import full_circuit  # noqa: E402
+    m = model.Composer()
+    full_circuit(ModelOps(m))
+    assert m.check() == -1
+    padded = 1 << (m.n - 1).bit_length()
+    e = model.export(m, 0, 0)
+    out = {k: np.array(v, dtype=np.uint64).reshape(-1, 4) for k, v in e.items() if k.startswith("q_") or k == "var_values"}
+    out.update({k: np.array(e[k], dtype=np.uint64) for k in ("w_l", "w_r", "w_o")})
+    out["w_4"] = np.array(m.w_4, dtype=np.uint64)
+    out["q_4"] = limbs(m.q_4)
+    out["q_arith"] = limbs(m.q_arith)
+    out["dense_pi"] = limbs(m.dense_pi())
+    out["sigma"] = np.array(m.sigma(padded), dtype=np.uint64)
+    out["padded_n"] = np.array([padded], dtype=np.uint64)
+    np.savez_compressed(os.path.join(HERE, "composer_full.npz"), **out)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

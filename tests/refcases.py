@@ -30,3 +30,23 @@ RANGE_CHECK_CASES = [
 
 # (a, b, expected)
 MAYBE_EQUAL_CASES = [(100, 100, True), (20, 3330, False), (0, 0, True)]
+
+
+def full_circuit(ops):
+    """One small circuit that touches every call of the path, spelled once and replayed on the big-int model (which
+    freezes it as tests/golden/composer_full.npz), on the C oracle and on the device composer.  `ops` supplies
+    add_input(int), allocate(int) -> AllocatedScalar, range_check_loop(min, max, [witness ints]) -> [Variable],
+    max_bound(max, allocated) -> Variable, maybe_equal(a, b), is_non_zero(var, int), conditionally_select_one/zero,
+    constrain_to_constant(var, int, pi int or None), boolean_gate(var).  Every row is satisfied."""
+    x = ops.add_input(9)
+    r = ops.range_check_loop(50_000, 250_000, [50_001, 250_000, 7])          # outcomes 1, 0, 0
+    ops.is_non_zero(x, 9)
+    y = ops.conditionally_select_one(x, r[0])                                  # selector 1 -> y = x = 9
+    ops.constrain_to_constant(y, 20, 11)                                       # 9 - 20 + PI(11) = 0
+    m = ops.maybe_equal(ops.allocate(5), ops.allocate(5))                      # 1
+    z = ops.conditionally_select_zero(m, r[1])                                 # 1 * 0 = 0
+    ops.constrain_to_constant(z, 0, None)
+    b = ops.max_bound(2**64, ops.allocate(2**64 + 5))                          # out of range: 0
+    ops.constrain_to_constant(b, 0, None)
+    ops.boolean_gate(m)
+    ops.constrain_to_constant(r[0], 1, None)

@@ -571,3 +571,51 @@ def test_ragged_batched_appends(engine):
     padded = 1 << (n - 1).bit_length()
     assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded))
     _sigma_properties(dev, padded)
+
+
+class DeviceOps:
+    """tests/refcases.py:full_circuit on the device composer (the range_check loop as ONE batched append when `batched`)"""
+
+    def __init__(self, dev, batched):
+        self.dev, self.batched = dev, batched
+
+    def add_input(self, v): return self.dev.add_input(S(v))
+    def allocate(self, v): return pg.AllocatedScalar.allocate(self.dev, S(v))
+    def max_bound(self, mx, a): return pg.max_bound(self.dev, S(mx), a)[0]
+    def maybe_equal(self, a, b): return pg.maybe_equal(self.dev, a, b)
+    def is_non_zero(self, var, value): pg.is_non_zero(self.dev, var, S(value))
+    def conditionally_select_one(self, y, s): return pg.conditionally_select_one(self.dev, y, s)
+    def conditionally_select_zero(self, x, s): return pg.conditionally_select_zero(self.dev, x, s)
+    def constrain_to_constant(self, a, c, pi): self.dev.constrain_to_constant(a, S(c), S(pi) if pi is not None else None)
+    def boolean_gate(self, a): self.dev.boolean_gate(a)
+
+    def range_check_loop(self, mn, mx, ws):
+        if not self.batched:
+            return [pg.range_check(self.dev, S(mn), S(mx), self.allocate(w)) for w in ws]
+        wit = torch.from_numpy(synth.scalars_from_ints(ws).view(np.int64)).to("cuda:0")
+        return [int(r) for r in self.dev.range_check_batch(S(mn), S(mx), wit)]
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_full_composer_golden_fixture(engine, batched):
+    """tests/golden/composer_full.npz (frozen from the big-int model; the C oracle reproduces it in the CPU suite): the
+    device composer's live columns, q_4 / q_arith / w_4, wire values, dense public inputs and sigma, from row 0"""
+    import os
+    from tests.refcases import full_circuit
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "composer_full.npz")))
+    dev = pg.StandardComposer(engine)
+    full_circuit(DeviceOps(dev, batched))
+    assert dev.check() == -1
+    exp = dev.export()
+    for k in COLS:
+        assert np.array_equal(exp[k], g[k]), k
+    mat = {k: v.cpu().numpy().view(np.uint64) for k, v in dev.materialize().items()}
+    for k in ("q_4", "q_arith", "w_4"):
+        assert np.array_equal(mat[k], g[k]), k
+    for k in ("q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add"):
+        assert not mat[k].any()
+    for wire, col in (("w_l", "w_l_value"), ("w_r", "w_r_value"), ("w_o", "w_o_value"), ("w_4", "w_4_value")):
+        assert np.array_equal(mat[col], g["var_values"][g[wire].astype(np.int64)]), col
+    assert np.array_equal(dev.construct_dense_pi_vec().cpu().numpy().view(np.uint64), g["dense_pi"])
+    padded = int(g["padded_n"][0])
+    assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64).reshape(-1), g["sigma"])
