@@ -71,7 +71,7 @@ constexpr uint32_t kPermIters = 16;                               // gates per t
 constexpr uint64_t kPermChunk = (uint64_t)kThreads * kPermIters;  // gates per workgroup of the gap kernel
 constexpr uint32_t kPermRowsPerThread = 5;  // item kernel: rows loaded per thread before any is processed
 constexpr uint32_t kPermLocalLdsLimit = 64 * 1024 - 256;
-constexpr uint32_t kPermNone = 0xFFFF, kPermDone = 0xFFFE, kPermForeign = 0xFFFD;
+constexpr uint32_t kPermNone = 0xFFFF, kPermDone = 0xFFFE;
 
 __device__ __forceinline__ uint64_t perm_encode(uint64_t gate, uint32_t wire, uint64_t padded_n) { return wire * padded_n + gate; }
 __device__ __forceinline__ uint64_t perm_encode_pos(uint64_t p, uint64_t padded_n) { return (p & 3) * padded_n + (p >> 2); }
@@ -160,19 +160,25 @@ __global__ __launch_bounds__(kThreads) void perm_gap_kernel(const PermCtx X, uin
     }
 }
 
-// one workgroup per item of a batched segment.  Dynamic LDS: cnt[V] off[V+1] (u32), lw[3L] pos[3L] sig[4L] (u16), zm[L] (u8)
-__host__ __device__ inline uint32_t perm_local_lds_bytes(uint32_t L, uint32_t V) { return 4 * (2 * V + 1) + 2 * 10 * L + L + 16; }
+// one workgroup per item (or group of small items) of a batched segment.  Dynamic LDS, kept small because the kernel
+// lives on occupancy (halving the resident workgroups costs 1.7x): cnt[V] (u32, LDS atomics), off[V+1] (u16),
+// lw[3L] (u16: local Variable id per position, later reused for the successors of those positions), pos[3L] (u16),
+// sig4[L] (u16: successors of the fourth-wire positions), zm[L] (u8: wires holding zero_var | foreign wires << 4)
+__host__ __device__ inline uint32_t perm_local_lds_bytes(uint32_t L, uint32_t V) {
+    return 4 * V + 2 * (V + 2) + 2 * (3 * L + 3 * L + L) + L + 16;
+}
 
-__global__ __launch_bounds__(kThreads) void perm_item_kernel(const PermCtx X, const PermSeg S, uint64_t groups, const PermSparse Q,
+__global__ __launch_bounds__(kThreads, 7) void perm_item_kernel(const PermCtx X, const PermSeg S, uint64_t groups, const PermSparse Q,
                                                             uint64_t *sigma) {
     extern __shared__ uint32_t perm_lds[];
     __shared__ uint64_t s_warp[4];
     __shared__ uint32_t s_foreign, s_rank;
     __shared__ unsigned long long s_base;
     const uint32_t Lmax = S.L * S.group, Vmax = S.V * S.group, tid = threadIdx.x;
-    uint32_t *cnt = perm_lds, *off = cnt + Vmax;
-    uint16_t *lw = reinterpret_cast<uint16_t *>(off + Vmax + 1), *pos = lw + 3 * Lmax, *sig = pos + 3 * Lmax;
-    uint8_t *zm = reinterpret_cast<uint8_t *>(sig + 4 * Lmax);
+    uint32_t *cnt = perm_lds;
+    uint16_t *off = reinterpret_cast<uint16_t *>(cnt + Vmax), *lw = off + ((Vmax + 2) & ~1u), *pos = lw + 3 * Lmax, *sig4 = pos + 3 * Lmax;
+    uint16_t *sig3 = lw;  // the ids are dead once the positions are scattered
+    uint8_t *zm = reinterpret_cast<uint8_t *>(sig4 + Lmax);
     for (uint64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const uint64_t ib = grp * S.group, ie = ib + S.group < S.items ? ib + S.group : S.items;
         const uint64_t rb0 = perm_rows_before(S, ib), vb0 = perm_vars_before(S, ib);
@@ -193,34 +199,30 @@ __global__ __launch_bounds__(kThreads) void perm_item_kernel(const PermCtx X, co
             for (uint32_t u = 0; u < kPermRowsPerThread; u++) {
                 const uint32_t r = rb + u * kThreads + tid;
                 if (r >= L) continue;
-                uint32_t zero = 0;
+                uint32_t mask = 0;  // bits 0..3: wire holds zero_var; bits 4..6: wire references a Variable created elsewhere
 #pragma unroll
                 for (uint32_t w = 0; w < 3; w++) {
                     const uint64_t rel = var[u][w] - v0;
                     uint32_t id = kPermNone;
-                    if (var[u][w] == X.zero_var) zero |= 1u << w;
+                    if (var[u][w] == X.zero_var) mask |= 1u << w;
                     else if (rel < (uint64_t)V) atomicAdd(&cnt[id = (uint32_t)rel], 1u);
-                    else {
-                        id = kPermForeign;
-                        atomicAdd(&s_foreign, 1u);
-                    }
+                    else mask |= 16u << w;
                     lw[3 * r + w] = (uint16_t)id;
-                    sig[4 * r + w] = (uint16_t)kPermNone;
                 }
+                if (mask >> 4) atomicAdd(&s_foreign, (uint32_t)__popc(mask >> 4));
                 const uint64_t var4 = perm_fourth_var(X, g0 + r);
-                if (var4 == X.zero_var) zero |= 8u;
+                if (var4 == X.zero_var) mask |= 8u;
                 else perm_sparse_put(X, Q, atomicAdd(Q.count, 1ull), var4, g0 + r, 3);
-                sig[4 * r + 3] = (uint16_t)kPermNone;
-                zm[r] = (uint8_t)zero;
+                zm[r] = (uint8_t)mask;
             }
         }
         __syncthreads();
-        if (s_foreign) {  // references to Variables created elsewhere: one reservation in the sparse list per workgroup
+        if (s_foreign) {  // one reservation in the sparse list per workgroup
             if (tid == 0) s_base = atomicAdd(Q.count, (unsigned long long)s_foreign);
             __syncthreads();
-            for (uint32_t j = tid; j < n3; j += kThreads)
-                if (lw[j] == kPermForeign) {
-                    const uint32_t r = j / 3, w = j - 3 * r;
+            for (uint32_t r = tid; r < L; r += kThreads)
+                for (uint32_t m = zm[r] >> 4; m; m &= m - 1) {
+                    const uint32_t w = (uint32_t)__ffs((int)m) - 1;
                     perm_sparse_put(X, Q, s_base + atomicAdd(&s_rank, 1u), X.C.w[w][g0 + r], g0 + r, w);
                 }
         }
@@ -230,18 +232,18 @@ __global__ __launch_bounds__(kThreads) void perm_item_kernel(const PermCtx X, co
             for (uint32_t id = b; id < e; id++) sum += cnt[id];
             uint32_t run = (uint32_t)block_exclusive_scan(sum, s_warp, tot);
             for (uint32_t id = b; id < e; id++) {
-                off[id] = run;
+                off[id] = (uint16_t)run;
                 run += cnt[id];
                 cnt[id] = 0;
             }
-            if (tid == 0) off[V] = (uint32_t)tot;
+            if (tid == 0) off[V] = (uint16_t)tot;
         }
         __syncthreads();
         for (uint32_t j = tid; j < n3; j += kThreads) {
             const uint32_t id = lw[j];
-            if (id < kPermForeign) pos[off[id] + atomicAdd(&cnt[id], 1u)] = (uint16_t)j;
+            if (id != kPermNone) pos[off[id] + atomicAdd(&cnt[id], 1u)] = (uint16_t)j;
         }
-        __syncthreads();
+        __syncthreads();  // lw is dead from here on: its storage holds the successors (sig3)
         for (uint32_t id = tid; id < V; id += kThreads) {
             const uint32_t b = off[id], k = off[id + 1] - b;
             for (uint32_t i = 1; i < k; i++) {  // the atomics scattered in any order: restore position order
@@ -253,22 +255,22 @@ __global__ __launch_bounds__(kThreads) void perm_item_kernel(const PermCtx X, co
                 }
                 pos[b + h] = x;
             }
-            for (uint32_t i = 0; i < k; i++) {  // 3 r + w -> 4 r + w
-                const uint32_t a = pos[b + i], z = pos[b + (i + 1 == k ? 0 : i + 1)];
-                sig[a + a / 3] = (uint16_t)(z + z / 3);
+            for (uint32_t i = 0; i < k; i++) {  // successors are stored as 4 r + w
+                const uint32_t z = pos[b + (i + 1 == k ? 0 : i + 1)];
+                sig3[pos[b + i]] = (uint16_t)(z + z / 3);
             }
         }
         for (uint32_t r = tid; r < L; r += kThreads) {  // zero chain
-            const uint32_t zero = zm[r];
+            const uint32_t zero = zm[r] & 15u;
             if (!zero) continue;
             uint32_t nr = r + 1;
-            while (nr < L && zm[nr] == 0) nr++;
-            uint32_t succ = nr < L ? 4 * nr + (uint32_t)__ffs((int)zm[nr]) - 1 : kPermDone;
+            while (nr < L && (zm[nr] & 15u) == 0) nr++;
+            uint32_t succ = nr < L ? 4 * nr + (uint32_t)__ffs((int)(zm[nr] & 15u)) - 1 : kPermDone;
             for (uint32_t m = zero; m;) {
                 const uint32_t w = 31 - __clz((int)m);
                 m &= ~(1u << w);
                 if (succ == kPermDone) sigma[perm_encode(g0 + r, w, X.padded_n)] = perm_next_zero_from(X, g0 + L);
-                sig[4 * r + w] = (uint16_t)succ;
+                if (w == 3) sig4[r] = (uint16_t)succ; else sig3[3 * r + w] = (uint16_t)succ;
                 succ = 4 * r + w;
             }
         }
@@ -276,7 +278,9 @@ __global__ __launch_bounds__(kThreads) void perm_item_kernel(const PermCtx X, co
 #pragma unroll
         for (uint32_t w = 0; w < 4; w++)
             for (uint32_t r = tid; r < L; r += kThreads) {
-                const uint32_t s = sig[4 * r + w];
+                const uint32_t m = zm[r];
+                if (w < 3 ? (m >> (4 + w) & 1u) : !(m & 8u)) continue;  // that position is on the sparse list
+                const uint32_t s = w < 3 ? sig3[3 * r + w] : sig4[r];
                 if (s < kPermDone) sigma[perm_encode(g0 + r, w, X.padded_n)] = perm_encode(g0 + (s >> 2), s & 3, X.padded_n);
             }
         __syncthreads();
