@@ -96,6 +96,10 @@ class StandardComposer {
     StandardComposer(const StandardComposer &) = delete;
     StandardComposer &operator=(const StandardComposer &) = delete;
 
+    // capacity is explicit here (the reference's Vecs grow on their own): reserve, or let appends double it
+    void reserve(uint64_t gate_capacity, uint64_t var_capacity) { pg_throw(pg_composer_reserve(h, gate_capacity, var_capacity), "reserve"); }
+    void auto_grow(bool on = true) { pg_throw(pg_composer_auto_grow(h, on ? 1 : 0), "auto_grow"); }
+
     uint64_t circuit_size() const { return pg_composer_circuit_size(h); }
     uint64_t num_variables() const { return pg_composer_num_variables(h); }
     Variable zero_var() const { return Variable{pg_composer_zero_var(h)}; }

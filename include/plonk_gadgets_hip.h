@@ -248,8 +248,17 @@ void pg_composer_destroy(pg_composer *c);
 uint64_t pg_composer_circuit_size(const pg_composer *c);  /* StandardComposer::circuit_size(): rows so far */
 uint64_t pg_composer_num_variables(const pg_composer *c);
 pg_variable pg_composer_zero_var(const pg_composer *c);
-/* device pointers to the live columns (row 0 = gate 0, var_values[0] = Variable(0)) */
+/* device pointers to the live columns (row 0 = gate 0, var_values[0] = Variable(0)); they move when the composer grows */
 pg_status pg_composer_columns(const pg_composer *c, pg_columns *out);
+/* Capacity.  The reference's composer is a set of Vecs that grow on their own; here growth is an explicit decision
+ * because it re-allocates HBM and copies the live part (device to device, on the composer's stream):
+ *   pg_composer_reserve    make room for at least that many rows / Variables in total (never shrinks);
+ *   pg_composer_auto_grow  on = an append that does not fit doubles the capacity it ran out of (at least to what the
+ *                          append needs) instead of returning PG_ERR_CAPACITY; off (the default) = fixed capacity. */
+pg_status pg_composer_reserve(pg_composer *c, uint64_t gate_capacity, uint64_t var_capacity);
+pg_status pg_composer_auto_grow(pg_composer *c, int on);
+uint64_t pg_composer_gate_capacity(const pg_composer *c);
+uint64_t pg_composer_var_capacity(const pg_composer *c);
 pg_status pg_composer_sync(pg_composer *c);
 
 /* composer calls used by the gadgets (same argument order as dusk-plonk 0.8; `pi` may be NULL = None) */

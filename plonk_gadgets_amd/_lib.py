@@ -104,6 +104,10 @@ SIGNATURES = {
     "pg_composer_num_variables": (C.c_uint64, [C.c_void_p]),
     "pg_composer_zero_var": (C.c_uint64, [C.c_void_p]),
     "pg_composer_columns": (C.c_int, [C.c_void_p, _P(ColumnsC)]),
+    "pg_composer_reserve": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
+    "pg_composer_auto_grow": (C.c_int, [C.c_void_p, C.c_int]),
+    "pg_composer_gate_capacity": (C.c_uint64, [C.c_void_p]),
+    "pg_composer_var_capacity": (C.c_uint64, [C.c_void_p]),
     "pg_composer_sync": (C.c_int, [C.c_void_p]),
     "pg_composer_add_input": (C.c_int, [C.c_void_p, _P(Scalar), _P(C.c_uint64)]),
     "pg_composer_add_witness_to_circuit_description": (C.c_int, [C.c_void_p, _P(Scalar), _P(C.c_uint64)]),

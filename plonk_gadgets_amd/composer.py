@@ -57,6 +57,18 @@ class StandardComposer:
         except Exception:
             pass
 
+    # -- capacity ---------------------------------------------------------------------------
+    def reserve(self, gate_capacity: int, var_capacity: int):
+        """room for at least that many rows / Variables in total (re-allocates and copies the live part)"""
+        _chk(self._lib.pg_composer_reserve(self._h, gate_capacity, var_capacity), "pg_composer_reserve")
+
+    def auto_grow(self, on: bool = True):
+        """like the reference's Vecs: an append that does not fit doubles the capacity instead of failing"""
+        _chk(self._lib.pg_composer_auto_grow(self._h, int(on)), "pg_composer_auto_grow")
+
+    def capacity(self) -> tuple:
+        return int(self._lib.pg_composer_gate_capacity(self._h)), int(self._lib.pg_composer_var_capacity(self._h))
+
     # -- state ------------------------------------------------------------------------------
     def circuit_size(self) -> int:
         return int(self._lib.pg_composer_circuit_size(self._h))

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 

@@ -619,3 +619,36 @@ def test_full_composer_golden_fixture(engine, batched):
     assert np.array_equal(dev.construct_dense_pi_vec().cpu().numpy().view(np.uint64), g["dense_pi"])
     padded = int(g["padded_n"][0])
     assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64).reshape(-1), g["sigma"])
+
+
+def test_composer_grows(engine):
+    """pg_composer_auto_grow / pg_composer_reserve: a composer created with room for 8 rows and 8 Variables builds the
+    golden circuit (single calls and a batched append) by doubling; nothing already appended is lost"""
+    import os
+    from tests.refcases import full_circuit
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "composer_full.npz")))
+    for batched in (False, True):
+        dev = pg.StandardComposer(engine, gate_capacity=8, var_capacity=8)
+        dev.auto_grow()
+        full_circuit(DeviceOps(dev, batched))
+        gc, vc = dev.capacity()
+        assert gc >= dev.circuit_size() > 8 and vc >= dev.num_variables() > 8
+        assert dev.check() == -1
+        exp = dev.export()
+        for k in COLS:
+            assert np.array_equal(exp[k], g[k]), k
+        padded = int(g["padded_n"][0])
+        assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64).reshape(-1), g["sigma"])
+    dev = pg.StandardComposer(engine, gate_capacity=8, var_capacity=8)
+    with pytest.raises(pg.PgError, match="capacity"):
+        pg.range_check(dev, S(0), S(2**64), pg.AllocatedScalar.allocate(dev, S(1)))
+    before = dev.export()
+    dev.reserve(1000, 2000)
+    assert dev.capacity() == (1000, 2000)
+    dev.reserve(10, 10)                 # never shrinks
+    assert dev.capacity() == (1000, 2000)
+    after = dev.export()
+    for k in COLS:
+        assert np.array_equal(before[k], after[k]), k
+    r = pg.range_check(dev, S(0), S(2**64), pg.AllocatedScalar.allocate(dev, S(1)))
+    assert dev.value(r).to_int() == 1 and dev.check() == -1
