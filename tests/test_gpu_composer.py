@@ -652,3 +652,27 @@ def test_composer_grows(engine):
         assert np.array_equal(before[k], after[k]), k
     r = pg.range_check(dev, S(0), S(2**64), pg.AllocatedScalar.allocate(dev, S(1)))
     assert dev.value(r).to_int() == 1 and dev.check() == -1
+
+
+def test_empty_batches_and_minimal_composer(engine):
+    """zero-item batched appends are no-ops; sigma of the smallest composers (only zero_var's row; the initial three
+    rows) equals the oracle's, for padded sizes from exactly n upwards"""
+    from oracle import pyoracle as po
+    for dummy in (False, True):
+        dev, ora = pg.StandardComposer(engine, with_dummy=dummy), po.Composer(dummy)
+        same(dev, ora)
+        n = dev.circuit_size()
+        for padded in (n, n + 1, 8):
+            assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded)), (dummy, padded)
+        empty = torch.empty((0, 4), dtype=torch.int64, device="cuda:0")
+        novars = torch.empty((0,), dtype=torch.int64, device="cuda:0")
+        assert dev.range_check_batch(S(0), S(2**64), empty).numel() == 0
+        assert dev.max_bound_batch(S(2**64), empty)[0].numel() == 0
+        assert dev.max_bound_ragged_batch(empty, empty)[0].numel() == 0
+        assert dev.maybe_equal_batch(novars, novars).numel() == 0
+        assert dev.is_non_zero_batch(novars)[1] == 0
+        assert dev.scalar_mix_batch(empty, empty, empty, empty, empty)[2] == 0
+        assert dev.add_input_batch(empty) == dev.num_variables()
+        same(dev, ora)
+        assert dev.check() == -1
+        assert np.array_equal(dev.permutation(8).cpu().numpy().view(np.uint64), ora.sigma(8))
