@@ -25,6 +25,7 @@ VARIANTS = {
     "inv_cap8": ["-DPG_INV_MAX_PER_LANE=8"],
     "side_stream_normal_priority": ["-DPG_SIDE_STREAM_NORMAL_PRIORITY"],
     "xcd_remap": ["-DPG_XCD_REMAP"],
+    "ablate_amul": ["-DPG_ABLATE_AMUL"],  # timing only (wrong values): the emit kernel without its per-accumulator multiplication
     "nt_stores": ["-DPG_NT_STORES"],
     "rc_w16": ["-DPG_RC_W=16"],
     "grid8": ["-DPG_GRID_BLOCKS_PER_CU=8"],
