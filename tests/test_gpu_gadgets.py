@@ -589,3 +589,54 @@ def test_device_inversion_edge_values(engine):
     torch.cuda.synchronize()
     assert_cols(cols.to_numpy(), exp)
     assert err.cpu().numpy().tolist() == errs and nerr == 1
+
+
+def test_calls_can_be_captured_in_a_hip_graph(engine):
+    """after one warm-up call (scratch allocated) the asynchronous plan + emit of the ragged mix -- five kernels on the
+    caller's stream, the inversion pre-pass on the engine's side stream, forked and joined with events -- records into a
+    HIP graph; replays write the same bytes as the eager calls, also for new inputs in the same buffers"""
+    import plonk_gadgets_amd as pg
+    batch = 3000
+    v, y, s, a, b = mix_inputs(batch, 77, zeros=(5, 2999))
+    ins = [dev(x) for x in (v, y, s, a, b)]
+    _, roff, voff = engine.ragged_buffers(batch)
+    res = torch.empty((batch, 2), dtype=torch.int64, device="cuda:0")
+    cols = pg.Columns.allocate(10 * batch, 15 * batch, "cuda:0")
+
+    def step():
+        engine.scalar_mix_plan_async(ins[0], roff, voff)
+        engine.scalar_mix_emit(*ins, roff, voff, cols, res, 3, 5, 0)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    eager = {k: t.copy() for k, t in cols.to_numpy().items()}
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        step()
+    for k in ("q_m", "w_l", "var_values"):
+        getattr(cols, k).zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    got = cols.to_numpy()
+    lay, nerr = engine.plan_result()
+    assert nerr == 2
+    ng, nv = lay.n_gates, lay.n_vars
+    for k in eager:
+        n = nv if k == "var_values" else ng
+        assert np.array_equal(got[k][:n], eager[k][:n]), k
+    # new inputs, same buffers: the replay follows them
+    v2, y2, s2, a2, b2 = mix_inputs(batch, 78)
+    for t, x in zip(ins, (v2, y2, s2, a2, b2)):
+        t.copy_(dev(x))
+    graph.replay()
+    torch.cuda.synchronize()
+    from oracle import pyoracle as po
+    ora = po.scalar_mix_batch(v2, y2, s2, a2, b2)
+    got = cols.to_numpy()
+    for k in ("q_m", "q_l", "q_r", "q_o", "q_c", "w_l", "w_r", "w_o"):
+        assert np.array_equal(got[k][:ora["n_gates"]], ora[k]), k
+    assert np.array_equal(got["var_values"][:ora["n_vars"]], ora["var_values"])
