@@ -676,3 +676,122 @@ def test_empty_batches_and_minimal_composer(engine):
         same(dev, ora)
         assert dev.check() == -1
         assert np.array_equal(dev.permutation(8).cpu().numpy().view(np.uint64), ora.sigma(8))
+
+
+@pytest.mark.parametrize("seed", list(range(1, 11)))
+def test_fuzz_composer_programs(engine, seed):
+    """random programs of 30 composer operations -- single calls and every batched append, on random earlier Variables,
+    random bounds and batch sizes -- replayed on the oracle call for call: same columns, same first unsatisfied row,
+    same sigma.  (Segments of every shape, gaps between them, references across segments, hot Variables.)"""
+    from oracle import pyoracle as po
+    import ctypes as C
+    import random
+    rng = random.Random(seed)
+    dev, ora = pg.StandardComposer(engine, 1 << 14, 1 << 14), po.Composer()
+    dev.auto_grow()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:0")
+    tv = lambda xs: torch.tensor(xs, dtype=torch.int64, device="cuda:0")
+    F = lambda x: po.fr(synth.mont(x))
+    nb = C.c_uint64()
+
+    def rand_scalars(k):
+        return synth.scalars_from_ints([rng.choice([0, 1, rng.randrange(1 << 16), rng.randrange(po_Q)]) for _ in range(k)])
+
+    po_Q = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    log = []
+    for step in range(30):
+        nv = dev.num_variables()
+        assert nv == ora.num_vars
+        op = rng.choice(["add_input", "rc", "rc_alloc", "mb", "mb_alloc", "mb_ragged", "dec", "sel0", "sel1", "meq", "inz", "mix",
+                         "bool", "single_sel0", "ctc", "alloc_batch"])
+        k = rng.randrange(1, 40)
+        old = [rng.randrange(nv) for _ in range(k)]
+        old2 = [rng.randrange(nv) for _ in range(k)]
+        log.append((op, k))
+        if op == "add_input":
+            x = rng.randrange(po_Q)
+            assert dev.add_input(S(x)) == ora.add_input(synth.mont(x))
+        elif op == "alloc_batch":
+            w = rand_scalars(k)
+            assert dev.add_input_batch(t(w)) == int(ora.allocate(w[0]).var)
+            for x in w[1:]:
+                ora.allocate(x)
+        elif op in ("rc", "rc_alloc"):
+            mx = rng.randrange(2, 1 << rng.randrange(2, 40))
+            mn = rng.randrange(0, mx)
+            w = rand_scalars(k)
+            if op == "rc":
+                r = dev.range_check_batch(S(mn), S(mx), t(w))
+                o = [ora.L.range_check(ora.c, F(mn), F(mx), ora.allocate(x)) for x in w]
+            else:
+                vals = [ora.L.composer_value(ora.c, v) for v in old]
+                wv = np.array([[x.l[i] for i in range(4)] for x in vals], dtype=np.uint64)
+                r = dev.range_check_allocated_batch(S(mn), S(mx), tv(old), t(wv))
+                o = [ora.L.range_check(ora.c, F(mn), F(mx), po.AllocatedScalar(v, x)) for v, x in zip(old, vals)]
+            assert r.cpu().numpy().view(np.uint64).tolist() == [int(x) for x in o]
+        elif op in ("mb", "mb_alloc"):
+            mx = rng.randrange(1, 1 << rng.randrange(1, 60))
+            w = rand_scalars(k)
+            if op == "mb":
+                r, _ = dev.max_bound_batch(S(mx), t(w))
+                o = [ora.L.max_bound(ora.c, F(mx), ora.allocate(x), C.byref(nb)) for x in w]
+            else:
+                vals = [ora.L.composer_value(ora.c, v) for v in old]
+                wv = np.array([[x.l[i] for i in range(4)] for x in vals], dtype=np.uint64)
+                r, _ = dev.max_bound_allocated_batch(S(mx), tv(old), t(wv))
+                o = [ora.L.max_bound(ora.c, F(mx), po.AllocatedScalar(v, x), C.byref(nb)) for v, x in zip(old, vals)]
+            assert r.cpu().numpy().view(np.uint64).tolist() == [int(x) for x in o]
+        elif op == "mb_ragged":
+            bounds = [rng.randrange(1, 1 << rng.randrange(1, 100)) for _ in range(k)]
+            w = rand_scalars(k)
+            r, _ = dev.max_bound_ragged_batch(t(synth.scalars_from_ints(bounds)), t(w))
+            o = [ora.L.max_bound(ora.c, F(b), ora.allocate(x), C.byref(nb)) for b, x in zip(bounds, w)]
+            assert r.cpu().numpy().view(np.uint64).tolist() == [int(x) for x in o]
+        elif op == "dec":
+            bits = rng.randrange(0, 30)
+            vals = [ora.L.composer_value(ora.c, v) for v in old]
+            wv = np.array([[x.l[i] for i in range(4)] for x in vals], dtype=np.uint64)
+            r = dev.scalar_decomposition_batch(bits, tv(old), t(wv))
+            o = [ora.L.scalar_decomposition_gadget(ora.c, bits, po.AllocatedScalar(v, x), None) for v, x in zip(old, vals)]
+            assert r.cpu().numpy().view(np.uint64).tolist() == [int(x) for x in o]
+        elif op in ("sel0", "sel1"):
+            fn = dev.conditionally_select_zero_batch if op == "sel0" else dev.conditionally_select_one_batch
+            ofn = ora.L.conditionally_select_zero if op == "sel0" else ora.L.conditionally_select_one
+            r = fn(tv(old), tv(old2))
+            assert r.cpu().numpy().view(np.uint64).tolist() == [int(ofn(ora.c, a, b)) for a, b in zip(old, old2)]
+        elif op == "meq":
+            r = dev.maybe_equal_batch(tv(old), tv(old2))
+            o = [ora.L.maybe_equal(ora.c, po.AllocatedScalar(a, ora.L.composer_value(ora.c, a)),
+                                   po.AllocatedScalar(b, ora.L.composer_value(ora.c, b))) for a, b in zip(old, old2)]
+            assert r.cpu().numpy().view(np.uint64).tolist() == [int(x) for x in o]
+        elif op == "inz":
+            err, nerr = dev.is_non_zero_batch(tv(old))
+            o = [int(ora.L.is_non_zero(ora.c, v, ora.L.composer_value(ora.c, v))) for v in old]
+            assert err.cpu().numpy().tolist() == o and nerr == sum(o)
+        elif op == "mix":
+            v, y, s, a, b = (rand_scalars(k) for _ in range(5))
+            r, err, nerr = dev.scalar_mix_batch(t(v), t(y), t(s), t(a), t(b))
+            o, oe = [], []
+            for i in range(k):
+                vv, yy, ss = ora.add_input(v[i]), ora.add_input(y[i]), ora.add_input(s[i])
+                aa, bb = ora.allocate(a[i]), ora.allocate(b[i])
+                oe.append(int(ora.L.is_non_zero(ora.c, vv, po.fr(v[i]))))
+                o.append([int(ora.L.conditionally_select_one(ora.c, yy, ss)), int(ora.L.maybe_equal(ora.c, aa, bb))])
+            assert r.cpu().numpy().view(np.uint64).tolist() == o and err.cpu().numpy().tolist() == oe
+        elif op == "bool":
+            dev.boolean_gate(old[0])
+            ora.L.composer_boolean_gate(ora.c, old[0])
+        elif op == "single_sel0":
+            assert pg.conditionally_select_zero(dev, old[0], old2[0]) == int(ora.L.conditionally_select_zero(ora.c, old[0], old2[0]))
+        elif op == "ctc":
+            x = rng.randrange(po_Q)
+            dev.constrain_to_constant(old[0], S(x), None)
+            ora.L.composer_constrain_to_constant(ora.c, old[0], F(x), None)
+    try:
+        same(dev, ora)
+        assert dev.check() == ora.check()
+        n = dev.circuit_size()
+        padded = 1 << (n - 1).bit_length()
+        assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded))
+    except AssertionError as e:
+        raise AssertionError(f"seed {seed}, program {log}: {e}")
