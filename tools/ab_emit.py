@@ -28,6 +28,8 @@ VARIANTS = {
     "ablate_amul": ["-DPG_ABLATE_AMUL"],  # timing only (wrong values): the emit kernel without its per-accumulator multiplication
     "nt_stores": ["-DPG_NT_STORES"],
     "rc_w16": ["-DPG_RC_W=16"],
+    "mb_w32": ["-DPG_MB_W=32"],
+    "mb_w24": ["-DPG_MB_W=24"],
     "rc_w64": ["-DPG_RC_W=64"],
     "rc_w128": ["-DPG_RC_W=128"],
     "grid8": ["-DPG_GRID_BLOCKS_PER_CU=8"],
