@@ -112,7 +112,7 @@ __device__ __forceinline__ int perm_home_seg(const PermCtx &X, uint64_t var) {
 }
 
 struct PermSparse {
-    uint64_t *keys;               // Variable << 33 | position, in any order
+    uint64_t *keys;               // Variable << pos_bits | position, in any order
     unsigned long long *count;    // entries wanted so far (may pass cap: the host then grows the list and runs again)
     uint64_t cap;
 };
