@@ -28,6 +28,10 @@ VARIANTS = {
     "ablate_amul": ["-DPG_ABLATE_AMUL"],  # timing only (wrong values): the emit kernel without its per-accumulator multiplication
     "nt_stores": ["-DPG_NT_STORES"],
     "rc_w16": ["-DPG_RC_W=16"],
+    "mix_w32": ["-DPG_MIX_W=32"],
+    "mix_w16": ["-DPG_MIX_W=16"],
+    "seq_mix_w32": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_MIX_W=32"],
+    "seq_mix_w128": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_MIX_W=128"],
     "mb_w32": ["-DPG_MB_W=32"],
     "mb_w24": ["-DPG_MB_W=24"],
     "rc_w64": ["-DPG_RC_W=64"],
