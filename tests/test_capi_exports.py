@@ -92,13 +92,13 @@ def test_host_inversion_matches_fermat_and_pow():
 
 
 def test_generated_rust_declarations_cover_the_header():
-    """bindings/rust/ffi.rs (tools/gen_rust_ffi.py; not compiled here -- no Rust toolchain) is current and declares
+    """bindings/rust/src/ffi.rs (tools/gen_rust_ffi.py; not compiled here -- no Rust toolchain) is current and declares
     every function of the header exactly once"""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gen_rust_ffi as g
     text, names = g.generate()
     assert sorted(names) == declared_functions() and len(set(names)) == len(names)
-    assert open(os.path.join(ROOT, "bindings", "rust", "ffi.rs")).read() == text, "run python tools/gen_rust_ffi.py"
+    assert open(os.path.join(ROOT, "bindings", "rust", "src", "ffi.rs")).read() == text, "run python tools/gen_rust_ffi.py"
     for n in names:
         assert len(re.findall(r"\bpub fn %s\(" % n, text)) == 1
