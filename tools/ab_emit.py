@@ -159,7 +159,7 @@ def run_c4(log2_chunk=19, rounds=4):
                           "gbps_median": nbytes / ts[len(ts) // 2] / 1e6}))
 
 
-def run(log2_chunk=18, rounds=4):
+def run(log2_chunk=18, rounds=4, mn_int=0, mx_int=2**254):
     import numpy as np
     import torch
     from plonk_gadgets_amd import _lib, synth
@@ -167,8 +167,9 @@ def run(log2_chunk=18, rounds=4):
     dev = torch.device("cuda", 0)
     chunk = 1 << log2_chunk
     wit = torch.from_numpy(synth.random_scalars(chunk).view(np.int64)).to(dev)
-    mn, mx = pg.BlsScalar.from_int(0), pg.BlsScalar.from_int(2**254)
-    G, V = 1031, 1034
+    mn, mx = pg.BlsScalar.from_int(mn_int), pg.BlsScalar.from_int(mx_int)
+    lay0 = pg.Engine(0).range_check_layout(mn, mx, 1)
+    G, V = lay0.gates_per_item, lay0.vars_per_item
     cols = pg.Columns.allocate(chunk * G, chunk * V, dev)
     res = torch.empty((chunk,), dtype=torch.int64, device=dev)
     cc = cols.as_c()
