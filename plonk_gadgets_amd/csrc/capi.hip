@@ -195,6 +195,7 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
     PG_HIP_TRY(hipSetDevice(e->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const pg::EmitOut O = make_out(c, batch, GD::W, gate_base, var_base, zero_var, row_off, var_off);
+    bool side = false;  // the inversion pre-pass runs on the engine's side stream
     if constexpr (GD::kInv > 0) {
         const uint64_t elems = batch * GD::kInv;
         PG_TRY(ensure_inv_scratch(e, elems));
@@ -211,24 +212,29 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
         const uint64_t lanes = (elems + per_lane - 1) / per_lane;
         const uint32_t blocks = (uint32_t)((lanes + pg::kThreads - 1) / pg::kThreads);
 #if defined(PG_SEQUENTIAL_PREPASS)  // A/B build: the pre-pass on the caller's stream, ahead of the emit kernel
-        hipLaunchKernelGGL(pg::batch_invert_kernel<GD>, dim3(blocks), dim3(pg::kThreads), 0, st, A, O, elems,
-                           (uint32_t)per_lane, e->d_prefix);
-        PG_HIP_TRY(hipGetLastError());
-        PG_HIP_TRY(hipEventRecord(e->ev_inv, st));
+        side = false;
 #else
-        PG_HIP_TRY(hipEventRecord(e->ev_fork, st));  // the pre-pass reads the call's inputs: order it after the stream
-        PG_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-        hipLaunchKernelGGL(pg::batch_invert_kernel<GD>, dim3(blocks), dim3(pg::kThreads), 0, e->side, A, O, elems,
-                           (uint32_t)per_lane, e->d_prefix);
-        PG_HIP_TRY(hipGetLastError());
-        PG_HIP_TRY(hipEventRecord(e->ev_inv, e->side));
+        // a handful of elements (the single-gadget calls of pg_composer): two event hops cost more than the overlap buys
+        side = elems >= 2048;
 #endif
+        if (!side) {
+            hipLaunchKernelGGL(pg::batch_invert_kernel<GD>, dim3(blocks), dim3(pg::kThreads), 0, st, A, O, elems,
+                               (uint32_t)per_lane, e->d_prefix);
+            PG_HIP_TRY(hipGetLastError());
+        } else {
+            PG_HIP_TRY(hipEventRecord(e->ev_fork, st));  // the pre-pass reads the call's inputs: order it after the stream
+            PG_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+            hipLaunchKernelGGL(pg::batch_invert_kernel<GD>, dim3(blocks), dim3(pg::kThreads), 0, e->side, A, O, elems,
+                               (uint32_t)per_lane, e->d_prefix);
+            PG_HIP_TRY(hipGetLastError());
+            PG_HIP_TRY(hipEventRecord(e->ev_inv, e->side));
+        }
     }
     const uint32_t max_blocks = (uint32_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
     const uint32_t grid = O.tiles < max_blocks ? O.tiles : max_blocks;
     hipLaunchKernelGGL(pg::emit_kernel<GD>, dim3(grid), dim3(pg::kThreads), 0, st, A, O);
     PG_HIP_TRY(hipGetLastError());
-    if constexpr (GD::kInv > 0) PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_inv, 0));  // join
+    if (side) PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_inv, 0));  // join
     return PG_OK;
 }
 
