@@ -107,6 +107,17 @@ pg_status pg_scalar_invert_fermat(const pg_scalar *a, pg_scalar *out);
 uint64_t pg_bits_count(const pg_scalar *s);                    /* src/range.rs:173-181 */
 uint64_t pg_num_bits_closest_power_of_two(const pg_scalar *s); /* src/range.rs:185-189 */
 
+/* ---- the data format on the way in and out -------------------------------------------
+ * A BlsScalar travels as 32 little-endian bytes of its canonical value (dusk-bytes Serializable, what
+ * src/range.rs:162 reads back with to_bytes); the kernels want Montgomery limbs.  Both conversions in bulk, device to
+ * device, 16-byte aligned buffers of 32 * batch bytes:
+ *   from_canonical  BlsScalar::from_bytes per element; an encoding >= q (from_bytes returns Err) becomes 0, is flagged in
+ *                   d_bad_mask (may be NULL) and counted; PG_ERR_INVALID_ARGUMENT if any (synchronises `stream`)
+ *   to_canonical    BlsScalar::to_bytes per element */
+pg_status pg_scalars_from_canonical_batch(pg_engine *e, const void *d_bytes, uint64_t batch, pg_scalar *d_out,
+                                          uint8_t *d_bad_mask, uint64_t *bad_count /* may be NULL */, void *stream);
+pg_status pg_scalars_to_canonical_batch(pg_engine *e, const pg_scalar *d_scalars, uint64_t batch, void *d_bytes, void *stream);
+
 /* ---- range gadgets, batched --------------------------------------------
  * pg_range_check_batch: for every witness i, in order,
  *     w = AllocatedScalar::allocate(composer, witness[i]);   src/allocated_scalar.rs:27

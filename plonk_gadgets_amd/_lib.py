@@ -64,6 +64,8 @@ SIGNATURES = {
     "pg_range_check_layout": (C.c_int, [_P(Scalar), _P(Scalar), C.c_uint64, _P(LayoutC)]),
     "pg_range_check_batch": (C.c_int, [C.c_void_p, _P(Scalar), _P(Scalar), C.c_void_p, C.c_uint64, C.c_uint64,
                                        C.c_uint64, _P(ColumnsC), C.c_void_p, C.c_void_p]),
+    "pg_scalars_from_canonical_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, _P(C.c_uint64), C.c_void_p]),
+    "pg_scalars_to_canonical_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "pg_range_check_structure_batch": (C.c_int, [C.c_void_p, _P(Scalar), _P(Scalar), C.c_uint64, C.c_uint64, C.c_uint64, _P(ColumnsC),
                                                  C.c_void_p]),
     "pg_range_check_allocated_batch": (C.c_int, [C.c_void_p, _P(Scalar), _P(Scalar), C.c_void_p, C.c_void_p, C.c_uint64,

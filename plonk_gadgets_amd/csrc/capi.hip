@@ -374,6 +374,41 @@ pg_status pg_engine_sync(pg_engine *e, void *stream) {
     return PG_OK;
 }
 
+/* ---- encodings, in bulk ---------------------------------------------------- */
+pg_status pg_scalars_from_canonical_batch(pg_engine *e, const void *d_bytes, uint64_t batch, pg_scalar *d_out, uint8_t *d_bad_mask,
+                                          uint64_t *bad_count, void *stream) {
+    if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
+    if (bad_count) *bad_count = 0;
+    if (batch == 0) return PG_OK;
+    PG_TRY(check_scalars(d_bytes, "d_bytes"));
+    PG_TRY(check_scalars(d_out, "d_out"));
+    PG_TRY(ensure_scratch(e, 1));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    PG_HIP_TRY(hipSetDevice(e->device));
+    PG_HIP_TRY(hipMemsetAsync(e->d_err_count, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(pg::from_canonical_kernel, dim3((uint32_t)((batch + pg::kThreads - 1) / pg::kThreads)), dim3(pg::kThreads), 0, st,
+                       static_cast<const uint4 *>(d_bytes), batch, reinterpret_cast<uint4 *>(d_out), d_bad_mask, e->d_err_count);
+    PG_HIP_TRY(hipGetLastError());
+    PG_HIP_TRY(hipMemcpyAsync(&e->h_plan->errs, e->d_err_count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    PG_HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t bad = e->h_plan->errs;
+    if (bad_count) *bad_count = bad;
+    if (bad) return fail(PG_ERR_INVALID_ARGUMENT, std::to_string(bad) + " encoding(s) are not below the modulus");
+    return PG_OK;
+}
+
+pg_status pg_scalars_to_canonical_batch(pg_engine *e, const pg_scalar *d_scalars, uint64_t batch, void *d_bytes, void *stream) {
+    if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
+    if (batch == 0) return PG_OK;
+    PG_TRY(check_scalars(d_scalars, "d_scalars"));
+    PG_TRY(check_scalars(d_bytes, "d_bytes"));
+    PG_HIP_TRY(hipSetDevice(e->device));
+    hipLaunchKernelGGL(pg::to_canonical_kernel, dim3((uint32_t)((batch + pg::kThreads - 1) / pg::kThreads)), dim3(pg::kThreads), 0,
+                       static_cast<hipStream_t>(stream), reinterpret_cast<const uint4 *>(d_scalars), batch, static_cast<uint4 *>(d_bytes));
+    PG_HIP_TRY(hipGetLastError());
+    return PG_OK;
+}
+
 /* ---- host scalar helpers ------------------------------------------------ */
 void pg_scalar_from_u64(uint64_t v, pg_scalar *out) { from_fr(pg::fr_from_u64(v), out); }
 void pg_scalar_from_canonical(const uint64_t raw[4], pg_scalar *out) {

@@ -294,6 +294,37 @@ __global__ __launch_bounds__(kThreads) void fill_oneshot_kernel(uint4 *dst, uint
         if (base + k * kThreads < n16) store16(dst + base + k * kThreads, v);
 }
 
+// ---- BlsScalar <-> its 32-byte little-endian canonical encoding, in bulk ----------------
+// (dusk-bytes Serializable: from_bytes rejects values >= q, to_bytes leaves Montgomery form; src/range.rs:162)
+__global__ __launch_bounds__(kThreads) void from_canonical_kernel(const uint4 *raw, uint64_t n, uint4 *out, uint8_t *bad_mask,
+                                                                 uint32_t *bad_count) {
+    const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    FrVec x;
+    x.v[0] = raw[2 * i];
+    x.v[1] = raw[2 * i + 1];
+    const Fr q = fr_modulus();
+    bool ge = true;  // x >= q ?
+    for (int k = 3; k >= 0; k--)
+        if (x.f.l[k] != q.l[k]) { ge = x.f.l[k] > q.l[k]; break; }
+    FrVec r;
+    r.f = ge ? fr_zero() : fr_to_mont(x.f);
+    out[2 * i] = r.v[0];
+    out[2 * i + 1] = r.v[1];
+    if (bad_mask) bad_mask[i] = ge ? 1 : 0;
+    if (ge) atomicAdd(bad_count, 1u);
+}
+__global__ __launch_bounds__(kThreads) void to_canonical_kernel(const uint4 *in, uint64_t n, uint4 *raw) {
+    const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    FrVec x, r;
+    x.v[0] = in[2 * i];
+    x.v[1] = in[2 * i + 1];
+    r.f = fr_from_mont(x.f);
+    raw[2 * i] = r.v[0];
+    raw[2 * i + 1] = r.v[1];
+}
+
 // ---- exclusive prefix sums for ragged batches ---------------------------
 // counts[i] (rows, vars of item i) -> off[i], off[batch] = total.  Three small
 // kernels: per-block sums, scan of the block sums (one block), final scan.

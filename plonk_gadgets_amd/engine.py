@@ -130,6 +130,29 @@ class Engine:
             raise PgError(st, "pg_range_check_batch")
         return out, result_vars
 
+    # ---- encodings ------------------------------------------------------------------
+    def scalars_from_canonical(self, raw: torch.Tensor):
+        """int64[batch, 4] canonical little-endian values (BlsScalar::to_bytes) -> (Montgomery limbs, bad mask, bad count);
+        values >= q come out as 0 and are flagged (BlsScalar::from_bytes would return Err)"""
+        assert raw.is_cuda and raw.dtype == torch.int64 and raw.dim() == 2 and raw.shape[1] == 4 and raw.is_contiguous()
+        out = torch.empty_like(raw)
+        bad = torch.zeros((raw.shape[0],), dtype=torch.uint8, device=raw.device)
+        n = C.c_uint64()
+        st = self._lib.pg_scalars_from_canonical_batch(self._h, raw.data_ptr(), raw.shape[0], out.data_ptr(), bad.data_ptr(),
+                                                       C.byref(n), self._stream())
+        if st not in (0, 2):
+            raise PgError(st, "pg_scalars_from_canonical_batch")
+        return out, bad, int(n.value)
+
+    def scalars_to_canonical(self, scalars: torch.Tensor) -> torch.Tensor:
+        assert scalars.is_cuda and scalars.dtype == torch.int64 and scalars.dim() == 2 and scalars.shape[1] == 4
+        assert scalars.is_contiguous()
+        out = torch.empty_like(scalars)
+        st = self._lib.pg_scalars_to_canonical_batch(self._h, scalars.data_ptr(), scalars.shape[0], out.data_ptr(), self._stream())
+        if st != 0:
+            raise PgError(st, "pg_scalars_to_canonical_batch")
+        return out
+
     def range_check_structure_batch(self, min_range: BlsScalar, max_range: BlsScalar, batch: int, gate_base: int,
                                     var_base: int, out: Columns):
         """selectors and wire indices of range_check_batch's rows -- no witnesses, `out.var_values` is left alone"""

@@ -672,3 +672,21 @@ def test_two_engines_on_two_streams():
             ora = po.scalar_mix_batch(*inp)
         assert_cols(got, ora)
         assert np.array_equal(u64(res).reshape(-1), np.asarray(ora["result_vars"]).reshape(-1)), kind
+
+
+def test_bulk_encodings(engine):
+    """BlsScalar::from_bytes / to_bytes over a batch, device to device: Montgomery limbs of the model, the round trip, and
+    the three encodings that are not below q flagged and zeroed"""
+    from oracle.model import Q, mont_limbs
+    ints = [0, 1, 2, Q - 1, 2**64, 2**128 + 5, 2**254, (Q - 1) // 2] + [int(x) for x in synth.splitmix64(300, 9)]
+    ints += [(7**k) % Q for k in range(1, 200, 3)]
+    raw = np.array([[(x >> (64 * i)) & (2**64 - 1) for i in range(4)] for x in ints], dtype=np.uint64)
+    out, bad, nbad = engine.scalars_from_canonical(dev(raw))
+    assert nbad == 0 and not bool(bad.any())
+    assert np.array_equal(u64(out), np.array([mont_limbs(x) for x in ints], dtype=np.uint64))
+    assert np.array_equal(u64(engine.scalars_to_canonical(out)), raw)
+    over = [Q, Q + 1, 2**256 - 1, Q - 1]
+    raw2 = np.array([[(x >> (64 * i)) & (2**64 - 1) for i in range(4)] for x in over], dtype=np.uint64)
+    out2, bad2, nbad2 = engine.scalars_from_canonical(dev(raw2))
+    assert nbad2 == 3 and bad2.cpu().numpy().tolist() == [1, 1, 1, 0]
+    assert np.array_equal(u64(out2)[:3], np.zeros((3, 4), dtype=np.uint64)) and u64(out2)[3].tolist() == mont_limbs(Q - 1)
