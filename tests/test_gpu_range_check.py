@@ -310,3 +310,29 @@ def test_structure_only_rows(engine):
         rows_only = pg.Columns.allocate(lay.n_gates, 0, "cuda:0")          # no variable table at all
         engine.range_check_structure_batch(pg.BlsScalar.from_int(mn), pg.BlsScalar.from_int(mx), batch, 1234, 56789, rows_only)
         assert torch.equal(rows_only.w_o, full.w_o) and torch.equal(rows_only.q_c, full.q_c)
+
+
+def test_host_pipeline(engine):
+    """chunks streamed to pinned host memory while the next chunk is emitted: every chunk the consumer sees equals the
+    oracle's rows for those items at their global numbering"""
+    import plonk_gadgets_amd as pg
+    from plonk_gadgets_amd.host_pipeline import HostPipeline
+    from oracle import pyoracle as po
+    mn, mx, total, chunk = 50_000, 250_000, 96, 16
+    wit = np.ascontiguousarray(mixed_witnesses(mn, mx, total, 5)[:total])
+    ora = po.range_check_fast(synth.mont(mn), synth.mont(mx), wit, threads=2, var_base=5)
+    G, V = 4 * ora["num_bits"] + 11, 2 * ora["num_bits"] + 524
+    pipe = HostPipeline(engine, pg.BlsScalar.from_int(mn), pg.BlsScalar.from_int(mx), chunk)
+    seen = []
+
+    def consume(cols, k, first):
+        assert first == k * chunk
+        for name in ("q_m", "q_l", "q_r", "q_o", "q_c"):
+            assert np.array_equal(getattr(cols, name).numpy().view(np.uint64), ora[name][first * G:(first + chunk) * G]), (k, name)
+        for name in ("w_l", "w_r", "w_o"):
+            assert np.array_equal(getattr(cols, name).numpy().view(np.uint64), ora[name][first * G:(first + chunk) * G]), (k, name)
+        assert np.array_equal(cols.var_values.numpy().view(np.uint64), ora["var_values"][first * V:(first + chunk) * V]), k
+        seen.append(k)
+
+    pipe.run(torch.from_numpy(wit.view(np.int64)).to("cuda:0"), 3, 5, consume=consume)
+    assert seen == list(range(total // chunk))
