@@ -30,3 +30,13 @@ def test_c_example_runs_on_gpu():
     print(p.stdout, p.stderr)
     assert p.returncode == 0 and p.stdout.strip().endswith("OK")
     assert "first unsatisfied row: -1" in p.stdout
+
+
+@pytest.mark.gpu
+def test_python_example_runs_on_gpu():
+    """examples/circuit_on_device.py: bulk decoding, a batched append, single calls, check, materialize, permutation"""
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "circuit_on_device.py"), "10"], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT)
+    print(p.stdout, p.stderr)
+    assert p.returncode == 0 and "prover-ready" in p.stdout
