@@ -1,0 +1,83 @@
+/* tests/cpp/oracle_sanitize.c -- the CPU oracle (the checker of every parity test) under -fsanitize=address,undefined:
+ * every batch driver, the fast threaded form, the full composer with sigma / dense PI, on small inputs.
+ * Built together with oracle/*.c and run by tests/test_fr_host_sanitizers.py. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gadgets.h"
+
+static uint64_t s = 0x2545F4914F6CDD1Dull;
+static uint64_t rnd(void) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+static fr_t rnd_fr(void) {
+    uint64_t raw[4] = {rnd(), rnd(), rnd(), rnd() % 0x73eda753299d7d48ull};
+    return fr_from_raw(raw);
+}
+
+static oracle_columns_t alloc_cols(size_t g, size_t v) {
+    oracle_columns_t c;
+    c.q_m = malloc(g * 32); c.q_l = malloc(g * 32); c.q_r = malloc(g * 32); c.q_o = malloc(g * 32); c.q_c = malloc(g * 32);
+    c.w_l = malloc(g * 8); c.w_r = malloc(g * 8); c.w_o = malloc(g * 8);
+    c.var_values = malloc(v * 32);
+    return c;
+}
+static void free_cols(oracle_columns_t *c) {
+    free(c->q_m); free(c->q_l); free(c->q_r); free(c->q_o); free(c->q_c); free(c->w_l); free(c->w_r); free(c->w_o); free(c->var_values);
+}
+
+int main(void) {
+    enum { B = 24 };
+    fr_t wit[B], bounds[B], v[B], y[B], sel[B], a[B], b[B];
+    for (int i = 0; i < B; i++) {
+        wit[i] = i % 3 ? fr_from_u64(40000 + 9000 * (uint64_t)i) : rnd_fr();
+        bounds[i] = fr_from_u64(1 + (rnd() >> (rnd() % 60)));
+        v[i] = i == 5 ? fr_from_u64(0) : rnd_fr();
+        y[i] = rnd_fr(); sel[i] = fr_from_u64(i & 1); a[i] = rnd_fr(); b[i] = i % 2 ? a[i] : rnd_fr();
+    }
+    uint64_t gb, vb, ng, nv, res[2 * B], nbits[B];
+    uint8_t err[B];
+    const fr_t mn = fr_from_u64(50000), mx = fr_from_u64(250000);
+    /* range_check: sizes from a dry run, then with output */
+    if (oracle_range_check_batch(mn, mx, wit, B, 1, NULL, NULL, &gb, &vb, &ng, &nv)) return 1;
+    oracle_columns_t c = alloc_cols(ng, nv), f = alloc_cols(ng, nv);
+    if (oracle_range_check_batch(mn, mx, wit, B, 1, &c, res, &gb, &vb, &ng, &nv)) return 2;
+    if (oracle_range_check_fast(mn, mx, wit, B, vb, 3, &f, res + B)) return 3;
+    if (memcmp(c.q_c, f.q_c, ng * 32) || memcmp(c.w_o, f.w_o, ng * 8) || memcmp(c.var_values, f.var_values, nv * 32) ||
+        memcmp(res, res + B, B * 8)) return 4;
+    free_cols(&c); free_cols(&f);
+    if (oracle_max_bound_batch(bounds, wit, B, 1, NULL, NULL, NULL, &gb, &vb, &ng, &nv)) return 5;
+    c = alloc_cols(ng, nv);
+    if (oracle_max_bound_batch(bounds, wit, B, 1, &c, res, nbits, &gb, &vb, &ng, &nv)) return 6;
+    free_cols(&c);
+    oracle_scalar_mix_batch(v, y, sel, a, b, B, 0, NULL, NULL, NULL, &gb, &vb, &ng, &nv);
+    c = alloc_cols(ng, nv);
+    oracle_scalar_mix_batch(v, y, sel, a, b, B, 0, &c, res, err, &gb, &vb, &ng, &nv);
+    if (err[5] != 1) return 7;
+    free_cols(&c);
+    /* one composer with everything, then sigma and the dense public inputs */
+    composer_t *cs = composer_new();
+    const fr_t pi = fr_from_u64(11);
+    var_t x = composer_add_input(cs, fr_from_u64(9));
+    var_t r = range_check(cs, mn, mx, allocated_scalar_allocate(cs, fr_from_u64(60000)));
+    if (is_non_zero(cs, x, fr_from_u64(9)) != GADGET_OK) return 8;
+    var_t yv = conditionally_select_one(cs, x, r);
+    composer_constrain_to_constant(cs, yv, fr_from_u64(20), &pi);
+    var_t m = maybe_equal(cs, allocated_scalar_allocate(cs, fr_from_u64(5)), allocated_scalar_allocate(cs, fr_from_u64(5)));
+    (void)conditionally_select_zero(cs, m, r);
+    (void)scalar_decomposition_gadget(cs, 9, allocated_scalar_allocate(cs, fr_from_u64(300)), NULL);
+    (void)composer_boolean_gate(cs, m);
+    if (composer_check(cs) != -1) return 9;
+    const size_t n = composer_circuit_size(cs);
+    size_t padded = 1;
+    while (padded < n) padded <<= 1;
+    uint64_t *sigma = malloc(4 * padded * 8);
+    fr_t *dense = malloc(n * 32);
+    composer_sigma(cs, padded, sigma);
+    composer_dense_pi(cs, dense);
+    uint64_t acc = 0;
+    for (size_t i = 0; i < 4 * padded; i++) acc ^= sigma[i] ^ i;   /* a permutation of 0..4*padded-1 */
+    free(sigma); free(dense);
+    composer_free(cs);
+    printf("oracle under sanitizers: ok (%zu rows, xor %llu)\n", n, (unsigned long long)acc);
+    return acc != 0;
+}

@@ -13,3 +13,15 @@ def test_field_arithmetic_under_sanitizers(tmp_path):
                            "-o", exe])
     p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "bad = 0" in p.stdout, p.stdout + p.stderr
+
+
+def test_oracle_under_sanitizers(tmp_path):
+    """the checker itself: oracle/*.c with a driver that runs every batch driver, the threaded fast form and a full
+    composer (sigma, dense PI) under ASan + UBSan"""
+    exe = str(tmp_path / "oracle_sanitize")
+    ora = os.path.join(ROOT, "oracle")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", ora,
+                           os.path.join(ROOT, "tests", "cpp", "oracle_sanitize.c")] +
+                          [os.path.join(ora, f) for f in ("fr.c", "composer.c", "gadgets.c", "fast.c")] + ["-lpthread", "-o", exe])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "oracle under sanitizers: ok" in p.stdout, p.stdout + p.stderr
