@@ -797,3 +797,38 @@ def test_fuzz_composer_programs(engine, seed):
         assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded))
     except AssertionError as e:
         raise AssertionError(f"seed {seed}, program {log}: {e}")
+
+
+def test_two_host_threads_two_composers():
+    """one engine + composer per host thread (ctypes releases the GIL during the calls): both threads build the golden
+    circuit twenty times over, each result equals the fixture"""
+    import os
+    import threading
+    from tests.refcases import full_circuit
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "composer_full.npz")))
+    padded = int(g["padded_n"][0])
+    failures = []
+
+    def work(tid):
+        try:
+            eng = pg.Engine(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for it in range(20):
+                    dev = pg.StandardComposer(eng, gate_capacity=64, var_capacity=64)
+                    dev.auto_grow()
+                    full_circuit(DeviceOps(dev, batched=(it + tid) % 2 == 0))
+                    exp = dev.export()
+                    for k in COLS:
+                        assert np.array_equal(exp[k], g[k]), (tid, it, k)
+                    assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64).reshape(-1), g["sigma"]), (tid, it)
+                    assert dev.check() == -1
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            import traceback
+            failures.append(traceback.format_exc())
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not failures, failures[0]
