@@ -341,6 +341,23 @@ pg_status pg_composer_conditionally_select_one_batch(pg_composer *c, const pg_va
 pg_status pg_composer_maybe_equal_batch(pg_composer *c, const pg_variable *d_a_var, const pg_variable *d_b_var, uint64_t batch,
                                         pg_variable *d_result_vars);
 
+/* the composer's gate calls over device arrays of Variables, one set of selectors for the whole batch (no public
+ * inputs): the loops
+ *   poly_gate:             for i { composer.poly_gate(a[i], b[i], c[i], q_m, q_l, q_r, q_o, q_c, None) }
+ *   add / mul:             for i { out[i] = composer.add((q_l, a[i]), (q_r, b[i]), q_c, None) }  /  mul(q_m, a[i], b[i], q_c, None)
+ *   constrain_to_constant: for i { composer.constrain_to_constant(a[i], constant, None) }
+ *   boolean_gate:          for i { composer.boolean_gate(a[i]) }
+ * every index must be a Variable of this composer (as the reference panics on an unknown one; not checked here). */
+pg_status pg_composer_poly_gate_batch(pg_composer *c, const pg_variable *d_a, const pg_variable *d_b, const pg_variable *d_c,
+                                      const pg_scalar *q_m, const pg_scalar *q_l, const pg_scalar *q_r, const pg_scalar *q_o,
+                                      const pg_scalar *q_c, uint64_t batch);
+pg_status pg_composer_add_batch(pg_composer *c, const pg_scalar *q_l, const pg_variable *d_a, const pg_scalar *q_r,
+                                const pg_variable *d_b, const pg_scalar *q_c, uint64_t batch, pg_variable *d_out_vars);
+pg_status pg_composer_mul_batch(pg_composer *c, const pg_scalar *q_m, const pg_variable *d_a, const pg_variable *d_b,
+                                const pg_scalar *q_c, uint64_t batch, pg_variable *d_out_vars);
+pg_status pg_composer_constrain_to_constant_batch(pg_composer *c, const pg_variable *d_a, const pg_scalar *constant, uint64_t batch);
+pg_status pg_composer_boolean_gate_batch(pg_composer *c, const pg_variable *d_a, uint64_t batch);
+
 /* ragged batched appends: the composer plans the call itself (one host synchronisation for the totals), keeps the
  * per-item offsets for the permutation, and emits.
  *   max_bound_ragged: for i { allocate(d_witness[i]); max_bound(composer, d_max_range[i], w) } -- one public bound per

@@ -143,6 +143,12 @@ SIGNATURES = {
     "pg_composer_is_non_zero_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, _P(C.c_uint64)]),
     "pg_composer_scalar_mix_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                                C.c_void_p, C.c_void_p, _P(C.c_uint64)]),
+    "pg_composer_poly_gate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(Scalar), _P(Scalar), _P(Scalar),
+                                              _P(Scalar), _P(Scalar), C.c_uint64]),
+    "pg_composer_add_batch": (C.c_int, [C.c_void_p, _P(Scalar), C.c_void_p, _P(Scalar), C.c_void_p, _P(Scalar), C.c_uint64, C.c_void_p]),
+    "pg_composer_mul_batch": (C.c_int, [C.c_void_p, _P(Scalar), C.c_void_p, C.c_void_p, _P(Scalar), C.c_uint64, C.c_void_p]),
+    "pg_composer_constrain_to_constant_batch": (C.c_int, [C.c_void_p, C.c_void_p, _P(Scalar), C.c_uint64]),
+    "pg_composer_boolean_gate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "pg_composer_copy_out": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _P(ColumnsC)]),
     "pg_composer_read_value": (C.c_int, [C.c_void_p, C.c_uint64, _P(Scalar)]),
     "pg_composer_check": (C.c_int, [C.c_void_p, _P(C.c_int64)]),

@@ -231,6 +231,38 @@ class StandardComposer:
             _chk(st, "pg_composer_scalar_mix_batch")
         return res, err, int(nerr.value)
 
+    # -- the gate calls over arrays of Variables (one set of selectors per batch, no public inputs) --------------------
+    def _vars(self, *ts):
+        for t in ts:
+            assert t.is_cuda and t.dtype == torch.int64 and t.dim() == 1 and t.is_contiguous() and t.shape == ts[0].shape
+        return ts[0].shape[0]
+
+    def poly_gate_batch(self, a, b, c, q_m, q_l, q_r, q_o, q_c):
+        n = self._vars(a, b, c)
+        _chk(self._lib.pg_composer_poly_gate_batch(self._h, a.data_ptr(), b.data_ptr(), c.data_ptr(), C.byref(q_m.c), C.byref(q_l.c),
+                                                   C.byref(q_r.c), C.byref(q_o.c), C.byref(q_c.c), n), "pg_composer_poly_gate_batch")
+
+    def add_batch(self, q_l: BlsScalar, a, q_r: BlsScalar, b, q_c: BlsScalar) -> torch.Tensor:
+        n = self._vars(a, b)
+        out = torch.empty_like(a)
+        _chk(self._lib.pg_composer_add_batch(self._h, C.byref(q_l.c), a.data_ptr(), C.byref(q_r.c), b.data_ptr(), C.byref(q_c.c), n,
+                                             out.data_ptr()), "pg_composer_add_batch")
+        return out
+
+    def mul_batch(self, q_m: BlsScalar, a, b, q_c: BlsScalar) -> torch.Tensor:
+        n = self._vars(a, b)
+        out = torch.empty_like(a)
+        _chk(self._lib.pg_composer_mul_batch(self._h, C.byref(q_m.c), a.data_ptr(), b.data_ptr(), C.byref(q_c.c), n, out.data_ptr()),
+             "pg_composer_mul_batch")
+        return out
+
+    def constrain_to_constant_batch(self, a, constant: BlsScalar):
+        _chk(self._lib.pg_composer_constrain_to_constant_batch(self._h, a.data_ptr(), C.byref(constant.c), self._vars(a)),
+             "pg_composer_constrain_to_constant_batch")
+
+    def boolean_gate_batch(self, a):
+        _chk(self._lib.pg_composer_boolean_gate_batch(self._h, a.data_ptr(), self._vars(a)), "pg_composer_boolean_gate_batch")
+
     # -- read-back ----------------------------------------------------------------------------------------
     def value(self, v: Variable) -> BlsScalar:
         out = _lib.Scalar()

@@ -67,6 +67,42 @@ __global__ void gate_kernel(const GateCmd cmd, const ComposerCols C) {
     C.w[2][cmd.gate] = out;
 }
 
+// the same calls over device arrays of Variables with one set of selectors: item i writes row gate0 + i; OP_ADD / OP_MUL
+// also create Variable var0 + i = q_l a + q_r b + q_c  /  q_m a b + q_c (read from the composer's own table) on the
+// output wire.  c may be NULL for OP_ADD / OP_MUL.
+struct GateBatch {
+    uint32_t op;
+    uint32_t pad;
+    uint64_t gate0, var0, batch;
+    const uint64_t *a, *b, *c;
+    uint64_t *out_vars;  // OP_ADD / OP_MUL: the new Variables (may be NULL)
+    Fr q_m, q_l, q_r, q_o, q_c;
+};
+__global__ __launch_bounds__(kThreads) void gate_batch_kernel(const GateBatch B, const ComposerCols C) {
+    FrVec q[5];
+    q[0].f = B.q_m; q[1].f = B.q_l; q[2].f = B.q_r; q[3].f = B.q_o; q[4].f = B.q_c;
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < B.batch; i += (uint64_t)gridDim.x * kThreads) {
+        const uint64_t a = B.a[i], b = B.b[i], g = B.gate0 + i;
+        uint64_t out = B.c ? B.c[i] : 0;
+        if (B.op == OP_ADD || B.op == OP_MUL) {
+            const Fr va = get_fr(C.vars, a), vb = get_fr(C.vars, b);
+            const Fr v = B.op == OP_ADD ? fr_add(fr_add(fr_mul(B.q_l, va), fr_mul(B.q_r, vb)), B.q_c)
+                                        : fr_add(fr_mul(fr_mul(B.q_m, va), vb), B.q_c);
+            out = B.var0 + i;
+            put_fr(C.vars, out, v);
+            if (B.out_vars) B.out_vars[i] = out;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            C.q[k][2 * g] = q[k].v[0];
+            C.q[k][2 * g + 1] = q[k].v[1];
+        }
+        C.w[0][g] = a;
+        C.w[1][g] = b;
+        C.w[2][g] = out;
+    }
+}
+
 // small host blob -> device staging buffer (inputs of single-gadget calls: scalars, Variables, offsets)
 struct StageBlob {
     uint64_t w[40];

@@ -703,9 +703,9 @@ def test_fuzz_composer_programs(engine, seed):
         nv = dev.num_variables()
         assert nv == ora.num_vars
         op = rng.choice(["add_input", "rc", "rc_alloc", "mb", "mb_alloc", "mb_ragged", "dec", "sel0", "sel1", "meq", "inz", "mix",
-                         "bool", "single_sel0", "ctc", "alloc_batch"])
+                         "bool", "single_sel0", "ctc", "alloc_batch", "poly_b", "add_b", "mul_b", "ctc_b", "bool_b"])
         k = rng.randrange(1, 40)
-        if seed > 100 and op in ("sel0", "sel1", "meq", "inz", "mix", "alloc_batch"):
+        if seed > 100 and op in ("sel0", "sel1", "meq", "inz", "mix", "alloc_batch", "poly_b", "add_b", "mul_b", "ctc_b", "bool_b"):
             k = rng.randrange(400, 2500)  # small items by the thousand: many groups per segment, a shorter last group
         old = [rng.randrange(nv) for _ in range(k)]
         old2 = [rng.randrange(nv) for _ in range(k)]
@@ -780,6 +780,30 @@ def test_fuzz_composer_programs(engine, seed):
                 oe.append(int(ora.L.is_non_zero(ora.c, vv, po.fr(v[i]))))
                 o.append([int(ora.L.conditionally_select_one(ora.c, yy, ss)), int(ora.L.maybe_equal(ora.c, aa, bb))])
             assert r.cpu().numpy().view(np.uint64).tolist() == o and err.cpu().numpy().tolist() == oe
+        elif op == "poly_b":
+            old3 = [rng.randrange(nv) for _ in range(k)]
+            q = [rng.choice([0, 1, po_Q - 1, rng.randrange(po_Q)]) for _ in range(5)]
+            dev.poly_gate_batch(tv(old), tv(old2), tv(old3), *[S(x) for x in q])
+            for a, b, c3 in zip(old, old2, old3):
+                ora.L.composer_poly_gate(ora.c, a, b, c3, *[F(x) for x in q], None)
+        elif op in ("add_b", "mul_b"):
+            q1, q2, q3 = (rng.choice([1, po_Q - 1, rng.randrange(po_Q)]) for _ in range(3))
+            if op == "add_b":
+                r = dev.add_batch(S(q1), tv(old), S(q2), tv(old2), S(q3))
+                o = [ora.L.composer_add(ora.c, F(q1), a, F(q2), b, F(q3), None) for a, b in zip(old, old2)]
+            else:
+                r = dev.mul_batch(S(q1), tv(old), tv(old2), S(q3))
+                o = [ora.L.composer_mul(ora.c, F(q1), a, b, F(q3), None) for a, b in zip(old, old2)]
+            assert r.cpu().numpy().view(np.uint64).tolist() == [int(x) for x in o]
+        elif op == "ctc_b":
+            x = rng.randrange(po_Q)
+            dev.constrain_to_constant_batch(tv(old), S(x))
+            for a in old:
+                ora.L.composer_constrain_to_constant(ora.c, a, F(x), None)
+        elif op == "bool_b":
+            dev.boolean_gate_batch(tv(old))
+            for a in old:
+                ora.L.composer_boolean_gate(ora.c, a)
         elif op == "bool":
             dev.boolean_gate(old[0])
             ora.L.composer_boolean_gate(ora.c, old[0])
