@@ -236,6 +236,25 @@ inline Result is_non_zero(StandardComposer &c, const pg_variable *d_var, uint64_
     pg_throw(st, "Batched::is_non_zero");
     return Result{};
 }
+// the composer's own gate calls over arrays of Variables, one set of selectors per batch
+inline void poly_gate(StandardComposer &c, const pg_variable *d_a, const pg_variable *d_b, const pg_variable *d_c, const BlsScalar &q_m,
+                      const BlsScalar &q_l, const BlsScalar &q_r, const BlsScalar &q_o, const BlsScalar &q_c, uint64_t batch) {
+    pg_throw(pg_composer_poly_gate_batch(c.h, d_a, d_b, d_c, &q_m.s, &q_l.s, &q_r.s, &q_o.s, &q_c.s, batch), "Batched::poly_gate");
+}
+inline void add(StandardComposer &c, const BlsScalar &q_l, const pg_variable *d_a, const BlsScalar &q_r, const pg_variable *d_b,
+                const BlsScalar &q_c, uint64_t batch, pg_variable *d_out_vars) {
+    pg_throw(pg_composer_add_batch(c.h, &q_l.s, d_a, &q_r.s, d_b, &q_c.s, batch, d_out_vars), "Batched::add");
+}
+inline void mul(StandardComposer &c, const BlsScalar &q_m, const pg_variable *d_a, const pg_variable *d_b, const BlsScalar &q_c,
+                uint64_t batch, pg_variable *d_out_vars) {
+    pg_throw(pg_composer_mul_batch(c.h, &q_m.s, d_a, d_b, &q_c.s, batch, d_out_vars), "Batched::mul");
+}
+inline void constrain_to_constant(StandardComposer &c, const pg_variable *d_a, const BlsScalar &constant, uint64_t batch) {
+    pg_throw(pg_composer_constrain_to_constant_batch(c.h, d_a, &constant.s, batch), "Batched::constrain_to_constant");
+}
+inline void boolean_gate(StandardComposer &c, const pg_variable *d_a, uint64_t batch) {
+    pg_throw(pg_composer_boolean_gate_batch(c.h, d_a, batch), "Batched::boolean_gate");
+}
 }  // namespace Batched
 
 namespace RangeGadgets {

@@ -381,6 +381,8 @@ static void batched_appends_equal_loops(Engine &e) {
     const uint64_t nb = Batched::max_bound_allocated(a, bound, d_wv, d_wit, batch, d_res2);
     Batched::conditionally_select_one(a, d_wv, d_sv, batch, nullptr);
     Batched::maybe_equal(a, d_res, d_res2, batch, nullptr);
+    Batched::constrain_to_constant(a, d_res2, BlsScalar::one(), batch);
+    Batched::boolean_gate(a, d_res, batch);
     uint64_t errs = 0;
     CHECK(Batched::is_non_zero(a, d_wv, batch, nullptr, &errs).is_ok() && errs == 0);
     CHECK(Batched::is_non_zero(a, d_sv, batch, nullptr, &errs).is_err() && errs == (batch + 1) / 2);
@@ -403,6 +405,8 @@ static void batched_appends_equal_loops(Engine &e) {
     for (uint64_t i = 0; i < batch; i++) conditionally_select_one(b, aw[i].var, as[i].var);
     for (uint64_t i = 0; i < batch; i++)
         maybe_equal(b, AllocatedScalar{r1[i], b.value(r1[i])}, AllocatedScalar{r2[i], b.value(r2[i])});
+    for (uint64_t i = 0; i < batch; i++) b.constrain_to_constant(r2[i], BlsScalar::one(), std::nullopt);
+    for (uint64_t i = 0; i < batch; i++) b.boolean_gate(r1[i]);
     for (uint64_t i = 0; i < batch; i++) CHECK(is_non_zero(b, aw[i].var, aw[i].scalar).is_ok());
     uint64_t loop_errs = 0;
     for (uint64_t i = 0; i < batch; i++) loop_errs += is_non_zero(b, as[i].var, as[i].scalar).is_err();
