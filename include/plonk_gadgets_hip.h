@@ -414,6 +414,61 @@ pg_status pg_composer_permutation(pg_composer *c, uint64_t padded_n, uint64_t *d
 pg_status pg_check_rows(pg_engine *e, const pg_columns *cols, uint64_t n_gates, uint64_t var_base, uint64_t n_vars,
                         pg_variable zero_var, int64_t *first_bad, void *stream);
 
+/* ---- multi-GPU: shards, packed chunks, the all-gather (BASELINE.json config 5) -------------
+ * The reference has no counterpart: it is single-threaded (`&mut StandardComposer`, src/range.rs:27-32).  What is
+ * sharded is the loop  for w in witnesses { allocate; range_check }  of tests/range_gadgets_tests.rs:29-44: items are
+ * independent and item i owns rows [gate_base + i*G, +G) and variables [var_base + i*V, +V), so rank r of P emits its
+ * contiguous range [lo, hi) straight at its final global numbering -- no exchange is needed to place anything.  One
+ * process per GPU; the host (the Rust host of north_star, or Python) calls the same entry points on every rank. */
+typedef struct pg_shard {
+    uint32_t rank, world;
+    uint64_t lo, hi;              /* this rank's items of the whole batch: [lo, hi); the first total % world ranks get one more */
+    uint64_t gate_base, var_base; /* global number of the shard's first row / first variable */
+    uint64_t n_gates, n_vars;     /* rows / variables the shard emits */
+} pg_shard;
+pg_status pg_shard_range(uint64_t total, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi);
+pg_status pg_range_check_shard_layout(const pg_scalar *min_range, const pg_scalar *max_range, uint64_t total, uint32_t rank,
+                                      uint32_t world, uint64_t gate_base, uint64_t var_base, pg_shard *out);
+/* pg_range_check_batch on this rank's shard of a `total`-item batch whose first row / variable are (gate_base,
+ * var_base): d_witness_local holds the hi - lo witnesses of the shard, `out` buffers sized by the shard layout.
+ * No communication.  `shard` (may be NULL) receives the placement. */
+pg_status pg_range_check_sharded_batch(pg_engine *e, const pg_scalar *min_range, const pg_scalar *max_range,
+                                       const pg_scalar *d_witness_local, uint64_t total, uint32_t rank, uint32_t world,
+                                       uint64_t gate_base, uint64_t var_base, const pg_columns *out,
+                                       pg_variable *d_result_vars /* may be NULL */, pg_shard *shard, void *stream);
+
+/* A packed chunk: the nine arrays of one call back to back in ONE buffer (offsets in 8-byte words, every section
+ * 16-byte aligned), so that a chunk is a single collective.  pg_columns_in_packed gives the pg_columns view to emit into. */
+typedef struct pg_packed {
+    uint64_t q_words[5], w_words[3], var_words; /* offsets of q_m..q_c, w_l..w_o, var_values */
+    uint64_t total_words, n_gates, n_vars;
+} pg_packed;
+pg_status pg_packed_layout(uint64_t n_gates, uint64_t n_vars, pg_packed *out);
+pg_status pg_columns_in_packed(void *d_packed, uint64_t n_gates, uint64_t n_vars, pg_columns *out);
+
+/* The communicator: RCCL over xGMI, bound at run time (dlsym in the process, then dlopen of librccl.so.1; PG_RCCL_LIB
+ * overrides) -- the library itself does not link RCCL.  Rank 0 calls pg_comm_unique_id and hands the 128 bytes to the
+ * other ranks out of band (the host's own channel: a file, a socket, MPI, torch.distributed); every rank then calls
+ * pg_comm_create with the same id (collective: returns when all `world` ranks have joined).  A host that already owns
+ * an ncclComm_t passes it to pg_comm_adopt instead (not destroyed by pg_comm_destroy). */
+#define PG_COMM_ID_BYTES 128
+typedef struct pg_comm pg_comm;
+pg_status pg_comm_unique_id(uint8_t id[PG_COMM_ID_BYTES]);
+pg_status pg_comm_create(pg_engine *e, const uint8_t id[PG_COMM_ID_BYTES], uint32_t rank, uint32_t world, pg_comm **out);
+pg_status pg_comm_adopt(pg_engine *e, void *nccl_comm, pg_comm **out);
+void pg_comm_destroy(pg_comm *c);
+uint32_t pg_comm_rank(const pg_comm *c);
+uint32_t pg_comm_world(const pg_comm *c);
+/* "a single RCCL all-gather of the emitted gate columns" (north_star), enqueued on `stream` after the emission:
+ *   pg_allgather_bytes    d_recv[r * bytes_per_rank ..] = rank r's d_send (one ncclAllGather; a packed chunk, a variable
+ *                         table, or the 16 bytes of (rows, variables) totals a ragged sharded batch exchanges);
+ *   pg_allgather_columns  the nine arrays of equal-sized shards, one grouped launch; rank order == witness order, so
+ *                         every gathered column is the whole batch's column (n_gates / n_vars: per rank). */
+pg_status pg_allgather_bytes(pg_comm *c, const void *d_send, void *d_recv, uint64_t bytes_per_rank /* multiple of 8 */,
+                             void *stream);
+pg_status pg_allgather_columns(pg_comm *c, const pg_columns *local, uint64_t n_gates, uint64_t n_vars,
+                               const pg_columns *gathered, void *stream);
+
 /* ---- diagnostics ----------------------------------------------------------
  * pg_fill_bytes: a bare streaming fill (16 B per lane, same store form as the emitters) that bench.py times on the same
  * box as a comparison point.  streams = 1..16: the buffer is written as that many equal parts

@@ -37,6 +37,16 @@ class FullColumnsC(C.Structure):
                                           "w_4_value")]
 
 
+class ShardC(C.Structure):
+    _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32)] + [(n, C.c_uint64) for n in
+                                                                 ("lo", "hi", "gate_base", "var_base", "n_gates", "n_vars")]
+
+
+class PackedC(C.Structure):
+    _fields_ = [("q_words", C.c_uint64 * 5), ("w_words", C.c_uint64 * 3), ("var_words", C.c_uint64),
+                ("total_words", C.c_uint64), ("n_gates", C.c_uint64), ("n_vars", C.c_uint64)]
+
+
 class LayoutC(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("num_bits", "gates_per_item", "vars_per_item", "n_gates", "n_vars")]
 
@@ -157,6 +167,21 @@ SIGNATURES = {
     "pg_composer_permutation": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     "pg_check_rows": (C.c_int, [C.c_void_p, _P(ColumnsC), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _P(C.c_int64),
                                 C.c_void_p]),
+    "pg_shard_range": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, _P(C.c_uint64), _P(C.c_uint64)]),
+    "pg_range_check_shard_layout": (C.c_int, [_P(Scalar), _P(Scalar), C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
+                                              _P(ShardC)]),
+    "pg_range_check_sharded_batch": (C.c_int, [C.c_void_p, _P(Scalar), _P(Scalar), C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
+                                               C.c_uint64, C.c_uint64, _P(ColumnsC), C.c_void_p, _P(ShardC), C.c_void_p]),
+    "pg_packed_layout": (C.c_int, [C.c_uint64, C.c_uint64, _P(PackedC)]),
+    "pg_columns_in_packed": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, _P(ColumnsC)]),
+    "pg_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "pg_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _P(C.c_void_p)]),
+    "pg_comm_adopt": (C.c_int, [C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
+    "pg_comm_destroy": (None, [C.c_void_p]),
+    "pg_comm_rank": (C.c_uint32, [C.c_void_p]),
+    "pg_comm_world": (C.c_uint32, [C.c_void_p]),
+    "pg_allgather_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "pg_allgather_columns": (C.c_int, [C.c_void_p, _P(ColumnsC), C.c_uint64, C.c_uint64, _P(ColumnsC), C.c_void_p]),
     "pg_fill_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]),
     "pg_scalar_mix_batch": (C.c_int, [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                                           C.c_uint64, _P(ColumnsC), C.c_void_p, C.c_void_p]),

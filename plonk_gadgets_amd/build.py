@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libplonk_gadgets_hip.so")
 SOURCES = ["capi.hip"]
 HEADERS = ["fr.hpp", "emit.hpp", "invert.hpp", "range_gadgets.hpp", "scalar_gadgets.hpp", "composer.hpp", "permutation.hpp",
-           "capi_composer.inc"]
+           "capi_composer.inc", "capi_dist.inc"]
 
 
 def hipcc() -> str:
@@ -33,8 +33,8 @@ def build(force: bool = False, extra_flags: list[str] | None = None, out: str | 
     out = out or LIB
     if not force and out == LIB and not is_stale():
         return out
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", out] + [os.path.join(CSRC, s) for s in SOURCES] + (extra_flags or [])
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-I/opt/rocm/include",
+           "-o", out] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"] + (extra_flags or [])
     subprocess.check_call(cmd)
     return out
 

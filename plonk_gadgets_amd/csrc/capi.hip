@@ -778,3 +778,4 @@ pg_status pg_fill_bytes(pg_engine *e, void *d_dst, uint64_t bytes, uint32_t stre
 }  // extern "C"
 
 #include "capi_composer.inc"
+#include "capi_dist.inc"

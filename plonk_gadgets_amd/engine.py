@@ -130,6 +130,30 @@ class Engine:
             raise PgError(st, "pg_range_check_batch")
         return out, result_vars
 
+    def range_check_sharded_batch(self, min_range: BlsScalar, max_range: BlsScalar, witness_local: torch.Tensor, total: int,
+                                  rank: int, world: int, gate_base: int = 0, var_base: int = 0, out: Columns | None = None,
+                                  result_vars: torch.Tensor | None = None):
+        """this rank's shard of a `total`-item range_check batch, emitted at its global numbering
+        (pg_range_check_sharded_batch; no communication).  Returns (Columns, result_vars)."""
+        self._check_scalars(witness_local)
+        shard = _lib.ShardC()
+        st = self._lib.pg_range_check_shard_layout(C.byref(min_range.c), C.byref(max_range.c), total, rank, world, gate_base,
+                                                   var_base, C.byref(shard))
+        if st != 0:
+            raise PgError(st, "pg_range_check_shard_layout")
+        assert witness_local.shape[0] == shard.hi - shard.lo, (witness_local.shape, shard.lo, shard.hi)
+        if out is None:
+            out = Columns.allocate(shard.n_gates, shard.n_vars, self.device, shard.gate_base, shard.var_base)
+        if result_vars is None:
+            result_vars = torch.empty((witness_local.shape[0],), dtype=torch.int64, device=self.device)
+        cols = out.as_c()
+        st = self._lib.pg_range_check_sharded_batch(self._h, C.byref(min_range.c), C.byref(max_range.c), witness_local.data_ptr(),
+                                                    total, rank, world, gate_base, var_base, C.byref(cols),
+                                                    result_vars.data_ptr(), C.byref(shard), self._stream())
+        if st != 0:
+            raise PgError(st, "pg_range_check_sharded_batch")
+        return out, result_vars
+
     # ---- encodings ------------------------------------------------------------------
     def scalars_from_canonical(self, raw: torch.Tensor):
         """int64[batch, 4] canonical little-endian values (BlsScalar::to_bytes) -> (Montgomery limbs, bad mask, bad count);

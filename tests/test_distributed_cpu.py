@@ -236,3 +236,61 @@ def test_packed_layout_alignment():
         cols = pd.columns_in(flat, ng, nv)
         assert cols.q_m.shape == (ng, 4) and cols.w_o.shape == (ng,) and cols.var_values.shape == (nv, 4)
         assert cols.var_values.data_ptr() - flat.data_ptr() == off["var_values"] * 8
+
+
+def test_shard_entry_points_of_the_c_abi():
+    """pg_shard_range / pg_range_check_shard_layout / pg_columns_in_packed: host arithmetic, callable without a GPU"""
+    import ctypes as C
+    import plonk_gadgets_amd as pg
+    from plonk_gadgets_amd import _lib
+    lib = _lib.load()
+    lo, hi = C.c_uint64(), C.c_uint64()
+    assert lib.pg_shard_range(10, 3, 3, C.byref(lo), C.byref(hi)) == 2  # rank >= world
+    assert lib.pg_shard_range(10, 0, 0, C.byref(lo), C.byref(hi)) == 2
+    assert lib.pg_shard_range(10, 2, 3, C.byref(lo), C.byref(hi)) == 0 and (lo.value, hi.value) == (7, 10)
+    mn, mx = pg.BlsScalar.from_int(0), pg.BlsScalar.from_int(2**254)
+    s = _lib.ShardC()
+    # BASELINE config 5: 2^23 witnesses over 8 ranks, rank 5
+    assert lib.pg_range_check_shard_layout(C.byref(mn.c), C.byref(mx.c), 1 << 23, 5, 8, 3, 5, C.byref(s)) == 0
+    assert (s.lo, s.hi) == (5 << 20, 6 << 20)
+    assert (s.gate_base, s.var_base) == (3 + (5 << 20) * 1031, 5 + (5 << 20) * 1034)
+    assert (s.n_gates, s.n_vars) == (1031 << 20, 1034 << 20)
+    # the shards of all ranks tile the whole batch's numbering
+    ends = []
+    for r in range(3):
+        assert lib.pg_range_check_shard_layout(C.byref(mn.c), C.byref(mx.c), 10, r, 3, 3, 5, C.byref(s)) == 0
+        ends.append((s.gate_base, s.gate_base + s.n_gates, s.var_base, s.var_base + s.n_vars))
+    assert ends[0][0] == 3 and ends[0][1] == ends[1][0] and ends[1][1] == ends[2][0] and ends[2][1] == 3 + 10 * 1031
+    assert ends[0][2] == 5 and ends[0][3] == ends[1][2] and ends[1][3] == ends[2][2] and ends[2][3] == 5 + 10 * 1034
+    # packed view: pointer arithmetic only
+    buf = torch.zeros(4096, dtype=torch.int64)
+    p, cc = _lib.PackedC(), _lib.ColumnsC()
+    assert lib.pg_packed_layout(7, 9, C.byref(p)) == 0
+    assert lib.pg_columns_in_packed(buf.data_ptr(), 7, 9, C.byref(cc)) == 0
+    assert cc.q_m == buf.data_ptr() and cc.q_l - cc.q_m == 8 * 28 and cc.w_l - cc.q_c == 8 * 28
+    assert cc.w_r - cc.w_l == 8 * 8 and cc.var_values == buf.data_ptr() + 8 * p.var_words
+    assert p.total_words == 5 * 28 + 3 * 8 + 36
+    assert lib.pg_columns_in_packed(buf.data_ptr() + 8, 7, 9, C.byref(cc)) == 2  # misaligned
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_asked():
+    """`bench.py --gpus N` on a box with fewer than N GPUs fails loudly: never a silent 1-rank run"""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has 2+ GPUs")
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0 and "needs 2 GPUs" in r.stderr and not r.stdout.strip(), (r.returncode, r.stderr)
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    r = _run_bench(["--gpus", "4", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in r.stderr and not r.stdout.strip(), (r.returncode, r.stderr)
