@@ -109,6 +109,10 @@ struct pg_engine {
     // the pre-pass runs on its own stream beside the rows-only emit launch
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_inv = nullptr;
+    // the stream the last call was issued on (see enter_stream)
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
+    hipEvent_t ev_switch = nullptr;
 };
 
 namespace {
@@ -132,15 +136,16 @@ pg_status ensure_scratch(pg_engine *e, uint64_t batch) {
     return PG_OK;
 }
 
-// counts in e->d_rows / e->d_vars -> exclusive prefix sums; totals copied back (synchronises the stream)
+// counts in e->d_rows / e->d_vars and their block sums in e->d_blk_* (both left by the plan kernel) -> exclusive prefix
+// sums; totals copied back (the synchronous form synchronises the stream)
 pg_status scan_counts(pg_engine *e, uint64_t batch, uint64_t *d_row_off, uint64_t *d_var_off, uint64_t *n_rows,
                       uint64_t *n_vars, hipStream_t st) {
     const uint32_t nblk = (uint32_t)((batch + pg::kScanBlock - 1) / pg::kScanBlock);
-    hipLaunchKernelGGL(pg::scan_block_sums_kernel, dim3(nblk), dim3(pg::kThreads), 0, st, e->d_rows, e->d_vars, batch,
-                       e->d_blk_rows, e->d_blk_vars);
-    hipLaunchKernelGGL(pg::scan_top_kernel, dim3(1), dim3(pg::kThreads), 0, st, e->d_blk_rows, e->d_blk_vars, nblk);
+    const uint32_t prefixed = nblk > pg::kScanDirectBlocks ? 1u : 0u;
+    if (prefixed)
+        hipLaunchKernelGGL(pg::scan_top_kernel, dim3(1), dim3(pg::kThreads), 0, st, e->d_blk_rows, e->d_blk_vars, nblk);
     hipLaunchKernelGGL(pg::scan_final_kernel, dim3(nblk), dim3(pg::kThreads), 0, st, e->d_rows, e->d_vars, batch,
-                       e->d_blk_rows, e->d_blk_vars, d_row_off, d_var_off);
+                       e->d_blk_rows, e->d_blk_vars, d_row_off, d_var_off, prefixed);
     PG_HIP_TRY(hipGetLastError());
     PG_HIP_TRY(hipMemcpyAsync(&e->h_plan->n_gates, d_row_off + batch, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     PG_HIP_TRY(hipMemcpyAsync(&e->h_plan->n_vars, d_var_off + batch, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
@@ -179,10 +184,31 @@ pg_status ensure_inv_scratch(pg_engine *e, uint64_t elems) {
     PG_HIP_TRY(hipSetDevice(e->device));
     if (e->d_prefix) { (void)hipFree(e->d_prefix); e->d_prefix = nullptr; }
     e->inv_elems = 0;
-    PG_HIP_TRY(hipMalloc(&e->d_prefix, elems * 2 * sizeof(uint4)));
+    PG_HIP_TRY(hipMalloc(&e->d_prefix, elems * 4 * sizeof(uint4)));  // per element: the element and its running product
     e->inv_elems = elems;
     return PG_OK;
 }
+
+// The engine's scratch (plan counts, pre-pass products, the pinned plan result) is shared by consecutive calls and is
+// ordered only by the stream they are issued on.  A caller that moves to ANOTHER stream is made to wait for everything
+// the engine still has in flight on the previous one (and on the side stream, which joins it).
+pg_status enter_stream(pg_engine *e, hipStream_t st) {
+    PG_HIP_TRY(hipSetDevice(e->device));
+    if (e->have_last && e->last_stream != st) {
+        PG_HIP_TRY(hipEventRecord(e->ev_switch, e->last_stream));
+        PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_switch, 0));
+    }
+    e->last_stream = st;
+    e->have_last = true;
+    return PG_OK;
+}
+
+#ifndef PG_INV_LANES_PER_CU  // lanes of the pre-pass per CU (256 = one wave per SIMD)
+#define PG_INV_LANES_PER_CU 256
+#endif
+#ifndef PG_INV_MAX_PER_LANE
+#define PG_INV_MAX_PER_LANE 32
+#endif
 
 // One batched gadget call = the emit kernel on the caller's stream and, for gadgets that invert, the inversion pre-pass
 // on the engine's high-priority side stream.  The two write disjoint bytes (the pre-pass owns the inverse slots of
@@ -192,24 +218,21 @@ template <class GD>
 pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, uint64_t batch, uint64_t gate_base,
                  uint64_t var_base, uint64_t zero_var, const uint64_t *row_off, const uint64_t *var_off, void *stream) {
     if ((batch + GD::W - 1) / GD::W > 0xffffffffull) return fail(PG_ERR_INVALID_ARGUMENT, "batch too large for one call");
-    PG_HIP_TRY(hipSetDevice(e->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    PG_TRY(enter_stream(e, st));
     const pg::EmitOut O = make_out(c, batch, GD::W, gate_base, var_base, zero_var, row_off, var_off);
+    constexpr bool kSplit = pg::Split<GD>::ok;  // the rows, then the variable table (emit.hpp, EmitMode)
     bool side = false;  // the inversion pre-pass runs on the engine's side stream
     if constexpr (GD::kInv > 0) {
+        constexpr int GRP = GD::kInvGroup;
         const uint64_t elems = batch * GD::kInv;
         PG_TRY(ensure_inv_scratch(e, elems));
-#ifndef PG_INV_LANES_PER_CU  // one wave per SIMD
-#define PG_INV_LANES_PER_CU 256
-#endif
-#ifndef PG_INV_MAX_PER_LANE
-#define PG_INV_MAX_PER_LANE 32
-#endif
         const uint64_t lanes_wanted = (uint64_t)e->num_cus * PG_INV_LANES_PER_CU;
         uint64_t per_lane = (elems + lanes_wanted - 1) / lanes_wanted;
         if (per_lane < 1) per_lane = 1;
         if (per_lane > PG_INV_MAX_PER_LANE) per_lane = PG_INV_MAX_PER_LANE;
-        const uint64_t lanes = (elems + per_lane - 1) / per_lane;
+        const uint64_t groups = (per_lane + GRP - 1) / GRP;  // a lane owns groups * GRP elements
+        const uint64_t lanes = (elems + groups * GRP - 1) / (groups * GRP);
         const uint32_t blocks = (uint32_t)((lanes + pg::kThreads - 1) / pg::kThreads);
 #if defined(PG_SEQUENTIAL_PREPASS)  // A/B build: the pre-pass on the caller's stream, ahead of the emit kernel
         side = false;
@@ -218,21 +241,45 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
         side = elems >= 2048;
 #endif
         if (!side) {
-            hipLaunchKernelGGL(pg::batch_invert_kernel<GD>, dim3(blocks), dim3(pg::kThreads), 0, st, A, O, elems,
-                               (uint32_t)per_lane, e->d_prefix);
+            hipLaunchKernelGGL((pg::batch_invert_kernel<GD, GRP>), dim3(blocks), dim3(pg::kThreads), 0, st, A, O, elems,
+                               (uint32_t)groups, e->d_prefix);
             PG_HIP_TRY(hipGetLastError());
         } else {
             PG_HIP_TRY(hipEventRecord(e->ev_fork, st));  // the pre-pass reads the call's inputs: order it after the stream
             PG_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-            hipLaunchKernelGGL(pg::batch_invert_kernel<GD>, dim3(blocks), dim3(pg::kThreads), 0, e->side, A, O, elems,
-                               (uint32_t)per_lane, e->d_prefix);
+            hipLaunchKernelGGL((pg::batch_invert_kernel<GD, GRP>), dim3(blocks), dim3(pg::kThreads), 0, e->side, A, O, elems,
+                               (uint32_t)groups, e->d_prefix);
             PG_HIP_TRY(hipGetLastError());
             PG_HIP_TRY(hipEventRecord(e->ev_inv, e->side));
         }
     }
     const uint32_t max_blocks = (uint32_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
-    const uint32_t grid = O.tiles < max_blocks ? O.tiles : max_blocks;
-    hipLaunchKernelGGL(pg::emit_kernel<GD>, dim3(grid), dim3(pg::kThreads), 0, st, A, O);
+    if constexpr (kSplit) {
+        const pg::EmitOut R = make_out(c, batch, GD::kRowsW, gate_base, var_base, zero_var, row_off, var_off);
+        // Beside the pre-pass the rows launch is held to PG_ROWS_WGS_PER_CU workgroups per CU (by asking for LDS it does not
+        // use): a pure streaming writer sustains the same bandwidth at 3 as at 8, but at 8 its waves own every SIMD's
+        // registers and the pre-pass's workgroups (one fat wave per SIMD) only become resident as the first round of
+        // rows workgroups retires -- a hundred microseconds in, which then pushes the pre-pass past the end of the rows.
+        uint32_t pad = 0;
+#ifndef PG_ROWS_WGS_PER_CU
+#define PG_ROWS_WGS_PER_CU 3
+#endif
+        if (side && PG_ROWS_WGS_PER_CU > 0) {
+            static const size_t static_lds = [] {
+                hipFuncAttributes a{};
+                return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(pg::emit_kernel<GD, pg::EMIT_ROWS>)) == hipSuccess
+                           ? a.sharedSizeBytes : (size_t)0;
+            }();
+            const size_t want = (160 * 1024 / PG_ROWS_WGS_PER_CU) & ~(size_t)1023;  // per workgroup, so that exactly that many fit
+            if (static_lds && static_lds < want && want <= 64 * 1024) pad = (uint32_t)(want - static_lds);
+        }
+        hipLaunchKernelGGL((pg::emit_kernel<GD, pg::EMIT_ROWS>), dim3(R.tiles < max_blocks ? R.tiles : max_blocks), dim3(pg::kThreads), pad,
+                           st, A, R);
+        hipLaunchKernelGGL((pg::emit_kernel<GD, pg::EMIT_VARS>), dim3(O.tiles < max_blocks ? O.tiles : max_blocks), dim3(pg::kThreads), 0,
+                           st, A, O);
+    } else {
+        hipLaunchKernelGGL(pg::emit_kernel<GD>, dim3(O.tiles < max_blocks ? O.tiles : max_blocks), dim3(pg::kThreads), 0, st, A, O);
+    }
     PG_HIP_TRY(hipGetLastError());
     if (side) PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_inv, 0));  // join
     return PG_OK;
@@ -261,8 +308,9 @@ pg_status error_plan(pg_engine *e, PlanKernel kernel, const pg_scalar *d_value, 
     if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "NULL argument");
     if (out) std::memset(out, 0, sizeof *out);
     if (err_count) *err_count = 0;
-    if (batch == 0) {
-        if (e->h_plan) *e->h_plan = pg_engine::PlanResult{0, 0, 0, 0};
+    if (batch == 0) {  // stream-ordered like every other write of the plan result
+        PG_TRY(enter_stream(e, static_cast<hipStream_t>(stream)));
+        PG_HIP_TRY(hipMemsetAsync(e->h_plan, 0, sizeof(pg_engine::PlanResult), static_cast<hipStream_t>(stream)));
         return PG_OK;
     }
     PG_TRY(check_scalars(d_value, "value array"));
@@ -270,10 +318,11 @@ pg_status error_plan(pg_engine *e, PlanKernel kernel, const pg_scalar *d_value, 
     PG_TRY(check_u64s(d_var_off, "d_var_off"));
     PG_TRY(ensure_scratch(e, batch));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    PG_TRY(enter_stream(e, st));
     PG_HIP_TRY(hipMemsetAsync(e->d_err_count, 0, sizeof(uint32_t), st));
-    const uint32_t grid = (uint32_t)((batch + pg::kThreads - 1) / pg::kThreads);
+    const uint32_t grid = (uint32_t)((batch + pg::kScanBlock - 1) / pg::kScanBlock);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(pg::kThreads), 0, st, reinterpret_cast<const uint4 *>(d_value), batch,
-                       e->d_rows, e->d_vars, d_err_mask, e->d_err_count);
+                       e->d_rows, e->d_vars, d_err_mask, e->d_err_count, e->d_blk_rows, e->d_blk_vars);
     PG_HIP_TRY(hipGetLastError());
     PG_HIP_TRY(hipMemcpyAsync(&e->h_plan->errs, e->d_err_count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     if (!out) return scan_counts(e, batch, d_row_off, d_var_off, nullptr, nullptr, st);
@@ -337,7 +386,8 @@ pg_status pg_engine_create(int device, pg_engine **out) {
 #endif
     if (hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_inv, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&e->ev_inv, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_switch, hipEventDisableTiming) != hipSuccess) {
         pg_engine_destroy(e);
         return fail(PG_ERR_HIP, "creating the engine's side stream / events failed");
     }
@@ -364,6 +414,7 @@ void pg_engine_destroy(pg_engine *e) {
     if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_inv) (void)hipEventDestroy(e->ev_inv);
+    if (e->ev_switch) (void)hipEventDestroy(e->ev_switch);
     if (e->h_plan) (void)hipHostFree(e->h_plan);
     delete e;
 }
@@ -495,7 +546,7 @@ pg_status pg_range_check_structure_batch(pg_engine *e, const pg_scalar *min_rang
     A.pow2 = e->d_pow2;
     const pg::EmitOut O = make_out(&c, batch, pg::RangeCheckGD::W, gate_base, var_base, 0, nullptr, nullptr);
     const uint32_t max_blocks = (uint32_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
-    hipLaunchKernelGGL((pg::emit_kernel<pg::RangeCheckGD, true>), dim3(O.tiles < max_blocks ? O.tiles : max_blocks), dim3(pg::kThreads),
+    hipLaunchKernelGGL((pg::emit_kernel<pg::RangeCheckGD, pg::EMIT_STRUCTURE>), dim3(O.tiles < max_blocks ? O.tiles : max_blocks), dim3(pg::kThreads),
                        0, static_cast<hipStream_t>(stream), A, O);
     PG_HIP_TRY(hipGetLastError());
     return PG_OK;
@@ -600,7 +651,8 @@ static pg_status max_bound_ragged_plan_common(pg_engine *e, const pg_scalar *d_m
     if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "NULL argument");
     if (out) std::memset(out, 0, sizeof *out);
     if (batch == 0) {
-        *e->h_plan = pg_engine::PlanResult{0, 0, 0, 0};
+        PG_TRY(enter_stream(e, static_cast<hipStream_t>(stream)));
+        PG_HIP_TRY(hipMemsetAsync(e->h_plan, 0, sizeof(pg_engine::PlanResult), static_cast<hipStream_t>(stream)));
         return PG_OK;
     }
     PG_TRY(check_scalars(d_max_range, "d_max_range"));
@@ -609,11 +661,16 @@ static pg_status max_bound_ragged_plan_common(pg_engine *e, const pg_scalar *d_m
     PG_TRY(check_u64s(d_var_off, "d_var_off"));
     PG_TRY(ensure_scratch(e, batch));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const uint32_t grid = (uint32_t)((batch + pg::kThreads - 1) / pg::kThreads);
+    PG_TRY(enter_stream(e, st));
+    const uint32_t grid = (uint32_t)((batch + pg::kScanBlock - 1) / pg::kScanBlock);
     hipLaunchKernelGGL(pg::max_bound_plan_kernel, dim3(grid), dim3(pg::kThreads), 0, st,
-                       reinterpret_cast<const uint4 *>(d_max_range), batch, e->d_pow2, d_num_bits, e->d_rows, e->d_vars);
+                       reinterpret_cast<const uint4 *>(d_max_range), batch, e->d_pow2, d_num_bits, e->d_rows, e->d_vars,
+                       e->d_blk_rows, e->d_blk_vars);
     PG_HIP_TRY(hipGetLastError());
-    e->h_plan->errs = 0;
+    // a max_bound plan has no failing items: zero the error word IN STREAM ORDER (an earlier plan's asynchronous copy into
+    // the same pinned word may still be in flight)
+    PG_HIP_TRY(hipMemsetAsync(e->d_err_count, 0, sizeof(uint32_t), st));
+    PG_HIP_TRY(hipMemcpyAsync(&e->h_plan->errs, e->d_err_count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     if (!out) return scan_counts(e, batch, d_row_off, d_var_off, nullptr, nullptr, st);
     PG_TRY(scan_counts(e, batch, d_row_off, d_var_off, &out->n_gates, &out->n_vars, st));
     return PG_OK;

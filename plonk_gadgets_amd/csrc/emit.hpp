@@ -21,6 +21,8 @@
 // the closed form item * G.
 #pragma once
 
+#include <type_traits>
+
 #include "fr.hpp"
 
 namespace pg {
@@ -66,8 +68,8 @@ __device__ __forceinline__ Fr lds_fr(const uint4 *table, uint32_t id) {
     return t.f;
 }
 
-__device__ __forceinline__ void fill_common_table(uint4 *table, const uint4 *pow2, uint32_t tid) {
-    for (uint32_t e = tid; e < kTableEntries; e += kThreads) {
+__device__ __forceinline__ void fill_common_table(uint4 *table, const uint4 *pow2, uint32_t tid, uint32_t entries) {
+    for (uint32_t e = tid; e < entries; e += kThreads) {
         FrVec t;
         t.f = fr_zero();
         if (e == T_ONE) t.f = fr_one();
@@ -82,9 +84,13 @@ __device__ __forceinline__ void fill_common_table(uint4 *table, const uint4 *pow
 
 // ragged batches: item that owns tile-relative position r (off[] = exclusive prefix sums in LDS, off[Wt] = total).
 // Items much larger than a sweep step are found by walking on from the previous item; small items (a step skips
-// many of them) by bisection.
-template <bool SMALL_ITEMS>
-__device__ __forceinline__ uint32_t find_item(const uint32_t *off, uint32_t Wt, uint32_t r, uint32_t it) {
+// many of them) by bisection -- unless every item of the tile has the gadget's full size UNI (no item stopped early:
+// the common case), when the owner is a division by a constant and LDS is not touched at all.
+template <bool SMALL_ITEMS, uint32_t UNI>
+__device__ __forceinline__ uint32_t find_item(const uint32_t *off, uint32_t Wt, uint32_t r, uint32_t it, bool uniform) {
+    if constexpr (UNI != 0) {
+        if (uniform) return r / UNI;
+    }
     if constexpr (SMALL_ITEMS) {
         uint32_t lo = it, hi = Wt;  // invariant: off[lo] <= r < off[hi]
         while (hi - lo > 1) {
@@ -106,35 +112,107 @@ __device__ __forceinline__ uint32_t find_item(const uint32_t *off, uint32_t Wt, 
 //   static constexpr bool kUsePow2;      table needs mont(2^i)
 //   uint32_t rows_per_item(A), vars_per_item(A)                      (uniform only)
 //   void fill_table(A, table, tid)       gadget constants into T_QC_A / T_QC_B
-//   void item(A, O, item, table, rec)    per-item arithmetic -> rec (+ per-item outputs)
+//   void item_rows(A, O, item, table, rec)  kRagged || kRecInRows: the part of the record the ROWS read (cheap: an
+//                                        item's shape), written before anything else so that the waves that do not
+//                                        run the item phase start storing rows at once
+//   void item(A, O, item, table, rec)    per-item arithmetic -> the rest of rec (+ per-item outputs); never rewrites
+//                                        what item_rows wrote
+//   uint32_t kUniformRows, kUniformVars  ragged only: rows / variables of an item that did not stop early (0: none)
 //   void selectors(A, rec, j, table, h, uint4 out[5])
 //   void wires(A, O, rec, item, item_var_base, j, uint64_t out[3])
 //   Fr   var_value(A, rec, table, k)
 //   bool is_inv_slot(A, rec, k)          item-variable k holds an inverse (written by the pre-pass, not here)
-//   int  kInv; Fr inv_element(A, item, e); uint4 *inv_slot(A, O, item, e)   the pre-pass's view (invert.hpp)
+//   kSplit / RowRec / kRowsW             optional: the gadget is emitted as EMIT_ROWS + EMIT_VARS (below)
+//   kPeriodic / var_value_full(A, rec, table, k)   optional: tiles of full-shape items take the periodic sweeps (below)
+//   int  kInv; inv_operands / inv_combine / inv_slot                        the pre-pass's view (invert.hpp)
+template <class GD, bool RAGGED = GD::kRagged>
+struct UniformShape {
+    static constexpr uint32_t rows = 0, vars = 0;
+};
+template <class GD>
+struct UniformShape<GD, true> {
+    static constexpr uint32_t rows = GD::kUniformRows, vars = GD::kUniformVars;
+};
+
+// kPeriodic (optional, ragged gadgets with small items): in a tile whose items all have the full shape, selectors depend
+// on the row-within-item alone and wires are `constant` or `item's first variable + constant`.  The sweeps of such a
+// tile then use a lane count that is a multiple of the item size, so that a lane meets the SAME row-within-item on
+// every pass: selector values, wire offsets and the variable's slot are computed once per tile and the loops are bare
+// stores (the generic sweeps spend ~30 vector + ~20 scalar instructions per 16-byte store on finding the item, the
+// row and the constants again -- measured on the fused mix: SQ_INSTS_VALU, profiles/).
+template <class GD, class = void>
+struct Periodic {
+    static constexpr bool ok = false;
+};
+template <class GD>
+struct Periodic<GD, std::void_t<decltype(GD::kPeriodic)>> {
+    static constexpr bool ok = GD::kPeriodic;
+};
+// largest lane count <= kThreads whose pass of two rows per lane is a whole number of items of R rows
+constexpr uint32_t periodic_wire_lanes(uint32_t R) {
+    uint32_t L = 256;
+    while ((2 * L) % R) L--;
+    return L;
+}
+
 #ifndef PG_EMIT_WAVES_PER_SIMD
 #define PG_EMIT_WAVES_PER_SIMD 1  // __launch_bounds__ second argument (waves per SIMD the register allocator must allow)
 #endif
-// Nothing this kernel writes depends on a field inversion: the variables that hold inverses (z of maybe_equal, inv of
-// is_non_zero) are written, at their final slots, by the inversion pre-pass (invert.hpp), which runs concurrently on
-// the engine's side stream; the variable sweep here skips exactly those slots (GD::is_inv_slot).
-//
-// kStructureOnly: selectors and wire indices alone -- for a gadget whose rows do not read the item record they are a
-// function of the public inputs and the numbering, not of the witnesses, so a rank can regenerate another rank's rows
-// instead of receiving them (distributed.VariablesOnlyPipeline); the item phase and the variable sweep are compiled out.
-template <class GD, bool kStructureOnly = false>
+
+// What one launch of the emit kernel writes:
+//   EMIT_ALL        rows and variables of every item (inverse slots excepted: the pre-pass writes those in place)
+//   EMIT_STRUCTURE  selectors and wire indices alone, no item phase at all -- for a gadget whose rows do not read the
+//                   item record they are a function of the public inputs and the numbering, not of the witnesses, so a
+//                   rank can regenerate another rank's rows instead of receiving them (distributed.VariablesOnlyPipeline)
+//   EMIT_ROWS       selectors and wire indices of a gadget whose rows DO depend on its inputs, but only through a cheap
+//                   per-item shape (GD::RowRec, GD::item_rows): a lean pure-store launch (no arithmetic, a few bytes of
+//                   LDS per item, GD::kRowsW items per tile) that shares the chip with the inversion pre-pass
+//   EMIT_VARS       the variable table alone (inverse slots excepted, as in EMIT_ALL)
+// A gadget with GD::kSplit is emitted as EMIT_ROWS then EMIT_VARS on the caller's stream, both beside the pre-pass: for
+// small items the all-in-one launch is a poor streaming writer -- its tile is bounded by the LDS the item records take
+// (64 items = 148 KB of output for the fused mix), so a workgroup's global round trips before its first store are never
+// amortised -- while four fifths of its bytes (the rows) need no record at all.
+enum EmitMode : int { EMIT_ALL = 0, EMIT_STRUCTURE = 1, EMIT_ROWS = 2, EMIT_VARS = 3 };
+
+template <class GD, class = void>
+struct Split {
+    static constexpr bool ok = false;
+};
+template <class GD>
+struct Split<GD, std::void_t<decltype(GD::kSplit)>> {
+    static constexpr bool ok = GD::kSplit;
+};
+template <class GD, int MODE>
+struct EmitShape {
+    using Rec = typename GD::ItemRec;
+    static constexpr int W = GD::W;
+};
+template <class GD>
+struct EmitShape<GD, EMIT_ROWS> {
+    using Rec = typename GD::RowRec;
+    static constexpr int W = GD::kRowsW;
+};
+
+// Nothing an EMIT_ALL launch writes depends on a field inversion: the variables that hold inverses (z of maybe_equal,
+// inv of is_non_zero) are written, at their final slots, by the inversion pre-pass (invert.hpp), which runs
+// concurrently on the engine's side stream; the variable sweep here skips exactly those slots (GD::is_inv_slot).
+template <class GD, int MODE = EMIT_ALL>
 __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(const typename GD::Args A, const EmitOut O) {
-    static_assert(!kStructureOnly || !(GD::kRagged || GD::kRecInRows), "rows of this gadget depend on its inputs");
-    constexpr int W = GD::W;
-    __shared__ uint4 s_table[kTableEntries * 2];
-    __shared__ typename GD::ItemRec s_item[W];
+    static_assert(MODE != EMIT_STRUCTURE || !(GD::kRagged || GD::kRecInRows), "rows of this gadget depend on its inputs");
+    constexpr bool kRows = MODE != EMIT_VARS;                     // selector and wire sweeps
+    constexpr bool kVars = MODE == EMIT_ALL || MODE == EMIT_VARS;  // item arithmetic and the variable sweep
+    constexpr int W = EmitShape<GD, MODE>::W;
+    using Rec = typename EmitShape<GD, MODE>::Rec;
+    constexpr uint32_t kTable = GD::kUsePow2 ? kTableEntries : T_POW;  // gadgets without a ladder need the 8 constants only
+    __shared__ uint4 s_table[kTable * 2];
+    __shared__ Rec s_item[W];
     __shared__ uint32_t s_roff[W + 1], s_voff[W + 1];
 
     const uint32_t tid = threadIdx.x;
     {
         const uint4 *p2 = nullptr;
         if constexpr (GD::kUsePow2) p2 = GD::pow2(A);
-        fill_common_table(s_table, p2, tid);
+        fill_common_table(s_table, p2, tid, kTable);
     }
     GD::fill_table(A, s_table, tid);
     __syncthreads();
@@ -152,13 +230,22 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
         const uint32_t Wt = (uint32_t)((O.batch - w0) < (uint64_t)W ? (O.batch - w0) : (uint64_t)W);
         uint64_t row0, var0;  // tile's first row / variable relative to the call
         uint32_t G = 0, V = 0;
+        // The tile's global loads are ISSUED together and waited for once: its offsets (ragged), then whatever the item
+        // phase reads.  Under a saturated memory system a round trip costs microseconds, and a small-item tile has only a
+        // few tens of microseconds of stores to hide it behind.
+        uint64_t my_r = 0, my_v = 0, tail_r = 0, tail_v = 0;
         if constexpr (GD::kRagged) {
             row0 = O.row_off[w0];
             var0 = O.var_off[w0];
-            // Wt + 1 entries: W may equal the block size, so stride over them
-            for (uint32_t i = tid; i <= Wt; i += kThreads) {
-                s_roff[i] = (uint32_t)(O.row_off[w0 + i] - row0);
-                s_voff[i] = (uint32_t)(O.var_off[w0 + i] - var0);
+            if (tid <= Wt) {
+                my_r = O.row_off[w0 + tid];
+                my_v = O.var_off[w0 + tid];
+            }
+            if constexpr (W == kThreads) {  // Wt + 1 entries, one more than there are threads
+                if (tid == 0) {
+                    tail_r = O.row_off[w0 + Wt];
+                    tail_v = O.var_off[w0 + Wt];
+                }
             }
         } else {
             G = GD::rows_per_item(A);
@@ -168,93 +255,199 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
         }
 
         // ---- item phase: one lane per item --------------------------------
-        if constexpr (!kStructureOnly) {
+        // With rows to write: first what they depend on (an item's shape: ladder length, stopped-early flag), so that
+        // after ONE barrier every wave can store rows; the witness-dependent arithmetic (loads, Montgomery conversions)
+        // then occupies the first lanes only, beside the other waves' selector and wire sweeps.  Without (EMIT_VARS):
+        // the whole record at once, its loads in flight together with the offsets'.
+        if constexpr ((GD::kRagged || GD::kRecInRows) && kRows && MODE != EMIT_STRUCTURE) {
+            for (uint32_t i = tid; i < Wt; i += kThreads) GD::item_rows(A, O, w0 + i, s_table, s_item[i]);
+        }
+        if constexpr (kVars && !kRows) {
             if (tid < Wt) GD::item(A, O, w0 + tid, s_table, s_item[tid]);
         }
-        if constexpr (GD::kRagged || GD::kRecInRows) __syncthreads();
+        if constexpr (GD::kRagged) {
+            if (tid <= Wt) {
+                s_roff[tid] = (uint32_t)(my_r - row0);
+                s_voff[tid] = (uint32_t)(my_v - var0);
+            }
+            if constexpr (W == kThreads) {
+                if (tid == 0) {
+                    s_roff[Wt] = (uint32_t)(tail_r - row0);
+                    s_voff[Wt] = (uint32_t)(tail_v - var0);
+                }
+            }
+        }
+        if constexpr (GD::kRagged || GD::kRecInRows || !kRows) __syncthreads();
+        if constexpr (kVars && kRows) {
+            if (tid < Wt) GD::item(A, O, w0 + tid, s_table, s_item[tid]);
+        }
 
         const uint32_t total_rows = GD::kRagged ? s_roff[Wt] : Wt * G;
         const uint32_t total_vars = GD::kRagged ? s_voff[Wt] : Wt * V;
+        constexpr uint32_t kUniR = UniformShape<GD>::rows, kUniV = UniformShape<GD>::vars;
+        const bool uni_rows = kUniR != 0 && total_rows == Wt * kUniR, uni_vars = kUniV != 0 && total_vars == Wt * kUniV;
 
-        // ---- selector sweep: 16 B per lane, 128 rows x 5 columns per pass ---
-        {
-            const uint32_t total = total_rows * 2;
-            const uint32_t h = tid & 1;
-            uint32_t it = 0, j = tid >> 1;
-            if constexpr (!GD::kRagged) { it = j / G; j -= it * G; }
-            for (uint32_t idx = tid; idx < total; idx += kThreads) {
-                if constexpr (GD::kRagged) {
-                    const uint32_t r = idx >> 1;
-                    it = find_item<GD::W >= 64>(s_roff, Wt, r, it);
-                    j = r - s_roff[it];
-                }
-                uint4 v[5];
-                GD::selectors(A, s_item[it], j, s_table, h, v);
+#if !defined(PG_NO_PERIODIC)
+        if constexpr (Periodic<GD>::ok && MODE != EMIT_STRUCTURE) {
+            if (uni_rows && uni_vars) {  // every item of the tile has the full shape
+                constexpr uint32_t R = kUniR, VV = kUniV;
+                if constexpr (kRows) {
+                    // selectors: lanes 2r, 2r+1 hold the halves of row r; IPP whole items per pass
+                    constexpr uint32_t IPP = (kThreads / 2) / R, LS = IPP * R * 2;
+                    if (tid < LS) {
+                        const uint32_t rl = tid >> 1, j = rl - (rl / R) * R;
+                        uint4 v[5];
+                        GD::selectors(A, s_item[0], j, s_table, tid & 1, v);
+                        uint4 *dst[5];
 #pragma unroll
-                for (int c = 0; c < 5; c++) store16(O.q[c] + (row0 * 2 + idx), v[c]);
-                if constexpr (!GD::kRagged) {
-                    j += kThreads / 2;
-                    if (j >= G) { const uint32_t d = j / G; it += d; j -= d * G; }
-                }
-            }
-        }
-
-        // ---- wire sweep: two rows (16 B) per lane per column ---------------
+                        for (int c = 0; c < 5; c++) dst[c] = O.q[c] + (row0 * 2 + tid);
+                        for (uint32_t idx = tid; idx < total_rows * 2; idx += LS) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            uint64_t *col = O.w[c] + row0;
-            // pair rows so that every pair starts on a 16-byte boundary
-            const uint32_t shift = (uint32_t)((reinterpret_cast<uintptr_t>(col) >> 3) & 1);
-            const uint32_t pairs = (total_rows + shift + 1) >> 1;
-            uint32_t it = 0;
-            for (uint32_t p = tid; p < pairs; p += kThreads) {
-                const int64_t r0 = (int64_t)2 * p - shift;
-                uint64_t val[2];
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const int64_t r = r0 + k;
-                    uint32_t rr = r < 0 ? 0u : (uint32_t)r;
-                    if (rr >= total_rows) rr = total_rows - 1;
-                    uint32_t j, vo;
-                    if constexpr (GD::kRagged) {
-                        it = find_item<GD::W >= 64>(s_roff, Wt, rr, it);
-                        j = rr - s_roff[it];
-                        vo = s_voff[it];
-                    } else {
-                        it = rr / G;
-                        j = rr - it * G;
-                        vo = it * V;
+                            for (int c = 0; c < 5; c++) {
+                                store16(dst[c], v[c]);
+                                dst[c] += LS;
+                            }
+                        }
                     }
-                    uint64_t out[3];
-                    GD::wires(A, O, s_item[it], w0 + it, O.var_base + var0 + vo, j, out);
-                    val[k] = out[c];
+                    // wires: two rows per lane; a pass of LW lanes covers 2 LW / R whole items
+                    constexpr uint32_t LW = periodic_wire_lanes(R), IPW = 2 * LW / R;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        uint64_t *col = O.w[c] + row0;
+                        const uint32_t shift = (uint32_t)((reinterpret_cast<uintptr_t>(col) >> 3) & 1);
+                        if (tid < LW) {
+                            uint64_t wbase[2], slope[2];
+#pragma unroll
+                            for (int k = 0; k < 2; k++) {
+                                const int32_t r = (int32_t)(2 * tid + k) - (int32_t)shift;
+                                const uint32_t rr = r < 0 ? 0u : (uint32_t)r, it = rr / R, j = rr - it * R;
+                                const uint64_t vb = O.var_base + var0 + (uint64_t)it * VV;
+                                uint64_t a[3], b[3];
+                                GD::wires(A, O, s_item[0], w0 + it, vb, j, a);
+                                GD::wires(A, O, s_item[0], w0 + it, vb + 1, j, b);
+                                wbase[k] = a[c];
+                                slope[k] = b[c] - a[c];  // 1: a Variable of the item; 0: a constant (zero_var)
+                            }
+                            const uint64_t step = (uint64_t)IPW * VV;
+                            uint64_t adv = 0;
+                            for (int64_t r0 = (int64_t)2 * tid - shift; r0 < (int64_t)total_rows; r0 += 2 * LW, adv += step) {
+                                const uint64_t v0 = wbase[0] + slope[0] * adv, v1 = wbase[1] + slope[1] * adv;
+                                if (r0 >= 0 && r0 + 1 < (int64_t)total_rows) {
+                                    store16(reinterpret_cast<uint4 *>(col + r0),
+                                            make_uint4((uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32)));
+                                } else {
+                                    if (r0 >= 0) col[r0] = v0;
+                                    if (r0 + 1 < (int64_t)total_rows) col[r0 + 1] = v1;
+                                }
+                            }
+                        }
+                    }
                 }
-                if (r0 >= 0 && r0 + 1 < (int64_t)total_rows) {
-                    store16(reinterpret_cast<uint4 *>(col + r0),
-                            make_uint4((uint32_t)val[0], (uint32_t)(val[0] >> 32), (uint32_t)val[1],
-                                       (uint32_t)(val[1] >> 32)));
-                } else {
-                    if (r0 >= 0) col[r0] = val[0];
-                    if (r0 + 1 < (int64_t)total_rows) col[r0 + 1] = val[1];
+                __syncthreads();  // item records visible
+                if constexpr (kVars) {
+                    // variables: lane = (item, slot); IPV whole items per pass
+                    constexpr uint32_t IPV = kThreads / VV, LV = IPV * VV;
+                    if (tid < LV) {
+                        const uint32_t it0 = tid / VV, k = tid - it0 * VV;
+                        const bool is_inv = GD::is_inv_slot(A, s_item[0], k);
+                        uint4 *dst = O.vars + (var0 + tid) * 2;
+                        if (!is_inv) {  // the inverse slots belong to the pre-pass
+                            for (uint32_t it = it0; it < Wt; it += IPV, dst += 2 * LV) {
+                                FrVec val;
+                                val.f = GD::var_value_full(A, s_item[it], s_table, k);  // k is the lane's for the whole tile
+                                store16(dst, val.v[0]);
+                                store16(dst + 1, val.v[1]);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();  // records and offsets are rewritten by the next tile
+                continue;
+            }
+        }
+#endif
+
+        if constexpr (kRows) {
+            // ---- selector sweep: 16 B per lane, 128 rows x 5 columns per pass ---
+            {
+                const uint32_t total = total_rows * 2;
+                const uint32_t h = tid & 1;
+                uint32_t it = 0, j = tid >> 1;
+                if constexpr (!GD::kRagged) { it = j / G; j -= it * G; }
+                for (uint32_t idx = tid; idx < total; idx += kThreads) {
+                    if constexpr (GD::kRagged) {
+                        const uint32_t r = idx >> 1;
+                        it = find_item<W >= 64, kUniR>(s_roff, Wt, r, it, uni_rows);
+                        j = uni_rows ? r - it * kUniR : r - s_roff[it];
+                    }
+                    uint4 v[5];
+                    GD::selectors(A, s_item[it], j, s_table, h, v);
+#pragma unroll
+                    for (int c = 0; c < 5; c++) store16(O.q[c] + (row0 * 2 + idx), v[c]);
+                    if constexpr (!GD::kRagged) {
+                        j += kThreads / 2;
+                        if (j >= G) { const uint32_t d = j / G; it += d; j -= d * G; }
+                    }
+                }
+            }
+
+            // ---- wire sweep: two rows (16 B) per lane per column ---------------
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                uint64_t *col = O.w[c] + row0;
+                // pair rows so that every pair starts on a 16-byte boundary
+                const uint32_t shift = (uint32_t)((reinterpret_cast<uintptr_t>(col) >> 3) & 1);
+                const uint32_t pairs = (total_rows + shift + 1) >> 1;
+                uint32_t it = 0;
+                for (uint32_t p = tid; p < pairs; p += kThreads) {
+                    const int64_t r0 = (int64_t)2 * p - shift;
+                    uint64_t val[2];
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const int64_t r = r0 + k;
+                        uint32_t rr = r < 0 ? 0u : (uint32_t)r;
+                        if (rr >= total_rows) rr = total_rows - 1;
+                        uint32_t j, vo;
+                        if constexpr (GD::kRagged) {
+                            it = find_item<W >= 64, kUniR>(s_roff, Wt, rr, it, uni_rows);
+                            j = uni_rows ? rr - it * kUniR : rr - s_roff[it];
+                            vo = (uni_rows && uni_vars) ? it * kUniV : s_voff[it];
+                        } else {
+                            it = rr / G;
+                            j = rr - it * G;
+                            vo = it * V;
+                        }
+                        uint64_t out[3];
+                        GD::wires(A, O, s_item[it], w0 + it, O.var_base + var0 + vo, j, out);
+                        val[k] = out[c];
+                    }
+                    if (r0 >= 0 && r0 + 1 < (int64_t)total_rows) {
+                        store16(reinterpret_cast<uint4 *>(col + r0),
+                                make_uint4((uint32_t)val[0], (uint32_t)(val[0] >> 32), (uint32_t)val[1],
+                                           (uint32_t)(val[1] >> 32)));
+                    } else {
+                        if (r0 >= 0) col[r0] = val[0];
+                        if (r0 + 1 < (int64_t)total_rows) col[r0 + 1] = val[1];
+                    }
                 }
             }
         }
 
-        if constexpr (!(GD::kRagged || GD::kRecInRows)) __syncthreads();  // item records visible
+        __syncthreads();  // item records visible
 
         // ---- variable sweep: one scalar (2 x 16 B) per lane ----------------
-        if constexpr (!kStructureOnly) {
+        if constexpr (kVars) {
             uint32_t it = 0, k = tid;
             if constexpr (!GD::kRagged) { it = k / V; k -= it * V; }
             for (uint32_t s = tid; s < total_vars; s += kThreads) {
                 if constexpr (GD::kRagged) {
-                    it = find_item<GD::W >= 64>(s_voff, Wt, s, it);
-                    k = s - s_voff[it];
+                    it = find_item<W >= 64, kUniV>(s_voff, Wt, s, it, uni_vars);
+                    k = uni_vars ? s - it * kUniV : s - s_voff[it];
                 }
-                if (!GD::is_inv_slot(A, s_item[it], k)) {  // inverse slots belong to the pre-pass
+                uint4 *dst = O.vars + (var0 + s) * 2;
+                if (!GD::is_inv_slot(A, s_item[it], k)) {  // the inverse slots belong to the pre-pass
                     FrVec val;
                     val.f = GD::var_value(A, s_item[it], s_table, k);
-                    uint4 *dst = O.vars + (var0 + s) * 2;
                     store16(dst, val.v[0]);
                     store16(dst + 1, val.v[1]);
                 }
@@ -326,8 +519,8 @@ __global__ __launch_bounds__(kThreads) void to_canonical_kernel(const uint4 *in,
 }
 
 // ---- exclusive prefix sums for ragged batches ---------------------------
-// counts[i] (rows, vars of item i) -> off[i], off[batch] = total.  Three small
-// kernels: per-block sums, scan of the block sums (one block), final scan.
+// counts[i] (rows, vars of item i) -> off[i], off[batch] = total.  The plan kernel leaves the per-item counts AND
+// their per-block sums (plan_block_sums); one more launch turns them into offsets (two above 4 M items).
 constexpr int kScanBlock = 1024;  // items per block (256 threads x 4)
 
 __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *s_warp, uint64_t &block_total) {
@@ -348,21 +541,6 @@ __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *s
     return base + incl - v;
 }
 
-__global__ __launch_bounds__(kThreads) void scan_block_sums_kernel(const uint32_t *rows, const uint32_t *vars, uint64_t n,
-                                                                  uint64_t *blk_rows, uint64_t *blk_vars) {
-    __shared__ uint64_t s_warp[4];
-    const uint64_t base = (uint64_t)blockIdx.x * kScanBlock;
-    uint64_t r = 0, v = 0;
-    for (int k = 0; k < 4; k++) {
-        uint64_t i = base + threadIdx.x * 4 + k;
-        if (i < n) { r += rows[i]; v += vars[i]; }
-    }
-    uint64_t tr, tv;
-    block_exclusive_scan(r, s_warp, tr);
-    block_exclusive_scan(v, s_warp, tv);
-    if (threadIdx.x == 0) { blk_rows[blockIdx.x] = tr; blk_vars[blockIdx.x] = tv; }
-}
-
 // single block: in-place exclusive scan of the block sums (nblk arbitrary: loops in chunks of 256)
 __global__ __launch_bounds__(kThreads) void scan_top_kernel(uint64_t *blk_rows, uint64_t *blk_vars, uint32_t nblk) {
     __shared__ uint64_t s_warp[4];
@@ -378,11 +556,36 @@ __global__ __launch_bounds__(kThreads) void scan_top_kernel(uint64_t *blk_rows, 
     }
 }
 
+// block sums straight from a plan kernel: thread t of plan block b owns items b * kScanBlock + 4 t .. + 3 (the
+// indexing of scan_final_kernel) and hands in the sums of its four counts -- the separate block-sums launch is gone
+__device__ __forceinline__ void plan_block_sums(uint64_t r, uint64_t v, uint64_t *blk_rows, uint64_t *blk_vars) {
+    __shared__ uint64_t s_plan_warp[4];
+    uint64_t tr, tv;
+    block_exclusive_scan(r, s_plan_warp, tr);
+    block_exclusive_scan(v, s_plan_warp, tv);
+    if (threadIdx.x == 0) { blk_rows[blockIdx.x] = tr; blk_vars[blockIdx.x] = tv; }
+}
+
+// blk_prefixed = 0: blk_* hold the block SUMS and every block adds up the ones before it itself (no scan_top launch;
+// the host takes this route up to kScanDirectBlocks blocks = 4 M items); 1: scan_top_kernel has turned them into
+// exclusive prefix sums
+constexpr uint32_t kScanDirectBlocks = 4096;
+
 __global__ __launch_bounds__(kThreads) void scan_final_kernel(const uint32_t *rows, const uint32_t *vars, uint64_t n,
                                                              const uint64_t *blk_rows, const uint64_t *blk_vars,
-                                                             uint64_t *row_off, uint64_t *var_off) {
+                                                             uint64_t *row_off, uint64_t *var_off, uint32_t blk_prefixed) {
     __shared__ uint64_t s_warp[4];
     const uint64_t base = (uint64_t)blockIdx.x * kScanBlock;
+    uint64_t br, bv;
+    if (blk_prefixed) {
+        br = blk_rows[blockIdx.x];
+        bv = blk_vars[blockIdx.x];
+    } else {
+        uint64_t pr = 0, pv = 0;
+        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kThreads) { pr += blk_rows[b]; pv += blk_vars[b]; }
+        block_exclusive_scan(pr, s_warp, br);
+        block_exclusive_scan(pv, s_warp, bv);
+    }
     uint64_t r[4], v[4], sr = 0, sv = 0;
     for (int k = 0; k < 4; k++) {
         uint64_t i = base + threadIdx.x * 4 + k;
@@ -392,8 +595,8 @@ __global__ __launch_bounds__(kThreads) void scan_final_kernel(const uint32_t *ro
         sv += v[k];
     }
     uint64_t tr, tv;
-    uint64_t er = blk_rows[blockIdx.x] + block_exclusive_scan(sr, s_warp, tr);
-    uint64_t ev = blk_vars[blockIdx.x] + block_exclusive_scan(sv, s_warp, tv);
+    uint64_t er = br + block_exclusive_scan(sr, s_warp, tr);
+    uint64_t ev = bv + block_exclusive_scan(sv, s_warp, tv);
     for (int k = 0; k < 4; k++) {
         uint64_t i = base + threadIdx.x * 4 + k;
         if (i < n) { row_off[i] = er; var_off[i] = ev; }

@@ -138,12 +138,20 @@ struct RangeCheckGD {
         const uint4 *pow2;
     };
     static constexpr int kInv = 2;
+    static constexpr int kInvGroup = 4;  // elements a lane of the pre-pass fetches per round trip (inv_combine is register-hungry here)
     // element e of item: u of the max block (e = 0) / min block (e = 1)
-    __device__ static Fr inv_element(const Args &A, uint64_t item, uint32_t e) {
-        FrVec x;
-        x.v[0] = A.witness[item * 2];
-        x.v[1] = A.witness[item * 2 + 1];
-        const Fr Tm = e == 0 ? fr_sub(fr_sub(A.max_range, fr_one()), x.f) : fr_sub(x.f, A.min_range);
+    __device__ static void inv_operands(const Args &A, const EmitOut &, uint64_t item, uint32_t, FrVec &p, FrVec &q, uint32_t &) {
+        p.v[0] = A.witness[item * 2];
+        p.v[1] = A.witness[item * 2 + 1];
+        q.f = p.f;
+    }
+    __device__ static Fr inv_combine(const Args &A, uint32_t e, const Fr &x, const Fr &, uint32_t) {
+        // both bound blocks' T, the wanted one selected limb by limb (a ternary over two struct temporaries goes through
+        // private memory)
+        const Fr t0 = fr_sub(fr_sub(A.max_range, fr_one()), x), t1 = fr_sub(x, A.min_range);
+        Fr Tm;
+#pragma unroll
+        for (int i = 0; i < 4; i++) Tm.l[i] = e == 0 ? t0.l[i] : t1.l[i];
         return bound_u(Tm, fr_from_mont(Tm), A.n);
     }
     // z of the max block (e = 0) / min block (e = 1)
@@ -250,24 +258,27 @@ struct MaxBoundGD {
         const uint4 *pow2;
     };
     static constexpr int kInv = 1;
+    static constexpr int kInvGroup = 4;  // elements a lane of the pre-pass fetches per round trip (inv_combine is register-hungry here)
     __device__ static uint4 *inv_slot(const Args &A, const EmitOut &O, uint64_t item, uint32_t) {
         const uint32_t n = RAGGED ? A.num_bits_v[item] : A.n;
         const uint32_t x0 = (!RAGGED && A.witness_vars) ? 0u : 1u;
         const uint64_t first = RAGGED ? O.var_off[item] : item * (uint64_t)(n + 261 + x0);
         return O.vars + 2 * (first + x0 + bound_z_offset(n));
     }
-    __device__ static Fr inv_element(const Args &A, uint64_t item, uint32_t) {
-        FrVec x, m;
-        x.v[0] = A.witness[item * 2];
-        x.v[1] = A.witness[item * 2 + 1];
-        uint32_t n = A.n;
-        m.f = A.max_range;
+    // operands: the witness, the item's bound and ladder length (ragged: per item)
+    __device__ static void inv_operands(const Args &A, const EmitOut &, uint64_t item, uint32_t, FrVec &p, FrVec &q, uint32_t &n) {
+        p.v[0] = A.witness[item * 2];
+        p.v[1] = A.witness[item * 2 + 1];
+        n = A.n;
+        q.f = A.max_range;
         if constexpr (RAGGED) {
-            m.v[0] = A.max_range_v[item * 2];
-            m.v[1] = A.max_range_v[item * 2 + 1];
+            q.v[0] = A.max_range_v[item * 2];
+            q.v[1] = A.max_range_v[item * 2 + 1];
             n = A.num_bits_v[item];
         }
-        const Fr Tm = fr_sub(fr_sub(m.f, fr_one()), x.f);
+    }
+    __device__ static Fr inv_combine(const Args &, uint32_t, const Fr &x, const Fr &m, uint32_t n) {
+        const Fr Tm = fr_sub(fr_sub(m, fr_one()), x);
         return bound_u(Tm, fr_from_mont(Tm), n);
     }
     struct alignas(16) ItemRec {
@@ -300,6 +311,17 @@ struct MaxBoundGD {
         }
     }
 
+    static constexpr uint32_t kUniformRows = 0, kUniformVars = 0;  // ragged: ladder lengths differ from item to item
+    // ragged: what the rows of an item depend on -- its ladder length (from the plan) and q_c = mont(max_i - 1), both
+    // functions of the PUBLIC bound alone
+    __device__ static void item_rows(const Args &A, const EmitOut &, uint64_t item, const uint4 *, ItemRec &R) {
+        FrVec m;
+        m.v[0] = A.max_range_v[item * 2];
+        m.v[1] = A.max_range_v[item * 2 + 1];
+        R.qc = fr_sub(m.f, fr_one());  // range.rs:87
+        R.n = A.num_bits_v[item];
+    }
+
     __device__ static void item(const Args &A, const EmitOut &O, uint64_t item, const uint4 *table, ItemRec &R) {
         FrVec x;
         x.v[0] = A.witness[item * 2];
@@ -307,17 +329,14 @@ struct MaxBoundGD {
         R.x = x.f;
         uint32_t n = A.n;
         Fr qc;
-        if constexpr (RAGGED) {
-            FrVec m;
-            m.v[0] = A.max_range_v[item * 2];
-            m.v[1] = A.max_range_v[item * 2 + 1];
-            qc = fr_sub(m.f, fr_one());
-            n = A.num_bits_v[item];
+        if constexpr (RAGGED) {  // R.qc / R.n are item_rows' (same lane, earlier): read, never rewritten
+            qc = R.qc;
+            n = R.n;
         } else {
             qc = lds_fr(table, T_QC_A);
+            R.qc = qc;
+            R.n = n;
         }
-        R.qc = qc;
-        R.n = n;
         R.y = bound_item(fr_sub(qc, x.f), n, R.b);  // range.rs:102
         if (A.result_vars) {
             const uint64_t first = RAGGED ? O.var_off[item] : item * (uint64_t)(n + 261 + xo(A));
@@ -373,11 +392,14 @@ struct DecompositionGD {
         const uint4 *pow2;
     };
     static constexpr int kInv = 1;
-    __device__ static Fr inv_element(const Args &A, uint64_t item, uint32_t) {
-        FrVec x;
-        x.v[0] = A.witness[item * 2];
-        x.v[1] = A.witness[item * 2 + 1];
-        return bound_u(x.f, fr_from_mont(x.f), A.n);
+    static constexpr int kInvGroup = 4;  // elements a lane of the pre-pass fetches per round trip (inv_combine is register-hungry here)
+    __device__ static void inv_operands(const Args &A, const EmitOut &, uint64_t item, uint32_t, FrVec &p, FrVec &q, uint32_t &) {
+        p.v[0] = A.witness[item * 2];
+        p.v[1] = A.witness[item * 2 + 1];
+        q.f = p.f;
+    }
+    __device__ static Fr inv_combine(const Args &A, uint32_t, const Fr &x, const Fr &, uint32_t) {
+        return bound_u(x, fr_from_mont(x), A.n);
     }
     // the block shifted by one variable: z sits at (259 + n) - 1
     __device__ static uint4 *inv_slot(const Args &A, const EmitOut &O, uint64_t item, uint32_t) {
@@ -427,23 +449,32 @@ struct DecompositionGD {
 
 // plan of a ragged max_bound batch: ladder bits and row/variable counts per item (range.rs:87-90)
 __global__ __launch_bounds__(kThreads) void max_bound_plan_kernel(const uint4 *max_range, uint64_t batch, const uint4 *pow2,
-                                                                 uint32_t *num_bits, uint32_t *rows, uint32_t *vars) {
-    const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (i >= batch) return;
-    FrVec m, p;
-    m.v[0] = max_range[i * 2];
-    m.v[1] = max_range[i * 2 + 1];
-    const Fr mm1 = fr_sub(m.f, fr_one());
-    uint32_t nb = raw_bit_length(fr_from_mont(mm1));  // bits_count, range.rs:173-181
-    if (nb < 1) nb = 1;
-    // bits_count(BlsScalar::pow_of_2(nb)), range.rs:187-188 (nb <= 255)
-    p.v[0] = pow2[nb * 2];
-    p.v[1] = pow2[nb * 2 + 1];
-    uint32_t n = raw_bit_length(fr_from_mont(p.f));
-    if (n < 1) n = 1;
-    num_bits[i] = n;
-    rows[i] = 2 * n + 5;
-    vars[i] = n + 262;
+                                                                 uint32_t *num_bits, uint32_t *rows, uint32_t *vars,
+                                                                 uint64_t *blk_rows, uint64_t *blk_vars) {
+    uint64_t sr = 0, sv = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x * 4 + k;
+        if (i < batch) {
+            FrVec m, p;
+            m.v[0] = max_range[i * 2];
+            m.v[1] = max_range[i * 2 + 1];
+            const Fr mm1 = fr_sub(m.f, fr_one());
+            uint32_t nb = raw_bit_length(fr_from_mont(mm1));  // bits_count, range.rs:173-181
+            if (nb < 1) nb = 1;
+            // bits_count(BlsScalar::pow_of_2(nb)), range.rs:187-188 (nb <= 255)
+            p.v[0] = pow2[nb * 2];
+            p.v[1] = pow2[nb * 2 + 1];
+            uint32_t n = raw_bit_length(fr_from_mont(p.f));
+            if (n < 1) n = 1;
+            num_bits[i] = n;
+            rows[i] = 2 * n + 5;
+            vars[i] = n + 262;
+            sr += 2 * n + 5;
+            sv += n + 262;
+        }
+    }
+    plan_block_sums(sr, sv, blk_rows, blk_vars);  // the block sums of the prefix-sum pass, same launch
 }
 
 // engine table: mont(2^i) by repeated doubling (one thread; runs once per engine)

@@ -156,9 +156,12 @@ struct MaybeEqualGD {
     struct alignas(16) ItemRec { Fr u; };
     static constexpr int W = 256;
     static constexpr int kInv = 1;
-    __device__ static Fr inv_element(const Args &A, uint64_t item, uint32_t) {
-        return fr_sub(load_fr(A.a_val, item), load_fr(A.b_val, item));  // scalar.rs:121
+    static constexpr int kInvGroup = PG_INV_GRP;
+    __device__ static void inv_operands(const Args &A, const EmitOut &, uint64_t item, uint32_t, FrVec &p, FrVec &q, uint32_t &) {
+        p.f = load_fr(A.a_val, item);
+        q.f = load_fr(A.b_val, item);
     }
+    __device__ static Fr inv_combine(const Args &, uint32_t, const Fr &p, const Fr &q, uint32_t) { return fr_sub(p, q); }  // scalar.rs:121
     // variables of an item: u, z, y -- z is the pre-pass's (scalar.rs:122-123)
     __device__ static uint4 *inv_slot(const Args &, const EmitOut &O, uint64_t item, uint32_t) { return O.vars + 2 * (item * 3 + 1); }
     __device__ static bool is_inv_slot(const Args &, const ItemRec &, uint32_t k) { return k == 1; }
@@ -193,7 +196,12 @@ struct IsNonZeroGD {
     struct alignas(16) ItemRec { Fr value; };
     static constexpr int W = 256;
     static constexpr int kInv = 1;
-    __device__ static Fr inv_element(const Args &A, uint64_t item, uint32_t) { return load_fr(A.b_val, item); }  // scalar.rs:73
+    static constexpr int kInvGroup = PG_INV_GRP;
+    __device__ static void inv_operands(const Args &A, const EmitOut &, uint64_t item, uint32_t, FrVec &p, FrVec &q, uint32_t &) {
+        p.f = load_fr(A.b_val, item);  // scalar.rs:73
+        q.f = p.f;
+    }
+    __device__ static Fr inv_combine(const Args &, uint32_t, const Fr &p, const Fr &, uint32_t) { return p; }
     // variables of an item: var_assigned, inv, one -- an item whose value is 0 stopped before `inv` existed (scalar.rs:79)
     __device__ static uint4 *inv_slot(const Args &A, const EmitOut &O, uint64_t item, uint32_t) {
         if (fr_is_zero(load_fr(A.b_val, item))) return nullptr;
@@ -201,7 +209,9 @@ struct IsNonZeroGD {
     }
     __device__ static bool is_inv_slot(const Args &, const ItemRec &, uint32_t k) { return k == 1; }
     static constexpr bool kRagged = true, kRecInRows = false, kUsePow2 = false;
+    static constexpr uint32_t kUniformRows = 3, kUniformVars = 3;  // an item whose value is not 0
     __device__ static void fill_table(const Args &, uint4 *, uint32_t) {}
+    __device__ static void item_rows(const Args &, const EmitOut &, uint64_t, const uint4 *, ItemRec &) {}
     __device__ static void item(const Args &A, const EmitOut &, uint64_t item, const uint4 *, ItemRec &R) {
         R.value = load_fr(A.b_val, item);
     }
@@ -222,15 +232,25 @@ struct IsNonZeroGD {
     }
 };
 
+// plan kernels: per-item counts + the block sums of the prefix-sum pass in one launch (grid = blocks of kScanBlock items)
 __global__ __launch_bounds__(kThreads) void is_non_zero_plan_kernel(const uint4 *value, uint64_t batch, uint32_t *rows,
-                                                                   uint32_t *vars, uint8_t *err_mask, uint32_t *err_count) {
-    const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (i >= batch) return;
-    const bool err = fr_is_zero(load_fr(value, i));
-    rows[i] = err ? 1 : 3;
-    vars[i] = err ? 1 : 3;
-    if (err_mask) err_mask[i] = err ? 1 : 0;
-    if (err) atomicAdd(err_count, 1u);
+                                                                   uint32_t *vars, uint8_t *err_mask, uint32_t *err_count,
+                                                                   uint64_t *blk_rows, uint64_t *blk_vars) {
+    uint64_t sr = 0, sv = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x * 4 + k;
+        if (i < batch) {
+            const bool err = fr_is_zero(load_fr(value, i));
+            rows[i] = err ? 1 : 3;
+            vars[i] = err ? 1 : 3;
+            sr += err ? 1 : 3;
+            sv += err ? 1 : 3;
+            if (err_mask) err_mask[i] = err ? 1 : 0;
+            if (err) atomicAdd(err_count, 1u);
+        }
+    }
+    plan_block_sums(sr, sv, blk_rows, blk_vars);
 }
 
 // ---- the fused mix (BASELINE config C3) ---------------------------------------------
@@ -244,19 +264,32 @@ struct ScalarMixArgs {
 
 struct ScalarMixGD {
     using Args = ScalarMixArgs;
-    // every variable of the item, in emission order, is computed once by the item's lane: the variable sweep is then
-    // a plain LDS -> HBM copy (a wave that met one slot needing arithmetic would pay it for all 64 lanes)
+    // what the item's lane computes once: the five inputs and the four derived values that are not constants (the
+    // variable sweep is then an LDS -> HBM copy: a wave that met one slot needing arithmetic would pay it for all 64
+    // lanes).  Kept to 304 bytes: the records bound how many workgroups share a CU, and the variable-table launch lives
+    // on that overlap (7 per CU instead of 4 with one slot per variable).
     struct alignas(16) ItemRec {
-        Fr vals[15];
-        uint32_t err, pad[3];
+        Fr d[9];  // v y s a b | sy oms out | u
+        uint32_t err, yeq, pad[2];
     };
 #ifndef PG_MIX_W
 #define PG_MIX_W 64
 #endif
     static constexpr int W = PG_MIX_W;
     static constexpr int kInv = 2;
-    __device__ static Fr inv_element(const Args &A, uint64_t item, uint32_t e) {
-        return e == 0 ? load_fr(A.v, item) : fr_sub(load_fr(A.a, item), load_fr(A.b, item));
+    static constexpr int kInvGroup = PG_INV_GRP;
+    // element 0: v (is_non_zero, scalar.rs:73); element 1: a - b (maybe_equal, scalar.rs:121) -- pointers selected, not branches
+    __device__ static void inv_operands(const Args &A, const EmitOut &, uint64_t item, uint32_t e, FrVec &p, FrVec &q, uint32_t &) {
+        const uint4 *pp = e ? A.a : A.v, *qp = e ? A.b : A.v;
+        p.f = load_fr(pp, item);
+        q.f = load_fr(qp, item);
+    }
+    __device__ static Fr inv_combine(const Args &, uint32_t e, const Fr &p, const Fr &q, uint32_t) {
+        const Fr d = fr_sub(p, q);
+        Fr r;
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.l[i] = e ? d.l[i] : p.l[i];
+        return r;
     }
     // item variables: [v y s a b | va inv one | one' sy oms out | u z yeq]; an item with v = 0 has no inv / one
     __device__ static uint4 *inv_slot(const Args &A, const EmitOut &O, uint64_t item, uint32_t e) {
@@ -269,28 +302,35 @@ struct ScalarMixGD {
         return (!R.err && k == 6) || k == 5 + nz + 4 + 1;
     }
     static constexpr bool kRagged = true, kRecInRows = true, kUsePow2 = false;
+    static constexpr uint32_t kUniformRows = 10, kUniformVars = 15;  // an item whose v is not 0
+    // full-shape items: selectors are a function of the row, wires are the item's own variables (+ zero_var)
+    static constexpr bool kPeriodic = true;
+    // emitted as two launches (emit.hpp, EmitMode): the rows -- which depend on one bit per item -- as a lean store-only
+    // launch over tiles of kRowsW items, then the variable table
+    static constexpr bool kSplit = true;
+    static constexpr int kRowsW = 256;
+    struct RowRec {
+        uint32_t err;
+    };
     __device__ static void fill_table(const Args &, uint4 *, uint32_t) {}
+    // the rows of an item depend on one bit: did is_non_zero stop at its error (scalar.rs:79)?
+    template <class R>
+    __device__ static void item_rows(const Args &A, const EmitOut &, uint64_t item, const uint4 *, R &rec) {
+        rec.err = fr_is_zero(load_fr(A.v, item)) ? 1u : 0u;
+    }
     __device__ static void item(const Args &A, const EmitOut &O, uint64_t item, const uint4 *, ItemRec &R) {
         const Fr v = load_fr(A.v, item), y = load_fr(A.y, item), s = load_fr(A.s, item), a = load_fr(A.a, item),
                  b = load_fr(A.b, item);
         const uint32_t err = fr_is_zero(v) ? 1u : 0u;
-        R.err = err;
-        uint32_t k = 0;
-        R.vals[k++] = v; R.vals[k++] = y; R.vals[k++] = s; R.vals[k++] = a; R.vals[k++] = b;  // 5 x add_input
-        R.vals[k++] = v;                                                                     // var_assigned, scalar.rs:69
-        if (!err) {
-            R.vals[k++] = fr_zero();                                                         // inverse: the pre-pass's slot
-            R.vals[k++] = fr_one();                                                          // one, scalar.rs:83
-        }
+        R.err = err;  // what item_rows writes when there are rows to emit; an EMIT_VARS launch has no item_rows
+        R.d[0] = v; R.d[1] = y; R.d[2] = s; R.d[3] = a; R.d[4] = b;  // 5 x add_input (and var_assigned = v, scalar.rs:69)
         const Fr sy = fr_mul(y, s), oms = fr_sub(fr_one(), s);
-        R.vals[k++] = fr_one();                                                              // scalar.rs:41
-        R.vals[k++] = sy;                                                                    // scalar.rs:43
-        R.vals[k++] = oms;                                                                   // scalar.rs:45-50
-        R.vals[k++] = fr_add(sy, oms);                                                       // scalar.rs:53-58
+        R.d[5] = sy;                                                  // scalar.rs:43
+        R.d[6] = oms;                                                 // scalar.rs:45-50
+        R.d[7] = fr_add(sy, oms);                                     // scalar.rs:53-58
         const Fr u = fr_sub(a, b);
-        R.vals[k++] = u;                                                                     // scalar.rs:111-117
-        R.vals[k++] = fr_zero();                                                             // z: the pre-pass's slot
-        R.vals[k++] = fr_is_zero(u) ? fr_one() : fr_zero();                                  // scalar.rs:126
+        R.d[8] = u;                                                   // scalar.rs:111-117
+        R.yeq = fr_is_zero(u) ? 1u : 0u;                              // y = 1 - u z, scalar.rs:126
         if (A.result_vars) {
             const uint64_t vb = O.var_base + O.var_off[item];
             const uint64_t nz = err ? 1 : 3;
@@ -298,35 +338,59 @@ struct ScalarMixGD {
             A.result_vars[2 * item + 1] = vb + 5 + nz + 4 + 2;
         }
     }
-    __device__ static void row(const ItemRec &R, uint64_t vbase, uint64_t zero_var, uint32_t j, RowOut &r) {
+    template <class R_>
+    __device__ static void row(const R_ &R, uint64_t vbase, uint64_t zero_var, uint32_t j, RowOut &r) {
         const uint32_t nz = R.err ? 1 : 3;
         if (j < nz) is_non_zero_row(j, vbase + 0, vbase + 5, zero_var, r);
         else if (j < nz + 4) select_one_row(j - nz, vbase + 1, vbase + 2, vbase + 5 + nz, r);
         else maybe_equal_row(j - nz - 4, vbase + 3, vbase + 4, vbase + 5 + nz + 4, r);
     }
-    __device__ static void selectors(const Args &, const ItemRec &R, uint32_t j, const uint4 *table, uint32_t h, uint4 out[5]) {
+    template <class R_>
+    __device__ static void selectors(const Args &, const R_ &R, uint32_t j, const uint4 *table, uint32_t h, uint4 out[5]) {
         RowOut r;
         row(R, 0, 0, j, r);
         row_values(r, table, h, out);
     }
-    __device__ static void wires(const Args &, const EmitOut &O, const ItemRec &R, uint64_t, uint64_t vbase, uint32_t j,
+    template <class R_>
+    __device__ static void wires(const Args &, const EmitOut &O, const R_ &R, uint64_t, uint64_t vbase, uint32_t j,
                                  uint64_t out[3]) {
         RowOut r;
         row(R, vbase, O.zero_var, j, r);
         out[0] = r.w[0]; out[1] = r.w[1]; out[2] = r.w[2];
     }
-    __device__ static Fr var_value(const Args &, const ItemRec &R, const uint4 *, uint32_t k) { return R.vals[k]; }
+    // variable kc of a full-shape item: [v y s a b | va inv one | one' sy oms out | u z yeq]
+    __device__ static Fr var_value_full(const Args &, const ItemRec &R, const uint4 *, uint32_t kc) {
+        if (kc < 5) return R.d[kc];
+        if (kc == 5) return R.d[0];                          // var_assigned
+        if (kc == 7 || kc == 8) return fr_one();             // scalar.rs:83, :41
+        if (kc >= 9 && kc <= 12) return R.d[kc - 4];         // sy oms out u
+        if (kc == 14) return R.yeq ? fr_one() : fr_zero();
+        return fr_zero();                                    // 6, 13: the pre-pass's slots, never asked for
+    }
+    // an item that stopped at its error has no inv / one: its variables 6.. are the full shape's 8..
+    __device__ static Fr var_value(const Args &A, const ItemRec &R, const uint4 *t, uint32_t k) {
+        return var_value_full(A, R, t, (R.err && k >= 6) ? k + 2 : k);
+    }
 };
 
 __global__ __launch_bounds__(kThreads) void scalar_mix_plan_kernel(const uint4 *v, uint64_t batch, uint32_t *rows, uint32_t *vars,
-                                                                  uint8_t *err_mask, uint32_t *err_count) {
-    const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (i >= batch) return;
-    const bool err = fr_is_zero(load_fr(v, i));
-    rows[i] = err ? 8 : 10;
-    vars[i] = err ? 13 : 15;
-    if (err_mask) err_mask[i] = err ? 1 : 0;
-    if (err) atomicAdd(err_count, 1u);
+                                                                  uint8_t *err_mask, uint32_t *err_count, uint64_t *blk_rows,
+                                                                  uint64_t *blk_vars) {
+    uint64_t sr = 0, sv = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x * 4 + k;
+        if (i < batch) {
+            const bool err = fr_is_zero(load_fr(v, i));
+            rows[i] = err ? 8 : 10;
+            vars[i] = err ? 13 : 15;
+            sr += err ? 8 : 10;
+            sv += err ? 13 : 15;
+            if (err_mask) err_mask[i] = err ? 1 : 0;
+            if (err) atomicAdd(err_count, 1u);
+        }
+    }
+    plan_block_sums(sr, sv, blk_rows, blk_vars);
 }
 
 }  // namespace pg

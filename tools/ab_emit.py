@@ -15,11 +15,21 @@ VDIR = os.path.join(ROOT, "tools", "variants")
 
 # the build options that exist in the tree today (every one of them was measured; DESIGN.md section 3 has the numbers)
 VARIANTS = {
+    "r1": None,  # round 1's library, built by hand from `git archive 937331d` (not rebuilt by `build`)
     "base": [],
     "sequential_prepass": ["-DPG_SEQUENTIAL_PREPASS"],
     "invert_fermat": ["-DPG_INVERT_FERMAT"],
     "sequential_fermat": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_INVERT_FERMAT"],
+    "no_periodic": ["-DPG_NO_PERIODIC"],
+    "rows_wgs_0": ["-DPG_ROWS_WGS_PER_CU=0"],
+    "rows_wgs_2": ["-DPG_ROWS_WGS_PER_CU=2"],
+    "rows_wgs_4": ["-DPG_ROWS_WGS_PER_CU=4"],
+    "inv_grp4": ["-DPG_INV_GRP=4"],
+    "inv_grp16": ["-DPG_INV_GRP=16"],
     "inv_lanes512": ["-DPG_INV_LANES_PER_CU=512"],
+    "inv_lanes512_grp4": ["-DPG_INV_LANES_PER_CU=512", "-DPG_INV_GRP=4"],
+    "inv_lanes1024": ["-DPG_INV_LANES_PER_CU=1024"],
+    "inv_lanes1024_grp4": ["-DPG_INV_LANES_PER_CU=1024", "-DPG_INV_GRP=4"],
     "inv_lanes128_cap64": ["-DPG_INV_LANES_PER_CU=128", "-DPG_INV_MAX_PER_LANE=64"],
     "inv_cap16": ["-DPG_INV_MAX_PER_LANE=16"],
     "inv_cap8": ["-DPG_INV_MAX_PER_LANE=8"],
@@ -44,7 +54,7 @@ def build(only=None):
     from plonk_gadgets_amd import build as b
     os.makedirs(VDIR, exist_ok=True)
     for name, flags in VARIANTS.items():
-        if only and name not in only:
+        if flags is None or (only and name not in only):
             continue
         out = os.path.join(VDIR, f"lib_{name}.so")
         b.build(force=True, extra_flags=flags, out=out)
@@ -75,8 +85,9 @@ def run_c3(log2_chunk=20, rounds=4):
             continue
         lib = C.CDLL(path)
         for fn, (r, a) in _lib.SIGNATURES.items():
-            f = getattr(lib, fn)
-            f.restype, f.argtypes = r, a
+            if hasattr(lib, fn):  # an older library lacks the newer entry points
+                f = getattr(lib, fn)
+                f.restype, f.argtypes = r, a
         h = C.c_void_p()
         assert lib.pg_engine_create(0, C.byref(h)) == 0
         lay, nerr = _lib.LayoutC(), C.c_uint64()
@@ -128,8 +139,9 @@ def run_c4(log2_chunk=19, rounds=4):
             continue
         lib = C.CDLL(path)
         for fn, (r, a) in _lib.SIGNATURES.items():
-            f = getattr(lib, fn)
-            f.restype, f.argtypes = r, a
+            if hasattr(lib, fn):  # an older library lacks the newer entry points
+                f = getattr(lib, fn)
+                f.restype, f.argtypes = r, a
         h = C.c_void_p()
         assert lib.pg_engine_create(0, C.byref(h)) == 0
         lay = _lib.LayoutC()
@@ -181,8 +193,9 @@ def run(log2_chunk=18, rounds=4, mn_int=0, mx_int=2**254):
             continue
         lib = C.CDLL(path)
         for fn, (r, a) in _lib.SIGNATURES.items():
-            f = getattr(lib, fn)
-            f.restype, f.argtypes = r, a
+            if hasattr(lib, fn):  # an older library lacks the newer entry points
+                f = getattr(lib, fn)
+                f.restype, f.argtypes = r, a
         h = C.c_void_p()
         assert lib.pg_engine_create(0, C.byref(h)) == 0
         libs[name] = (lib, h)
