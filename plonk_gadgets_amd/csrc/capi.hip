@@ -256,13 +256,13 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
     const uint32_t max_blocks = (uint32_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
     if constexpr (kSplit) {
         const pg::EmitOut R = make_out(c, batch, GD::kRowsW, gate_base, var_base, zero_var, row_off, var_off);
-        // Beside the pre-pass the rows launch is held to PG_ROWS_WGS_PER_CU workgroups per CU (by asking for LDS it does not
-        // use): a pure streaming writer sustains the same bandwidth at 3 as at 8, but at 8 its waves own every SIMD's
-        // registers and the pre-pass's workgroups (one fat wave per SIMD) only become resident as the first round of
-        // rows workgroups retires -- a hundred microseconds in, which then pushes the pre-pass past the end of the rows.
+        // PG_ROWS_WGS_PER_CU > 0 (A/B builds): hold the rows launch to that many workgroups per CU, by asking for LDS it does
+        // not use, to leave registers for the pre-pass's fat waves.  Measured on the fused mix (tools/ab_emit.py): 2, 3 and
+        // 4 per CU all LOSE (0.77 / 0.79 / 0.82 ms against 0.74 unlimited) -- unlike the big-item emitters this launch needs
+        // its full residency to reach 7 TB/s, and the pre-pass gains less than the rows lose.  Default: off.
         uint32_t pad = 0;
 #ifndef PG_ROWS_WGS_PER_CU
-#define PG_ROWS_WGS_PER_CU 3
+#define PG_ROWS_WGS_PER_CU 0
 #endif
         if (side && PG_ROWS_WGS_PER_CU > 0) {
             static const size_t static_lds = [] {
@@ -275,7 +275,13 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
         }
         hipLaunchKernelGGL((pg::emit_kernel<GD, pg::EMIT_ROWS>), dim3(R.tiles < max_blocks ? R.tiles : max_blocks), dim3(pg::kThreads), pad,
                            st, A, R);
-        hipLaunchKernelGGL((pg::emit_kernel<GD, pg::EMIT_VARS>), dim3(O.tiles < max_blocks ? O.tiles : max_blocks), dim3(pg::kThreads), 0,
+        // the variable-table launch of a small-item gadget: a tile is a few microseconds of work, so workgroups stay and
+        // stride over the tiles instead of paying a dispatch (kernel arguments, constant table, first barrier) per tile
+#ifndef PG_VARS_BLOCKS_PER_CU
+#define PG_VARS_BLOCKS_PER_CU 8
+#endif
+        const uint32_t vars_blocks = (uint32_t)e->num_cus * PG_VARS_BLOCKS_PER_CU;
+        hipLaunchKernelGGL((pg::emit_kernel<GD, pg::EMIT_VARS>), dim3(O.tiles < vars_blocks ? O.tiles : vars_blocks), dim3(pg::kThreads), 0,
                            st, A, O);
     } else {
         hipLaunchKernelGGL(pg::emit_kernel<GD>, dim3(O.tiles < max_blocks ? O.tiles : max_blocks), dim3(pg::kThreads), 0, st, A, O);

@@ -21,6 +21,12 @@ VARIANTS = {
     "invert_fermat": ["-DPG_INVERT_FERMAT"],
     "sequential_fermat": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_INVERT_FERMAT"],
     "no_periodic": ["-DPG_NO_PERIODIC"],
+    "seq_l512_g4": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_INV_LANES_PER_CU=512", "-DPG_INV_GRP=4"],
+    "seq_g4": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_INV_GRP=4"],
+    "seq_l512": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_INV_LANES_PER_CU=512"],
+    "vars_blocks_64": ["-DPG_VARS_BLOCKS_PER_CU=64"],
+    "vars_blocks_16": ["-DPG_VARS_BLOCKS_PER_CU=16"],
+    "vars_blocks_6": ["-DPG_VARS_BLOCKS_PER_CU=6"],
     "rows_wgs_0": ["-DPG_ROWS_WGS_PER_CU=0"],
     "rows_wgs_2": ["-DPG_ROWS_WGS_PER_CU=2"],
     "rows_wgs_4": ["-DPG_ROWS_WGS_PER_CU=4"],
@@ -44,6 +50,7 @@ VARIANTS = {
     "seq_mix_w128": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_MIX_W=128"],
     "mb_w32": ["-DPG_MB_W=32"],
     "mb_w24": ["-DPG_MB_W=24"],
+    "mb_w8": ["-DPG_MB_W=8"],
     "rc_w64": ["-DPG_RC_W=64"],
     "rc_w128": ["-DPG_RC_W=128"],
     "grid8": ["-DPG_GRID_BLOCKS_PER_CU=8"],

@@ -4,7 +4,7 @@
 # (PMC passes never combined with other trace domains), into gpurun_out/prof_<round>/.  tools/summarize_profiles.py
 # turns them into profiles/<round>_*.csv + profiles/pmc_summary.json.
 set -u
-R=${1:-r01}
+R=${1:-r02}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT

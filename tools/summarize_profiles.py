@@ -8,7 +8,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
 DST = os.path.join(ROOT, "profiles")
 summary = {}
@@ -29,15 +29,17 @@ for w in ("c2", "c3", "c4"):
     vals = {}
     for kind, cn in (("pmcw", "WRITE_SIZE"), ("pmcf", "FETCH_SIZE")):
         f = newest(os.path.join(SRC, f"{kind}_{w}", "*", "*counter_collection.csv"))
-        keep = [r for r in csv.DictReader(open(f)) if "emit_kernel" in r["Kernel_Name"] or "batch_invert" in r["Kernel_Name"]]
+        # every kernel of the one step the PMC pass runs (steps = 1, warmup = 0): the emit launch(es), the inversion
+        # pre-pass, the plan and its prefix-sum launch
+        keep = [r for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in ("emit_kernel", "batch_invert", "plan_kernel", "scan_"))]
         with open(os.path.join(DST, f"{R}_{w}_pmc_{cn.lower()}.csv"), "w") as o:
             wr = csv.DictWriter(o, fieldnames=list(keep[0].keys()))
             wr.writeheader()
             wr.writerows(keep)
-        vals[cn] = [float(r["Counter_Value"]) for r in keep if "emit_kernel" in r["Kernel_Name"]][0]
+        vals[cn] = sum(float(r["Counter_Value"]) for r in keep)
     # MI355X_MICROARCH.md: WRITE_SIZE exact (KB) for 16-B-per-lane streaming stores; FETCH_SIZE counts half the bytes
     # of wide streaming reads on gfx950 -> doubled
-    summary[w] = {str(chunk): {"kernel": "pg::emit_kernel", "write_size_kb": vals["WRITE_SIZE"],
+    summary[w] = {str(chunk): {"kernel": "every kernel of one step (emit launches + pre-pass + plan)", "write_size_kb": vals["WRITE_SIZE"],
                                "fetch_size_kb_raw": vals["FETCH_SIZE"],
                                "hbm_bytes_per_launch": (vals["WRITE_SIZE"] + 2 * vals["FETCH_SIZE"]) * 1024,
                                "round": R,
