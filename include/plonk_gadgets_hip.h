@@ -46,7 +46,8 @@ typedef enum pg_status {
     PG_ERR_INVALID_ARGUMENT = 2,     /* NULL / misaligned pointer, num_bits > 256 (src/range.rs:134 panics), ... */
     PG_ERR_NO_DEVICE = 3,            /* no gfx950 device / HIP runtime failure at engine creation */
     PG_ERR_HIP = 4,                  /* a HIP call failed; pg_last_error() has the text */
-    PG_ERR_CAPACITY = 5              /* composer buffers too small for the append */
+    PG_ERR_CAPACITY = 5,             /* composer buffers too small for the append */
+    PG_ERR_BAD_ENCODING = 6          /* pg_scalars_from_canonical_batch: some 32-byte encodings are >= q (BlsScalar::from_bytes -> Err) */
 } pg_status;
 
 typedef struct pg_scalar { uint64_t l[4]; } pg_scalar; /* BlsScalar */
@@ -112,7 +113,8 @@ uint64_t pg_num_bits_closest_power_of_two(const pg_scalar *s); /* src/range.rs:1
  * src/range.rs:162 reads back with to_bytes); the kernels want Montgomery limbs.  Both conversions in bulk, device to
  * device, 16-byte aligned buffers of 32 * batch bytes:
  *   from_canonical  BlsScalar::from_bytes per element; an encoding >= q (from_bytes returns Err) becomes 0, is flagged in
- *                   d_bad_mask (may be NULL) and counted; PG_ERR_INVALID_ARGUMENT if any (synchronises `stream`)
+ *                   d_bad_mask (may be NULL) and counted; PG_ERR_BAD_ENCODING if any -- the output is complete all the
+ *                   same -- while PG_ERR_INVALID_ARGUMENT keeps meaning a bad pointer (synchronises `stream`)
  *   to_canonical    BlsScalar::to_bytes per element */
 pg_status pg_scalars_from_canonical_batch(pg_engine *e, const void *d_bytes, uint64_t batch, pg_scalar *d_out,
                                           uint8_t *d_bad_mask, uint64_t *bad_count /* may be NULL */, void *stream);
@@ -312,7 +314,8 @@ pg_status pg_composer_range_check_batch(pg_composer *c, const pg_scalar *min_ran
 pg_status pg_composer_add_input_batch(pg_composer *c, const pg_scalar *d_scalars, uint64_t batch, pg_variable *first_var);
 /* the loop  for i { range_check(composer, min, max, AllocatedScalar { var: d_witness_var[i], scalar: d_witness[i] }) }
  * on witnesses allocated before (device arrays; every d_witness_var[i] must be a Variable of this composer -- the
- * reference panics on an unknown one, here the row then fails pg_composer_check) */
+ * reference panics on an unknown one; here EVERY batched append that takes Variables checks its arrays on the device
+ * first (one small reduction and one host synchronisation) and returns PG_ERR_INVALID_ARGUMENT with nothing appended) */
 pg_status pg_composer_range_check_allocated_batch(pg_composer *c, const pg_scalar *min_range, const pg_scalar *max_range,
                                                   const pg_variable *d_witness_var, const pg_scalar *d_witness,
                                                   uint64_t batch, pg_variable *d_result_vars);
@@ -347,7 +350,8 @@ pg_status pg_composer_maybe_equal_batch(pg_composer *c, const pg_variable *d_a_v
  *   add / mul:             for i { out[i] = composer.add((q_l, a[i]), (q_r, b[i]), q_c, None) }  /  mul(q_m, a[i], b[i], q_c, None)
  *   constrain_to_constant: for i { composer.constrain_to_constant(a[i], constant, None) }
  *   boolean_gate:          for i { composer.boolean_gate(a[i]) }
- * every index must be a Variable of this composer (as the reference panics on an unknown one; not checked here). */
+ * every index must be a Variable of this composer (the reference panics on an unknown one; here the arrays are checked on
+ * the device first: PG_ERR_INVALID_ARGUMENT, nothing appended). */
 pg_status pg_composer_poly_gate_batch(pg_composer *c, const pg_variable *d_a, const pg_variable *d_b, const pg_variable *d_c,
                                       const pg_scalar *q_m, const pg_scalar *q_l, const pg_scalar *q_r, const pg_scalar *q_o,
                                       const pg_scalar *q_c, uint64_t batch);
@@ -404,6 +408,10 @@ pg_status pg_composer_materialize(pg_composer *c, const pg_full_columns *out);
  * map to themselves.  padded_n >= circuit_size (the prover pads to a power of two).  Enqueued on the composer's
  * stream (one host synchronisation inside, to size the sorted list); scratch is kept by the composer and only grows. */
 pg_status pg_composer_permutation(pg_composer *c, uint64_t padded_n, uint64_t *d_sigma);
+/* Size of the sorted list of wire positions that refer to Variables created outside their own item (plus every position
+ * of rows appended by single calls) for the NEXT pg_composer_permutation call; 0 = the composer's own estimate.  A
+ * figure that is too small costs a second pass (the first reports the size needed), never a wrong result. */
+pg_status pg_composer_permutation_reserve(pg_composer *c, uint64_t sparse_positions);
 
 /* Satisfiability of the rows of ONE batch call whose wires all point into its own variables (the allocate-style
  * batches: range_check, max_bound, scalar_mix): q_m a b + q_l a + q_r b + q_o c + q_c = 0 on every row, with

@@ -165,6 +165,7 @@ SIGNATURES = {
     "pg_composer_dense_pi": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pg_composer_materialize": (C.c_int, [C.c_void_p, _P(FullColumnsC)]),
     "pg_composer_permutation": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "pg_composer_permutation_reserve": (C.c_int, [C.c_void_p, C.c_uint64]),
     "pg_check_rows": (C.c_int, [C.c_void_p, _P(ColumnsC), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _P(C.c_int64),
                                 C.c_void_p]),
     "pg_shard_range": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, _P(C.c_uint64), _P(C.c_uint64)]),

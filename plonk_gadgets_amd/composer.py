@@ -289,6 +289,10 @@ class StandardComposer:
         _chk(self._lib.pg_composer_sync(self._h), "sync")
         return cols.to_numpy()
 
+    def permutation_reserve(self, sparse_positions: int):
+        """first-pass size of the permutation's sorted list of 'foreign' wire positions (0: the composer's estimate)"""
+        _chk(self._lib.pg_composer_permutation_reserve(self._h, sparse_positions), "pg_composer_permutation_reserve")
+
     def permutation(self, padded_n: int | None = None) -> torch.Tensor:
         """sigma as int64[4, padded_n]; entry [w, i] = w' * padded_n + i' (next position of the Variable)"""
         n = self.circuit_size()

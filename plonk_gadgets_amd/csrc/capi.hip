@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -351,6 +352,7 @@ const char *pg_status_string(pg_status s) {
         case PG_ERR_NO_DEVICE: return "no usable gfx950 device";
         case PG_ERR_HIP: return "HIP runtime error";
         case PG_ERR_CAPACITY: return "composer capacity exceeded";
+        case PG_ERR_BAD_ENCODING: return "encoding not below the modulus";
     }
     return "unknown status";
 }
@@ -450,7 +452,7 @@ pg_status pg_scalars_from_canonical_batch(pg_engine *e, const void *d_bytes, uin
     PG_HIP_TRY(hipStreamSynchronize(st));
     const uint32_t bad = e->h_plan->errs;
     if (bad_count) *bad_count = bad;
-    if (bad) return fail(PG_ERR_INVALID_ARGUMENT, std::to_string(bad) + " encoding(s) are not below the modulus");
+    if (bad) return fail(PG_ERR_BAD_ENCODING, std::to_string(bad) + " encoding(s) are not below the modulus");
     return PG_OK;
 }
 

@@ -103,6 +103,19 @@ __global__ __launch_bounds__(kThreads) void gate_batch_kernel(const GateBatch B,
     }
 }
 
+// largest entry of a device array of Variables -> *out (atomicMax; *out starts at 0): the batched appends check it
+// against the composer's variable count before anything is appended (the reference panics on an unknown Variable)
+__global__ __launch_bounds__(kThreads) void max_variable_kernel(const uint64_t *a, uint64_t n, unsigned long long *out) {
+    unsigned long long m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kThreads) m = a[i] > m ? a[i] : m;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(m, d, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 // small host blob -> device staging buffer (inputs of single-gadget calls: scalars, Variables, offsets)
 struct StageBlob {
     uint64_t w[40];

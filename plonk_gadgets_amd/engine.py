@@ -164,7 +164,7 @@ class Engine:
         n = C.c_uint64()
         st = self._lib.pg_scalars_from_canonical_batch(self._h, raw.data_ptr(), raw.shape[0], out.data_ptr(), bad.data_ptr(),
                                                        C.byref(n), self._stream())
-        if st not in (0, 2):
+        if st not in (0, 6):  # 6 = PG_ERR_BAD_ENCODING: flagged items, reported through the mask and the count
             raise PgError(st, "pg_scalars_from_canonical_batch")
         return out, bad, int(n.value)
 

@@ -426,22 +426,18 @@ def test_allocated_batch_on_the_composer(engine):
     _sigma_properties(dev, padded)
 
 
-def test_permutation_sparse_list_regrows():
-    """PG_PERM_FIRST_CAP=16: the sorted list starts far too short, the witness references inside the items overflow it,
-    and the pass runs a second time with the reported size (own process: the knob is read once)"""
-    import os
-    import subprocess
-    import sys
-    code = ("import numpy as np, plonk_gadgets_amd as pg, tests.test_gpu_composer as t\n"
-            "dev, ora = t._allocated_batch_case(pg.Engine(0), batch=300, seed=9)\n"
-            "n = dev.circuit_size(); padded = 1 << (n - 1).bit_length()\n"
-            "assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded))\n"
-            "assert np.array_equal(dev.permutation(n).cpu().numpy().view(np.uint64), ora.sigma(n))\n"
-            "print('regrow ok')\n")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PG_PERM_FIRST_CAP="16", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "regrow ok" in out.stdout, out.stdout + out.stderr
+def test_permutation_sparse_list_regrows(engine):
+    """pg_composer_permutation_reserve(16): the sorted list starts far too short, the witness references inside the items
+    overflow it, and the pass runs a second time with the size the first one reported -- same sigma"""
+    dev, ora = _allocated_batch_case(engine, batch=300, seed=9)
+    n = dev.circuit_size()
+    padded = 1 << (n - 1).bit_length()
+    dev.permutation_reserve(16)
+    assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded))
+    dev.permutation_reserve(16)
+    assert np.array_equal(dev.permutation(n).cpu().numpy().view(np.uint64), ora.sigma(n))
+    dev.permutation_reserve(0)
+    assert np.array_equal(dev.permutation(n).cpu().numpy().view(np.uint64), ora.sigma(n))
 
 
 def test_every_uniform_gadget_as_a_batched_append(engine):
@@ -517,6 +513,43 @@ def test_batched_appends_fail_cleanly(engine):
     assert [dev.value(int(r)).to_int() for r in res] == [1] * 8 and dev.check() == -1
     n = dev.circuit_size()
     _sigma_properties(dev, 1 << (n - 1).bit_length())
+
+
+def test_batched_appends_reject_unknown_variables(engine):
+    """every batched append that takes device arrays of Variables checks them against the composer's variable count
+    first (the reference panics on an unknown Variable): an index past the end -- or an int64 -1 -- is
+    PG_ERR_INVALID_ARGUMENT, nothing is appended, no out-of-bounds read happens, and the composer carries on"""
+    dev = pg.StandardComposer(engine, gate_capacity=1 << 14, var_capacity=1 << 14)
+    wit = torch.from_numpy(synth.uniform_below(8, 2**16, seed=2).view(np.int64)).to("cuda:0")
+    first = dev.add_input_batch(wit)
+    good = torch.arange(first, first + 8, dtype=torch.int64, device="cuda:0")
+    nv = dev.num_variables()
+    for poison in (nv, nv + 12345, -1, 1 << 40):
+        bad = good.clone()
+        bad[5] = poison
+        before = (dev.circuit_size(), dev.num_variables())
+        calls = [
+            lambda: dev.range_check_allocated_batch(S(0), S(2**16), bad, wit),
+            lambda: dev.max_bound_allocated_batch(S(2**16), bad, wit),
+            lambda: dev.scalar_decomposition_batch(16, bad, wit),
+            lambda: dev.conditionally_select_zero_batch(bad, good),
+            lambda: dev.conditionally_select_one_batch(good, bad),
+            lambda: dev.maybe_equal_batch(bad, bad),
+            lambda: dev.is_non_zero_batch(bad),
+            lambda: dev.poly_gate_batch(good, bad, good, S(0), S(1), S(0), S(0), S(0)),
+            lambda: dev.add_batch(S(1), bad, S(1), good, S(0)),
+            lambda: dev.mul_batch(S(1), good, bad, S(0)),
+            lambda: dev.constrain_to_constant_batch(bad, S(7)),
+            lambda: dev.boolean_gate_batch(bad),
+        ]
+        for k, call in enumerate(calls):
+            with pytest.raises(pg.PgError, match="unknown Variable"):
+                call()
+            assert (dev.circuit_size(), dev.num_variables()) == before, (poison, k)
+    # the composer is intact: the same calls with valid Variables append and check
+    res = dev.maybe_equal_batch(good, good)
+    dev.boolean_gate_batch(res)
+    assert [dev.value(int(r)).to_int() for r in res] == [1] * 8 and dev.check() == -1
 
 
 def test_ragged_batched_appends(engine):

@@ -690,3 +690,10 @@ def test_bulk_encodings(engine):
     out2, bad2, nbad2 = engine.scalars_from_canonical(dev(raw2))
     assert nbad2 == 3 and bad2.cpu().numpy().tolist() == [1, 1, 1, 0]
     assert np.array_equal(u64(out2)[:3], np.zeros((3, 4), dtype=np.uint64)) and u64(out2)[3].tolist() == mont_limbs(Q - 1)
+    # flagged encodings have a status of their own (PG_ERR_BAD_ENCODING = 6); an argument error stays an argument error
+    import ctypes as C
+    r2, o2, n = dev(raw2), torch.empty((4, 4), dtype=torch.int64, device="cuda:0"), C.c_uint64()
+    lib, st = engine._lib, engine._stream()
+    assert lib.pg_scalars_from_canonical_batch(engine._h, r2.data_ptr(), 4, o2.data_ptr(), None, C.byref(n), st) == 6 and n.value == 3
+    assert lib.pg_scalars_from_canonical_batch(engine._h, r2.data_ptr() + 8, 3, o2.data_ptr(), None, C.byref(n), st) == 2
+    assert lib.pg_scalars_from_canonical_batch(engine._h, None, 3, o2.data_ptr(), None, C.byref(n), st) == 2
