@@ -273,6 +273,20 @@ pg_status pg_composer_auto_grow(pg_composer *c, int on);
 uint64_t pg_composer_gate_capacity(const pg_composer *c);
 uint64_t pg_composer_var_capacity(const pg_composer *c);
 pg_status pg_composer_sync(pg_composer *c);
+/* The command queue.  The reference's usage is ONE composer call at a time (tests/range_gadgets_tests.rs:29-44:
+ * allocate, range_check, constrain_to_constant, ...); a launch per call would make that loop launch-bound.  Variables
+ * are numbered on the host and their assignments live on the device, so the single calls -- the gate calls below,
+ * pg_allocated_scalar_allocate, pg_range_check, pg_max_bound -- are RECORDED (arguments checked, numbering advanced,
+ * results returned at once) and reach the composer's stream, in order, when anything needs them: pg_composer_sync /
+ * _columns / _copy_out / _read_value / _check / _dense_pi / _materialize / _permutation, any batched append, any other
+ * gadget call, a capacity change, a full queue (8192 entries), or pg_composer_flush.  A run of gate calls is ONE launch
+ * (the outputs of add / mul computed in command order, level by level); a run of `allocate + range_check` (or
+ * max_bound) pairs with the same public bounds -- the reference's loop -- is ONE batched emit launch.
+ *   pg_composer_queue(c, 0) flushes and turns recording off (one launch per call, as before); on by default. */
+pg_status pg_composer_queue(pg_composer *c, int on);
+pg_status pg_composer_flush(pg_composer *c);
+/* entries waiting, flushes so far, launches those flushes took (any pointer may be NULL) */
+pg_status pg_composer_queue_stats(const pg_composer *c, uint64_t *pending, uint64_t *flushes, uint64_t *launches);
 
 /* composer calls used by the gadgets (same argument order as dusk-plonk 0.8; `pi` may be NULL = None) */
 pg_status pg_composer_add_input(pg_composer *c, const pg_scalar *s, pg_variable *out);

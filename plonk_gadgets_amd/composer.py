@@ -69,6 +69,24 @@ class StandardComposer:
     def capacity(self) -> tuple:
         return int(self._lib.pg_composer_gate_capacity(self._h)), int(self._lib.pg_composer_var_capacity(self._h))
 
+    # -- the command queue -----------------------------------------------------------------
+    def queue(self, on: bool = True):
+        """single calls are recorded and flushed as few launches (default) / one launch per call"""
+        _chk(self._lib.pg_composer_queue(self._h, int(on)), "pg_composer_queue")
+
+    def sync(self):
+        """flush what is recorded and wait for the composer's stream"""
+        _chk(self._lib.pg_composer_sync(self._h), "pg_composer_sync")
+
+    def flush(self):
+        _chk(self._lib.pg_composer_flush(self._h), "pg_composer_flush")
+
+    def queue_stats(self) -> tuple:
+        """(entries waiting, flushes so far, launches those flushes took)"""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _chk(self._lib.pg_composer_queue_stats(self._h, C.byref(a), C.byref(b), C.byref(c)), "pg_composer_queue_stats")
+        return int(a.value), int(b.value), int(c.value)
+
     # -- state ------------------------------------------------------------------------------
     def circuit_size(self) -> int:
         return int(self._lib.pg_composer_circuit_size(self._h))

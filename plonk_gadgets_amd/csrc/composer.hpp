@@ -67,6 +67,49 @@ __global__ void gate_kernel(const GateCmd cmd, const ComposerCols C) {
     C.w[2][cmd.gate] = out;
 }
 
+// A RUN of queued composer calls in ONE launch (pg_composer's command queue): cmds[i].pad = the command's level --
+// 0 for calls that read no Variable of the run, else 1 + the highest level among the run's commands whose output it
+// reads (computed on the host, where Variables are numbered).  One workgroup: rows and add_input values first, then the
+// outputs of add / mul level by level; the assignments the run creates live in LDS (Variables first_var .. first_var +
+// up to kQueueRun - 1) so that a command reads its predecessors' outputs without a trip through memory.
+constexpr uint32_t kQueueRun = 1024;
+__global__ __launch_bounds__(1024) void gate_queue_kernel(const GateCmd *cmds, uint32_t n, uint64_t first_var, uint32_t max_level,
+                                                          const ComposerCols C) {
+    __shared__ uint4 s_val[2 * kQueueRun];
+    const uint32_t tid = threadIdx.x;
+    GateCmd cmd{};
+    if (tid < n) cmd = cmds[tid];
+    const bool creates = tid < n && (cmd.op == OP_ADD || cmd.op == OP_MUL);
+    if (tid < n) {
+        if (cmd.op == OP_ADD_INPUT) {
+            put_fr(C.vars, cmd.var, cmd.value);
+            put_fr(s_val, cmd.var - first_var, cmd.value);
+        } else {
+            put_fr(C.q[0], cmd.gate, cmd.q_m);
+            put_fr(C.q[1], cmd.gate, cmd.q_l);
+            put_fr(C.q[2], cmd.gate, cmd.q_r);
+            put_fr(C.q[3], cmd.gate, cmd.q_o);
+            put_fr(C.q[4], cmd.gate, cmd.q_c);
+            C.w[0][cmd.gate] = cmd.a;
+            C.w[1][cmd.gate] = cmd.b;
+            C.w[2][cmd.gate] = creates ? cmd.var : cmd.c;
+        }
+    }
+    __syncthreads();
+    for (uint32_t lvl = 1; lvl <= max_level; lvl++) {
+        if (creates && cmd.pad == lvl) {
+            // an operand created by this run sits in LDS (its command has a lower level: done); any other is older
+            const Fr a = cmd.a >= first_var && cmd.a - first_var < kQueueRun ? get_fr(s_val, cmd.a - first_var) : get_fr(C.vars, cmd.a);
+            const Fr b = cmd.b >= first_var && cmd.b - first_var < kQueueRun ? get_fr(s_val, cmd.b - first_var) : get_fr(C.vars, cmd.b);
+            Fr v = cmd.op == OP_ADD ? fr_add(fr_mul(cmd.q_l, a), fr_mul(cmd.q_r, b)) : fr_mul(fr_mul(cmd.q_m, a), b);
+            v = fr_add(fr_add(v, cmd.q_c), cmd.pi);
+            put_fr(C.vars, cmd.var, v);
+            put_fr(s_val, cmd.var - first_var, v);
+        }
+        __syncthreads();
+    }
+}
+
 // the same calls over device arrays of Variables with one set of selectors: item i writes row gate0 + i; OP_ADD / OP_MUL
 // also create Variable var0 + i = q_l a + q_r b + q_c  /  q_m a b + q_c (read from the composer's own table) on the
 // output wire.  c may be NULL for OP_ADD / OP_MUL.

@@ -1,0 +1,154 @@
+"""GPU: pg_composer's command queue.  The reference drives a composer ONE call at a time
+(/root/reference/tests/range_gadgets_tests.rs:29-44); here those calls are recorded on the host (Variables are numbered
+there) and reach the device as few launches.  What must hold: the columns are those of the same calls on the CPU
+oracle's composer -- and of the same calls with recording off -- whatever the interleaving, and the launch counts are
+what the header promises."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import plonk_gadgets_amd as pg
+from plonk_gadgets_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+COLS = ("q_m", "q_l", "q_r", "q_o", "q_c", "w_l", "w_r", "w_o", "var_values")
+Q = synth.Q
+S = pg.BlsScalar.from_int
+
+
+@pytest.fixture(scope="module")
+def engine():
+    e = pg.Engine(0)
+    yield e
+    e.close()
+
+
+def same(dev, ora):
+    got, exp = dev.export(), ora.export()
+    assert dev.circuit_size() == ora.n and dev.num_variables() == ora.num_vars
+    for k in COLS:
+        assert got[k].shape == exp[k].shape, k
+        assert np.array_equal(got[k], exp[k]), k
+
+
+def f(x):
+    from oracle import pyoracle as po
+    return po.fr(synth.mont(x))
+
+
+def test_reference_loop_is_one_launch(engine):
+    """allocate, range_check, one call at a time, 300 times: recorded, then ONE batched launch (queue statistics); same
+    columns as the oracle's loop and as the same loop with recording off (one launch per call)"""
+    from oracle import pyoracle as po
+    vals = [50_000 + 997 * i for i in range(150)] + [int(x) % Q for x in synth.splitmix64(150, 77)]
+    mn, mx = 50_000, 250_000
+    ora = po.Composer()
+    for v in vals:
+        ora.L.range_check(ora.c, f(mn), f(mx), ora.allocate(synth.mont(v)))
+    exports = []
+    for queued in (True, False):
+        dev = pg.StandardComposer(engine, 1 << 16, 1 << 18)
+        dev.queue(queued)  # turning it off flushes what creation recorded
+        _, f0, l0 = dev.queue_stats()
+        res = [pg.range_check(dev, S(mn), S(mx), pg.AllocatedScalar.allocate(dev, S(v))) for v in vals]
+        if queued:
+            assert dev.queue_stats()[0] >= 2 * len(vals)  # nothing has been launched yet
+            dev.flush()
+            pending, f1, l1 = dev.queue_stats()
+            # the composer's initial state (gate calls) + the 300 pairs: two launches in one flush
+            assert pending == 0 and f1 - f0 == 1 and l1 - l0 <= 2, (pending, f1 - f0, l1 - l0)
+        same(dev, ora)
+        assert dev.check() == -1 and ora.check() == -1
+        assert [dev.value(r).to_int() for r in res[:150]] == [int(mn <= v < mx) for v in vals[:150]]
+        exports.append(dev.export())
+    for k in COLS:
+        assert np.array_equal(exports[0][k], exports[1][k]), k
+
+
+def test_dependent_gate_calls(engine):
+    """a run of gate calls whose outputs feed later calls of the same run (a chain of add / mul over earlier results,
+    1500 calls: more than one launch of the queue kernel): values are computed in command order, level by level"""
+    from oracle import pyoracle as po
+    dev, ora = pg.StandardComposer(engine, 1 << 14, 1 << 14), po.Composer()
+    L = ora.L
+    vs = [dev.add_input(S(3 + i)) for i in range(4)]
+    assert vs == [ora.add_input(synth.mont(3 + i)) for i in range(4)]
+    for i, r in enumerate(int(x) for x in synth.splitmix64(1500, 5)):
+        a, b = vs[r % len(vs)], vs[(r >> 20) % len(vs)]
+        if i % 3 == 2:
+            a = vs[-1]  # a dependency on the call just before: the chain grows deep
+        k1, k2, k3 = (r >> 8) % 97, (r >> 16) % 89, (r >> 24) % 83
+        if r & 1:
+            v = dev.add((S(k1), a), (S(k2), b), S(k3), None)
+            assert v == L.composer_add(ora.c, f(k1), a, f(k2), b, f(k3), None)
+        else:
+            pi = f(k2) if i % 5 == 0 else None
+            v = dev.mul(S(k1 + 1), a, b, S(k3), S(k2) if pi is not None else None)
+            assert v == L.composer_mul(ora.c, f(k1 + 1), a, b, f(k3), C.byref(pi) if pi is not None else None)
+        vs.append(v)
+        if i % 50 == 7:
+            dev.boolean_gate(dev.zero_var)
+            L.composer_boolean_gate(ora.c, 0)
+    assert dev.queue_stats()[0] > 1500
+    same(dev, ora)
+    assert dev.check() == ora.check()  # the public inputs and random constants leave rows unsatisfied: the SAME first one
+
+
+def test_interleaving_and_self_flush(engine):
+    """gadget calls on witnesses allocated long before (their own kind of run, two sets of bounds), a direct gadget call
+    and a batched append in between, and more entries than the queue holds (it flushes itself): everything lands in
+    call order"""
+    from oracle import pyoracle as po
+    dev, ora = pg.StandardComposer(engine, 1 << 17, 1 << 19), po.Composer()
+    L = ora.L
+    ws = [pg.AllocatedScalar.allocate(dev, S(1000 + 7 * i)) for i in range(40)]
+    ows = [ora.allocate(synth.mont(1000 + 7 * i)) for i in range(40)]
+    for w, ow in zip(ws[:20], ows[:20]):   # witnesses allocated earlier: an "allocated" run
+        assert pg.range_check(dev, S(0), S(2**16), w) == int(L.range_check(ora.c, f(0), f(2**16), ow))
+    for w, ow in zip(ws[20:30], ows[20:30]):   # another gadget: a new run
+        nb = C.c_uint64()
+        r, n = pg.max_bound(dev, S(5000), w)
+        assert r == int(L.max_bound(ora.c, f(5000), ow, C.byref(nb))) and n == nb.value == 14
+    # a direct (not queued) gadget call: flushes what is pending first
+    e = pg.maybe_equal(dev, ws[0], ws[1])
+    assert e == int(L.maybe_equal(ora.c, ows[0], ows[1]))
+    for w, ow in zip(ws[30:], ows[30:]):   # allocate-free calls with other bounds, then fused pairs again
+        assert pg.range_check(dev, S(1000), S(1200), w) == int(L.range_check(ora.c, f(1000), f(1200), ow))
+    for v in (5, 1100, 77777):
+        a, oa = pg.AllocatedScalar.allocate(dev, S(v)), ora.allocate(synth.mont(v))
+        assert pg.range_check(dev, S(1000), S(1200), a) == int(L.range_check(ora.c, f(1000), f(1200), oa))
+        dev.constrain_to_constant(a.var, S(v), None)   # a gate call between the pairs: they no longer fuse into one run
+        L.composer_constrain_to_constant(ora.c, oa.var, f(v), None)
+    # a batched append in the middle
+    wit = synth.uniform_below(16, 2**16, seed=4)
+    dev.range_check_batch(S(0), S(2**16), torch.from_numpy(wit.view(np.int64)).to("cuda:0"))
+    for w in wit:
+        L.range_check(ora.c, f(0), f(2**16), ora.allocate(w))
+    same(dev, ora)
+    assert dev.check() == -1 and ora.check() == -1
+    for i in range(9000):                  # > 8192 queue entries between two flushes
+        dev.boolean_gate(dev.zero_var)
+        L.composer_boolean_gate(ora.c, 0)
+    assert 0 < dev.queue_stats()[0] < 8192
+    same(dev, ora)
+    assert dev.check() == -1
+
+
+def test_errors_are_reported_at_the_call(engine):
+    """recording does not defer errors: an unknown Variable, a non-reduced scalar or a full composer fail at the call
+    that causes them, and nothing of that call is recorded"""
+    dev = pg.StandardComposer(engine, 64, 64)
+    a = dev.add_input(S(5))
+    n0, v0, p0 = dev.circuit_size(), dev.num_variables(), dev.queue_stats()[0]
+    with pytest.raises(pg.PgError, match="unknown Variable"):
+        dev.boolean_gate(a + 100)
+    with pytest.raises(pg.PgError, match="unknown Variable"):
+        dev.add((S(1), a), (S(1), a + 1), S(0), None)
+    with pytest.raises(pg.PgError, match="capacity"):
+        pg.range_check(dev, S(0), S(2**64), pg.AllocatedScalar(a, S(5)))
+    assert (dev.circuit_size(), dev.num_variables(), dev.queue_stats()[0]) == (n0, v0, p0)
+    dev.boolean_gate(dev.zero_var)
+    assert dev.check() == -1

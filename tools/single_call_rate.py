@@ -1,24 +1,37 @@
-import sys, os, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+"""The reference-shaped path: ONE composer call at a time from the host (tests/range_gadgets_tests.rs:29-44), with the
+composer's command queue on (calls recorded, flushed as few launches) and off (one launch per call).  1 GPU."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import plonk_gadgets_amd as pg
+
 S = pg.BlsScalar.from_int
 eng = pg.Engine(0)
-dev = pg.StandardComposer(eng, 1 << 21, 1 << 21)
 mn, mx = S(0), S(2**254)
-for _ in range(20):
-    pg.range_check(dev, mn, mx, pg.AllocatedScalar.allocate(dev, S(12345)))
-torch.cuda.synchronize()
-N = 1000
-t = time.perf_counter()
-for i in range(N):
-    pg.range_check(dev, mn, mx, pg.AllocatedScalar.allocate(dev, S(i)))
-torch.cuda.synchronize()
-dt = time.perf_counter() - t
-print("single range_check calls: %.1f us per call, %.3g constraints/s" % (dt / N * 1e6, N * 1031 / dt))
-t = time.perf_counter()
-for i in range(N):
-    dev.boolean_gate(5)
-torch.cuda.synchronize()
-dt = time.perf_counter() - t
-print("single gate calls: %.1f us per call" % (dt / N * 1e6))
+N = 2000
+scalars = [S(1000 + i) for i in range(N)]  # built outside the timed loops: the loops time the composer, not Python's big integers
+for queued in (False, True):
+    dev = pg.StandardComposer(eng, 1 << 22, 1 << 22)
+    dev.queue(queued)
+    for s in scalars[:50]:
+        pg.range_check(dev, mn, mx, pg.AllocatedScalar.allocate(dev, s))
+    dev.sync()
+    for rep in range(2):  # the second pass is the steady state: the first one also maps fresh HBM pages (890 MB of columns)
+        t = time.perf_counter()
+        for s in scalars:
+            pg.range_check(dev, mn, mx, pg.AllocatedScalar.allocate(dev, s))
+        dev.sync()
+        dt = time.perf_counter() - t
+        print("queue %-3s allocate + range_check: %6.2f us per pair, %.3g constraints/s%s" % (
+            "on" if queued else "off", dt / N * 1e6, N * 1031 / dt, "" if rep else "  [first pass over fresh memory]"))
+    t = time.perf_counter()
+    for i in range(N):
+        dev.boolean_gate(dev.zero_var)
+    dev.sync()
+    dt = time.perf_counter() - t
+    print("queue %-3s gate calls:             %6.2f us per call" % ("on" if queued else "off", dt / N * 1e6))
+    assert dev.check() == -1
+    dev.close()
