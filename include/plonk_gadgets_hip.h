@@ -476,6 +476,8 @@ pg_status pg_columns_in_packed(void *d_packed, uint64_t n_gates, uint64_t n_vars
 #define PG_COMM_ID_BYTES 128
 typedef struct pg_comm pg_comm;
 pg_status pg_comm_unique_id(uint8_t id[PG_COMM_ID_BYTES]);
+/* path of the RCCL the library bound ("" if none was found): inside a PyTorch process it must be PyTorch's own copy */
+const char *pg_comm_library(void);
 pg_status pg_comm_create(pg_engine *e, const uint8_t id[PG_COMM_ID_BYTES], uint32_t rank, uint32_t world, pg_comm **out);
 pg_status pg_comm_adopt(pg_engine *e, void *nccl_comm, pg_comm **out);
 void pg_comm_destroy(pg_comm *c);

@@ -179,6 +179,7 @@ SIGNATURES = {
     "pg_packed_layout": (C.c_int, [C.c_uint64, C.c_uint64, _P(PackedC)]),
     "pg_columns_in_packed": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, _P(ColumnsC)]),
     "pg_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "pg_comm_library": (C.c_char_p, []),
     "pg_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _P(C.c_void_p)]),
     "pg_comm_adopt": (C.c_int, [C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
     "pg_comm_destroy": (None, [C.c_void_p]),
