@@ -238,8 +238,12 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
 #if defined(PG_SEQUENTIAL_PREPASS)  // A/B build: the pre-pass on the caller's stream, ahead of the emit kernel
         side = false;
 #else
-        // a handful of elements (the single-gadget calls of pg_composer): two event hops cost more than the overlap buys
-        side = elems >= 2048;
+        // a handful of elements (the single-gadget calls of pg_composer): two event hops cost more than the overlap buys.
+        // A split gadget (small items) runs its pre-pass FIRST, on the caller's stream: its two emit launches need their full
+        // residency and the pre-pass its registers, and beside each other they take turns rather than overlap -- measured
+        // on five boxes of the pool the sequential order was the faster one on every box (0.74-0.82 ms against 0.76-0.89
+        // for the fused mix, tools/ab_emit.py run_c3), and the stable one (concurrent: median 10 % above its own minimum).
+        side = elems >= 2048 && !kSplit;
 #endif
         if (!side) {
             hipLaunchKernelGGL((pg::batch_invert_kernel<GD, GRP>), dim3(blocks), dim3(pg::kThreads), 0, st, A, O, elems,
@@ -276,10 +280,10 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
         }
         hipLaunchKernelGGL((pg::emit_kernel<GD, pg::EMIT_ROWS>), dim3(R.tiles < max_blocks ? R.tiles : max_blocks), dim3(pg::kThreads), pad,
                            st, A, R);
-        // the variable-table launch of a small-item gadget: a tile is a few microseconds of work, so workgroups stay and
-        // stride over the tiles instead of paying a dispatch (kernel arguments, constant table, first barrier) per tile
+        // grid of the variable-table launch (A/B knob: 6, 8, 16 workgroups per CU striding over the tiles measured no better
+        // than one workgroup per tile, tools/ab_emit.py)
 #ifndef PG_VARS_BLOCKS_PER_CU
-#define PG_VARS_BLOCKS_PER_CU 8
+#define PG_VARS_BLOCKS_PER_CU 64
 #endif
         const uint32_t vars_blocks = (uint32_t)e->num_cus * PG_VARS_BLOCKS_PER_CU;
         hipLaunchKernelGGL((pg::emit_kernel<GD, pg::EMIT_VARS>), dim3(O.tiles < vars_blocks ? O.tiles : vars_blocks), dim3(pg::kThreads), 0,

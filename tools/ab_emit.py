@@ -31,6 +31,7 @@ VARIANTS = {
     "rows_wgs_2": ["-DPG_ROWS_WGS_PER_CU=2"],
     "rows_wgs_4": ["-DPG_ROWS_WGS_PER_CU=4"],
     "inv_grp4": ["-DPG_INV_GRP=4"],
+    "inv_grp2": ["-DPG_INV_GRP=2"],
     "inv_grp16": ["-DPG_INV_GRP=16"],
     "inv_lanes512": ["-DPG_INV_LANES_PER_CU=512"],
     "inv_lanes512_grp4": ["-DPG_INV_LANES_PER_CU=512", "-DPG_INV_GRP=4"],
