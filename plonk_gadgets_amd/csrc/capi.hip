@@ -106,6 +106,7 @@ struct pg_engine {
     struct PlanResult { uint64_t n_gates, n_vars; uint32_t errs, pad; } *h_plan = nullptr;
     // scratch of the inversion pre-pass (grow-only): running products, 32 B per element
     uint4 *d_prefix = nullptr;
+    uint4 *d_inv = nullptr;  // compact inverses of a split gadget's call (32 B per element)
     uint64_t inv_elems = 0;
     // the pre-pass runs on its own stream beside the rows-only emit launch
     hipStream_t side = nullptr;
@@ -175,6 +176,7 @@ pg::EmitOut make_out(const pg_columns *c, uint64_t batch, int W, uint64_t gate_b
     O.zero_var = zero_var;
     O.row_off = row_off;
     O.var_off = var_off;
+    O.inv = nullptr;
     O.batch = batch;
     O.tiles = (uint32_t)((batch + W - 1) / W);
     return O;
@@ -184,8 +186,10 @@ pg_status ensure_inv_scratch(pg_engine *e, uint64_t elems) {
     if (elems <= e->inv_elems) return PG_OK;
     PG_HIP_TRY(hipSetDevice(e->device));
     if (e->d_prefix) { (void)hipFree(e->d_prefix); e->d_prefix = nullptr; }
+    if (e->d_inv) { (void)hipFree(e->d_inv); e->d_inv = nullptr; }
     e->inv_elems = 0;
     PG_HIP_TRY(hipMalloc(&e->d_prefix, elems * 4 * sizeof(uint4)));  // per element: the element and its running product
+    PG_HIP_TRY(hipMalloc(&e->d_inv, elems * 2 * sizeof(uint4)));
     e->inv_elems = elems;
     return PG_OK;
 }
@@ -221,7 +225,7 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
     if ((batch + GD::W - 1) / GD::W > 0xffffffffull) return fail(PG_ERR_INVALID_ARGUMENT, "batch too large for one call");
     hipStream_t st = static_cast<hipStream_t>(stream);
     PG_TRY(enter_stream(e, st));
-    const pg::EmitOut O = make_out(c, batch, GD::W, gate_base, var_base, zero_var, row_off, var_off);
+    pg::EmitOut O = make_out(c, batch, GD::W, gate_base, var_base, zero_var, row_off, var_off);
     constexpr bool kSplit = pg::Split<GD>::ok;  // the rows, then the variable table (emit.hpp, EmitMode)
     bool side = false;  // the inversion pre-pass runs on the engine's side stream
     if constexpr (GD::kInv > 0) {
@@ -235,6 +239,8 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
         const uint64_t groups = (per_lane + GRP - 1) / GRP;  // a lane owns groups * GRP elements
         const uint64_t lanes = (elems + groups * GRP - 1) / (groups * GRP);
         const uint32_t blocks = (uint32_t)((lanes + pg::kThreads - 1) / pg::kThreads);
+        uint4 *compact = kSplit ? e->d_inv : nullptr;
+        O.inv = compact;
 #if defined(PG_SEQUENTIAL_PREPASS)  // A/B build: the pre-pass on the caller's stream, ahead of the emit kernel
         side = false;
 #else
@@ -247,13 +253,13 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
 #endif
         if (!side) {
             hipLaunchKernelGGL((pg::batch_invert_kernel<GD, GRP>), dim3(blocks), dim3(pg::kThreads), 0, st, A, O, elems,
-                               (uint32_t)groups, e->d_prefix);
+                               (uint32_t)groups, e->d_prefix, compact);
             PG_HIP_TRY(hipGetLastError());
         } else {
             PG_HIP_TRY(hipEventRecord(e->ev_fork, st));  // the pre-pass reads the call's inputs: order it after the stream
             PG_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
             hipLaunchKernelGGL((pg::batch_invert_kernel<GD, GRP>), dim3(blocks), dim3(pg::kThreads), 0, e->side, A, O, elems,
-                               (uint32_t)groups, e->d_prefix);
+                               (uint32_t)groups, e->d_prefix, compact);
             PG_HIP_TRY(hipGetLastError());
             PG_HIP_TRY(hipEventRecord(e->ev_inv, e->side));
         }
@@ -280,8 +286,11 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
         }
         hipLaunchKernelGGL((pg::emit_kernel<GD, pg::EMIT_ROWS>), dim3(R.tiles < max_blocks ? R.tiles : max_blocks), dim3(pg::kThreads), pad,
                            st, A, R);
-        // grid of the variable-table launch (A/B knob: 6, 8, 16 workgroups per CU striding over the tiles measured no better
-        // than one workgroup per tile, tools/ab_emit.py)
+        // grid of the variable-table launch.  Measured and not kept (tools/ab_emit.py run_c3): 6 / 8 / 16 resident
+        // workgroups per CU striding over the tiles; the same with the next tile's loads issued before the current tile's
+        // stores (0.713 vs 0.706 ms); lanes 2s, 2s+1 storing the halves of slot s for full-line wave stores (0.30 vs
+        // 0.19 ms for this launch: twice the passes and LDS reads) -- the launch is bound by neither its loads' latency
+        // nor its dispatch rate nor partial lines.
 #ifndef PG_VARS_BLOCKS_PER_CU
 #define PG_VARS_BLOCKS_PER_CU 64
 #endif
@@ -423,6 +432,7 @@ void pg_engine_destroy(pg_engine *e) {
     if (e->d_blk_vars) (void)hipFree(e->d_blk_vars);
     if (e->d_err_count) (void)hipFree(e->d_err_count);
     if (e->d_prefix) (void)hipFree(e->d_prefix);
+    if (e->d_inv) (void)hipFree(e->d_inv);
     if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_inv) (void)hipEventDestroy(e->ev_inv);

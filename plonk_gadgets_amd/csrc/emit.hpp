@@ -42,6 +42,7 @@ struct EmitOut {
     uint64_t zero_var;             // composer.zero_var (fourth wire / assert_equal's output wire)
     const uint64_t *row_off;       // ragged only: [batch+1] exclusive prefix sums, relative to the call
     const uint64_t *var_off;
+    const uint4 *inv;              // split gadgets: the pre-pass's compact output, inverse e of item i at [e * batch + i]
     uint64_t batch;
     uint32_t tiles;
 };
@@ -58,6 +59,20 @@ __device__ __forceinline__ void store16(uint4 *p, uint4 v) {
     __builtin_nontemporal_store(t, reinterpret_cast<pg_u32x4 *>(p));
 #else
     *p = v;
+#endif
+}
+
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier:
+// it also waits until every global STORE the wave has issued is acknowledged by memory.  The emit kernel's waves exchange
+// nothing through global memory -- only item records, offsets and the constant table, all in LDS -- and they have just
+// issued a sweep of stores when they reach a barrier; draining those costs microseconds per barrier under load, which is
+// most of the life of a small tile's workgroup (the fused mix's variable-table launch: 8 stores per wave, 16.8 us wave
+// lifetime, 68 % of it waiting -- profiles/r02f_c3_prepass_counters.json).  Here: LDS operations done, then the barrier.
+__device__ __forceinline__ void lds_barrier() {
+#if defined(PG_FULL_BARRIERS)
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 }
 
@@ -167,8 +182,9 @@ constexpr uint32_t periodic_wire_lanes(uint32_t R) {
 //   EMIT_ROWS       selectors and wire indices of a gadget whose rows DO depend on its inputs, but only through a cheap
 //                   per-item shape (GD::RowRec, GD::item_rows): a lean pure-store launch (no arithmetic, a few bytes of
 //                   LDS per item, GD::kRowsW items per tile) that shares the chip with the inversion pre-pass
-//   EMIT_VARS       the variable table alone (inverse slots excepted, as in EMIT_ALL)
-// A gadget with GD::kSplit is emitted as EMIT_ROWS then EMIT_VARS on the caller's stream, both beside the pre-pass: for
+//   EMIT_VARS       the variable table alone, inverse slots included: the item phase reads the item's inverses from the
+//                   pre-pass's compact output (O.inv) into its record
+// A gadget with GD::kSplit is emitted as pre-pass, EMIT_ROWS, EMIT_VARS, in that order on the caller's stream: for
 // small items the all-in-one launch is a poor streaming writer -- its tile is bounded by the LDS the item records take
 // (64 items = 148 KB of output for the fused mix), so a workgroup's global round trips before its first store are never
 // amortised -- while four fifths of its bytes (the rows) need no record at all.
@@ -215,7 +231,7 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
         fill_common_table(s_table, p2, tid, kTable);
     }
     GD::fill_table(A, s_table, tid);
-    __syncthreads();
+    lds_barrier();
 
     for (uint32_t t = blockIdx.x; t < O.tiles; t += gridDim.x) {
 #if defined(PG_XCD_REMAP)
@@ -263,7 +279,11 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
             for (uint32_t i = tid; i < Wt; i += kThreads) GD::item_rows(A, O, w0 + i, s_table, s_item[i]);
         }
         if constexpr (kVars && !kRows) {
+#if defined(PG_ABLATE_ITEM_PHASE)  // timing-only build (wrong output): no item phase in the variables-only launch
+            if (tid < Wt) s_item[tid].err = 0;
+#else
             if (tid < Wt) GD::item(A, O, w0 + tid, s_table, s_item[tid]);
+#endif
         }
         if constexpr (GD::kRagged) {
             if (tid <= Wt) {
@@ -277,7 +297,7 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                 }
             }
         }
-        if constexpr (GD::kRagged || GD::kRecInRows || !kRows) __syncthreads();
+        if constexpr (GD::kRagged || GD::kRecInRows || !kRows) lds_barrier();
         if constexpr (kVars && kRows) {
             if (tid < Wt) GD::item(A, O, w0 + tid, s_table, s_item[tid]);
         }
@@ -343,7 +363,7 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                         }
                     }
                 }
-                __syncthreads();  // item records visible
+                lds_barrier();  // item records visible
                 if constexpr (kVars) {
                     // variables: lane = (item, slot); IPV whole items per pass
                     constexpr uint32_t IPV = kThreads / VV, LV = IPV * VV;
@@ -351,17 +371,24 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                         const uint32_t it0 = tid / VV, k = tid - it0 * VV;
                         const bool is_inv = GD::is_inv_slot(A, s_item[0], k);
                         uint4 *dst = O.vars + (var0 + tid) * 2;
-                        if (!is_inv) {  // the inverse slots belong to the pre-pass
+                        // EMIT_ALL: the inverse slots are the pre-pass's, written in place.  EMIT_VARS (split gadgets): the item
+                        // phase has fetched the item's inverses from the pre-pass's compact output into its record, and this
+                        // launch writes every slot -- whole lines
+                        if (MODE == EMIT_VARS || !is_inv) {
                             for (uint32_t it = it0; it < Wt; it += IPV, dst += 2 * LV) {
                                 FrVec val;
                                 val.f = GD::var_value_full(A, s_item[it], s_table, k);  // k is the lane's for the whole tile
+#if defined(PG_ABLATE_VAR_STORES)  // timing-only build (wrong output): the sweep without its stores
+                                if (val.v[0].x == 0x12345678u && val.v[1].y == 0x9abcdef0u) store16(dst, val.v[0]);
+#else
                                 store16(dst, val.v[0]);
                                 store16(dst + 1, val.v[1]);
+#endif
                             }
                         }
                     }
                 }
-                __syncthreads();  // records and offsets are rewritten by the next tile
+                lds_barrier();  // records and offsets are rewritten by the next tile
                 continue;
             }
         }
@@ -433,7 +460,7 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
             }
         }
 
-        __syncthreads();  // item records visible
+        lds_barrier();  // item records visible
 
         // ---- variable sweep: one scalar (2 x 16 B) per lane ----------------
         if constexpr (kVars) {
@@ -445,7 +472,7 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                     k = uni_vars ? s - it * kUniV : s - s_voff[it];
                 }
                 uint4 *dst = O.vars + (var0 + s) * 2;
-                if (!GD::is_inv_slot(A, s_item[it], k)) {  // the inverse slots belong to the pre-pass
+                if (MODE == EMIT_VARS || !GD::is_inv_slot(A, s_item[it], k)) {  // (see the periodic sweep)
                     FrVec val;
                     val.f = GD::var_value(A, s_item[it], s_table, k);
                     store16(dst, val.v[0]);
@@ -457,7 +484,7 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                 }
             }
         }
-        __syncthreads();  // records and offsets are rewritten by the next tile
+        lds_barrier();  // records and offsets are rewritten by the next tile
     }
 }
 

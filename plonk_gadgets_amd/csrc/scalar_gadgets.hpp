@@ -266,10 +266,10 @@ struct ScalarMixGD {
     using Args = ScalarMixArgs;
     // what the item's lane computes once: the five inputs and the four derived values that are not constants (the
     // variable sweep is then an LDS -> HBM copy: a wave that met one slot needing arithmetic would pay it for all 64
-    // lanes).  Kept to 304 bytes: the records bound how many workgroups share a CU, and the variable-table launch lives
-    // on that overlap (7 per CU instead of 4 with one slot per variable).
+    // lanes).  Kept to 368 bytes: the records bound how many workgroups share a CU, and the variable-table launch lives
+    // on that overlap (6 per CU instead of 4 with one slot per variable).
     struct alignas(16) ItemRec {
-        Fr d[9];  // v y s a b | sy oms out | u
+        Fr d[11];  // v y s a b | sy oms out | u | v^-1 (a-b)^-1  (the inverses: read back from the pre-pass's compact output)
         uint32_t err, yeq, pad[2];
     };
 #ifndef PG_MIX_W
@@ -318,25 +318,52 @@ struct ScalarMixGD {
     __device__ static void item_rows(const Args &A, const EmitOut &, uint64_t item, const uint4 *, R &rec) {
         rec.err = fr_is_zero(load_fr(A.v, item)) ? 1u : 0u;
     }
-    __device__ static void item(const Args &A, const EmitOut &O, uint64_t item, const uint4 *, ItemRec &R) {
-        const Fr v = load_fr(A.v, item), y = load_fr(A.y, item), s = load_fr(A.s, item), a = load_fr(A.a, item),
-                 b = load_fr(A.b, item);
-        const uint32_t err = fr_is_zero(v) ? 1u : 0u;
-        R.err = err;  // what item_rows writes when there are rows to emit; an EMIT_VARS launch has no item_rows
-        R.d[0] = v; R.d[1] = y; R.d[2] = s; R.d[3] = a; R.d[4] = b;  // 5 x add_input (and var_assigned = v, scalar.rs:69)
-        const Fr sy = fr_mul(y, s), oms = fr_sub(fr_one(), s);
+    // what an item's lane reads from memory, apart from the arithmetic on it
+    struct Loads {
+        Fr v, y, s, a, b, inv0, inv1;
+        uint64_t var_off;
+    };
+    __device__ static void item_load(const Args &A, const EmitOut &O, uint64_t item, Loads &L) {
+        L.v = load_fr(A.v, item);
+        L.y = load_fr(A.y, item);
+        L.s = load_fr(A.s, item);
+        L.a = load_fr(A.a, item);
+        L.b = load_fr(A.b, item);
+        L.var_off = O.var_off[item];
+        // the item's two inverses, if the pre-pass has run (the variables-only launch of the split): element e of item i
+        // sits at [e * batch + i] of its compact output
+        const uint4 *inv = O.inv ? O.inv : A.v;  // (no pre-pass output: any readable address, the values are not used)
+        L.inv0 = load_fr(inv, O.inv ? item : 0);
+        L.inv1 = load_fr(inv, O.inv ? O.batch + item : 0);
+    }
+    __device__ static void item_from(const Args &A, const EmitOut &O, uint64_t item, ItemRec &R, const Loads &L) {
+        const uint32_t err = fr_is_zero(L.v) ? 1u : 0u;
+        R.err = err;  // what item_rows writes when there are rows to emit; a variables-only launch has no item_rows
+        R.d[0] = L.v; R.d[1] = L.y; R.d[2] = L.s; R.d[3] = L.a; R.d[4] = L.b;  // 5 x add_input (and var_assigned = v, scalar.rs:69)
+        const Fr sy = fr_mul(L.y, L.s), oms = fr_sub(fr_one(), L.s);
         R.d[5] = sy;                                                  // scalar.rs:43
         R.d[6] = oms;                                                 // scalar.rs:45-50
         R.d[7] = fr_add(sy, oms);                                     // scalar.rs:53-58
-        const Fr u = fr_sub(a, b);
+        const Fr u = fr_sub(L.a, L.b);
         R.d[8] = u;                                                   // scalar.rs:111-117
+        R.d[9] = L.inv0;                                              // scalar.rs:77 (0 for an item that stopped at its error: never stored)
+        R.d[10] = L.inv1;                                             // scalar.rs:122-123
         R.yeq = fr_is_zero(u) ? 1u : 0u;                              // y = 1 - u z, scalar.rs:126
         if (A.result_vars) {
-            const uint64_t vb = O.var_base + O.var_off[item];
+            const uint64_t vb = O.var_base + L.var_off;
             const uint64_t nz = err ? 1 : 3;
             A.result_vars[2 * item] = vb + 5 + nz + 3;
             A.result_vars[2 * item + 1] = vb + 5 + nz + 4 + 2;
         }
+    }
+    __device__ static void item(const Args &A, const EmitOut &O, uint64_t item, const uint4 *, ItemRec &R) {
+        Loads L;
+        item_load(A, O, item, L);
+        // every load of the item (and the tile's offsets, issued just before) is in flight before the first use: left to
+        // itself the scheduler interleaves the record's LDS writes with the loads and the ten loads leave in three
+        // batches, each waited for -- three global round trips where one will do, in a workgroup that lives for little else
+        __builtin_amdgcn_sched_barrier(0);
+        item_from(A, O, item, R, L);
     }
     template <class R_>
     __device__ static void row(const R_ &R, uint64_t vbase, uint64_t zero_var, uint32_t j, RowOut &r) {
@@ -365,7 +392,7 @@ struct ScalarMixGD {
         if (kc == 7 || kc == 8) return fr_one();             // scalar.rs:83, :41
         if (kc >= 9 && kc <= 12) return R.d[kc - 4];         // sy oms out u
         if (kc == 14) return R.yeq ? fr_one() : fr_zero();
-        return fr_zero();                                    // 6, 13: the pre-pass's slots, never asked for
+        return R.d[kc == 6 ? 9 : 10];                        // 6: v^-1, 13: (a - b)^-1 (asked for by the variables-only launch)
     }
     // an item that stopped at its error has no inv / one: its variables 6.. are the full shape's 8..
     __device__ static Fr var_value(const Args &A, const ItemRec &R, const uint4 *t, uint32_t k) {

@@ -21,6 +21,10 @@ VARIANTS = {
     "invert_fermat": ["-DPG_INVERT_FERMAT"],
     "sequential_fermat": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_INVERT_FERMAT"],
     "no_periodic": ["-DPG_NO_PERIODIC"],
+    "full_barriers": ["-DPG_FULL_BARRIERS"],
+    "abl_var_stores": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_ABLATE_VAR_STORES"],   # timing only
+    "abl_item_phase": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_ABLATE_ITEM_PHASE"],   # timing only
+    "abl_both": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_ABLATE_ITEM_PHASE", "-DPG_ABLATE_VAR_STORES"],
     "seq_l512_g4": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_INV_LANES_PER_CU=512", "-DPG_INV_GRP=4"],
     "seq_g4": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_INV_GRP=4"],
     "seq_l512": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_INV_LANES_PER_CU=512"],
