@@ -26,7 +26,10 @@
 namespace pg {
 
 #ifndef PG_INV_GRP
-#define PG_INV_GRP 8  // elements fetched per lane per round trip (registers: 16 x GRP for the unwind's x and prefix)
+// elements fetched per lane per round trip (registers: ~40 x GRP with the software pipeline).  4 measured best for the
+// fused mix in the pre-pass-first order (0.627 ms against 0.650 for 8 and 0.633 for 2 with two waves per SIMD;
+// tools/ab_emit.py run_c3): 168 registers leave the dependent multiplication chains more room than 253
+#define PG_INV_GRP 4
 #endif
 
 // element s of a call -> (item, e), e-major

@@ -39,6 +39,8 @@ VARIANTS = {
     "inv_grp16": ["-DPG_INV_GRP=16"],
     "inv_lanes512": ["-DPG_INV_LANES_PER_CU=512"],
     "inv_lanes512_grp4": ["-DPG_INV_LANES_PER_CU=512", "-DPG_INV_GRP=4"],
+    "inv_lanes512_grp2": ["-DPG_INV_LANES_PER_CU=512", "-DPG_INV_GRP=2"],
+    "inv_lanes1024_grp2": ["-DPG_INV_LANES_PER_CU=1024", "-DPG_INV_GRP=2"],
     "inv_lanes1024": ["-DPG_INV_LANES_PER_CU=1024"],
     "inv_lanes1024_grp4": ["-DPG_INV_LANES_PER_CU=1024", "-DPG_INV_GRP=4"],
     "inv_lanes128_cap64": ["-DPG_INV_LANES_PER_CU=128", "-DPG_INV_MAX_PER_LANE=64"],
