@@ -103,7 +103,8 @@ struct pg_engine {
     uint32_t *d_err_count = nullptr;
     uint64_t scratch_items = 0;
     // totals of the last plan, written by async copies into pinned host memory (read after a synchronisation)
-    struct PlanResult { uint64_t n_gates, n_vars; uint32_t errs, pad; } *h_plan = nullptr;
+    using PlanResult = pg::PlanTotals;
+    PlanResult *h_plan = nullptr;
     // scratch of the inversion pre-pass (grow-only): running products, 32 B per element
     uint4 *d_prefix = nullptr;
     uint4 *d_inv = nullptr;  // compact inverses of a split gadget's call (32 B per element)
@@ -111,6 +112,9 @@ struct pg_engine {
     // the pre-pass runs on its own stream beside the rows-only emit launch
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_inv = nullptr;
+    // a split gadget's rows launch runs on this one (normal priority) beside its pre-pass, which starts first on the caller's
+    hipStream_t rows = nullptr;
+    hipEvent_t ev_rows = nullptr;
     // the stream the last call was issued on (see enter_stream)
     hipStream_t last_stream = nullptr;
     bool have_last = false;
@@ -133,7 +137,10 @@ pg_status ensure_scratch(pg_engine *e, uint64_t batch) {
     PG_HIP_TRY(hipMalloc(&e->d_vars, items * sizeof(uint32_t)));
     PG_HIP_TRY(hipMalloc(&e->d_blk_rows, nblk * sizeof(uint64_t)));
     PG_HIP_TRY(hipMalloc(&e->d_blk_vars, nblk * sizeof(uint64_t)));
-    if (!e->d_err_count) PG_HIP_TRY(hipMalloc(&e->d_err_count, sizeof(uint32_t)));
+    if (!e->d_err_count) {
+        PG_HIP_TRY(hipMalloc(&e->d_err_count, sizeof(uint32_t)));
+        PG_HIP_TRY(hipMemset(e->d_err_count, 0, sizeof(uint32_t)));  // zero between calls (see error_plan)
+    }
     e->scratch_items = items;
     return PG_OK;
 }
@@ -141,16 +148,14 @@ pg_status ensure_scratch(pg_engine *e, uint64_t batch) {
 // counts in e->d_rows / e->d_vars and their block sums in e->d_blk_* (both left by the plan kernel) -> exclusive prefix
 // sums; totals copied back (the synchronous form synchronises the stream)
 pg_status scan_counts(pg_engine *e, uint64_t batch, uint64_t *d_row_off, uint64_t *d_var_off, uint64_t *n_rows,
-                      uint64_t *n_vars, hipStream_t st) {
+                      uint64_t *n_vars, hipStream_t st, bool with_errs) {
     const uint32_t nblk = (uint32_t)((batch + pg::kScanBlock - 1) / pg::kScanBlock);
     const uint32_t prefixed = nblk > pg::kScanDirectBlocks ? 1u : 0u;
     if (prefixed)
         hipLaunchKernelGGL(pg::scan_top_kernel, dim3(1), dim3(pg::kThreads), 0, st, e->d_blk_rows, e->d_blk_vars, nblk);
     hipLaunchKernelGGL(pg::scan_final_kernel, dim3(nblk), dim3(pg::kThreads), 0, st, e->d_rows, e->d_vars, batch,
-                       e->d_blk_rows, e->d_blk_vars, d_row_off, d_var_off, prefixed);
+                       e->d_blk_rows, e->d_blk_vars, d_row_off, d_var_off, prefixed, e->h_plan, with_errs ? e->d_err_count : nullptr);
     PG_HIP_TRY(hipGetLastError());
-    PG_HIP_TRY(hipMemcpyAsync(&e->h_plan->n_gates, d_row_off + batch, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    PG_HIP_TRY(hipMemcpyAsync(&e->h_plan->n_vars, d_var_off + batch, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     if (n_rows) {  // synchronous form
         PG_HIP_TRY(hipStreamSynchronize(st));
         *n_rows = e->h_plan->n_gates;
@@ -227,7 +232,8 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
     PG_TRY(enter_stream(e, st));
     pg::EmitOut O = make_out(c, batch, GD::W, gate_base, var_base, zero_var, row_off, var_off);
     constexpr bool kSplit = pg::Split<GD>::ok;  // the rows, then the variable table (emit.hpp, EmitMode)
-    bool side = false;  // the inversion pre-pass runs on the engine's side stream
+    bool side = false;         // the inversion pre-pass runs on the engine's side stream
+    bool rows_beside = false;  // split gadget: the rows launch runs on the engine's rows stream, beside the pre-pass
     if constexpr (GD::kInv > 0) {
         constexpr int GRP = GD::kInvGroup;
         const uint64_t elems = batch * GD::kInv;
@@ -245,13 +251,18 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
         side = false;
 #else
         // a handful of elements (the single-gadget calls of pg_composer): two event hops cost more than the overlap buys.
-        // A split gadget (small items) runs its pre-pass FIRST, on the caller's stream: its two emit launches need their full
-        // residency and the pre-pass its registers, and beside each other they take turns rather than overlap -- measured
-        // on five boxes of the pool the sequential order was the faster one on every box (0.74-0.82 ms against 0.76-0.89
-        // for the fused mix, tools/ab_emit.py run_c3), and the stable one (concurrent: median 10 % above its own minimum).
+        // A split gadget (small items) keeps its pre-pass on the caller's stream, where it STARTS FIRST, and sends the rows
+        // launch -- which needs nothing the pre-pass computes -- to the engine's rows stream to run beside it (below).
         side = elems >= 2048 && !kSplit;
 #endif
+#if !defined(PG_SPLIT_SEQUENTIAL)  // (A/B build: pre-pass, rows, variable table one after the other on the caller's stream)
+        if constexpr (kSplit) rows_beside = elems >= 2048;
+#endif
         if (!side) {
+            if (rows_beside) {  // fork: the rows launch reads the call's inputs and offsets
+                PG_HIP_TRY(hipEventRecord(e->ev_fork, st));
+                PG_HIP_TRY(hipStreamWaitEvent(e->rows, e->ev_fork, 0));
+            }
             hipLaunchKernelGGL((pg::batch_invert_kernel<GD, GRP>), dim3(blocks), dim3(pg::kThreads), 0, st, A, O, elems,
                                (uint32_t)groups, e->d_prefix, compact);
             PG_HIP_TRY(hipGetLastError());
@@ -275,7 +286,7 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
 #ifndef PG_ROWS_WGS_PER_CU
 #define PG_ROWS_WGS_PER_CU 0
 #endif
-        if (side && PG_ROWS_WGS_PER_CU > 0) {
+        if (PG_ROWS_WGS_PER_CU > 0) {
             static const size_t static_lds = [] {
                 hipFuncAttributes a{};
                 return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(pg::emit_kernel<GD, pg::EMIT_ROWS>)) == hipSuccess
@@ -284,17 +295,35 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
             const size_t want = (160 * 1024 / PG_ROWS_WGS_PER_CU) & ~(size_t)1023;  // per workgroup, so that exactly that many fit
             if (static_lds && static_lds < want && want <= 64 * 1024) pad = (uint32_t)(want - static_lds);
         }
+        // The rows are store traffic and the pre-pass integer arithmetic, and the rows need nothing the pre-pass computes:
+        // beside each other they finish ~0.05-0.1 ms earlier than one after the other (fused mix, 2^20 items: pre-pass
+        // 170 -> 320 us, rows 356 -> 461 us, together 473 instead of 527 us; tools/c3_timeline.sh).  What matters is WHO
+        // STARTS FIRST: with the pre-pass on a second stream (round 1 / early round 2, even at high priority) the rows'
+        // workgroups own every SIMD's registers before the pre-pass's fat waves (168 registers) are placed, and it becomes
+        // resident a hundred microseconds late; on the caller's stream it is dispatched first and the rows fill in around it.
+        hipStream_t rows_st = rows_beside ? e->rows : st;
         hipLaunchKernelGGL((pg::emit_kernel<GD, pg::EMIT_ROWS>), dim3(R.tiles < max_blocks ? R.tiles : max_blocks), dim3(pg::kThreads), pad,
-                           st, A, R);
+                           rows_st, A, R);
+        if (rows_beside) {  // join: the variable table, and whatever the caller does next, follow both
+            PG_HIP_TRY(hipEventRecord(e->ev_rows, e->rows));
+            PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_rows, 0));
+        }
         // grid of the variable-table launch.  Measured and not kept (tools/ab_emit.py run_c3): 6 / 8 / 16 resident
         // workgroups per CU striding over the tiles; the same with the next tile's loads issued before the current tile's
         // stores (0.713 vs 0.706 ms); lanes 2s, 2s+1 storing the halves of slot s for full-line wave stores (0.30 vs
         // 0.19 ms for this launch: twice the passes and LDS reads) -- the launch is bound by neither its loads' latency
         // nor its dispatch rate nor partial lines.
 #ifndef PG_VARS_BLOCKS_PER_CU
-#define PG_VARS_BLOCKS_PER_CU 64
+#define PG_VARS_BLOCKS_PER_CU 128
 #endif
         const uint32_t vars_blocks = (uint32_t)e->num_cus * PG_VARS_BLOCKS_PER_CU;
+#if !defined(PG_NO_VARS_IMAGE)
+        if constexpr (pg::VarsImage<GD>::ok) {
+            pg::EmitOut I = make_out(c, batch, GD::kImageW, gate_base, var_base, zero_var, row_off, var_off);
+            I.inv = O.inv;
+            hipLaunchKernelGGL(pg::vars_image_kernel<GD>, dim3(I.tiles < vars_blocks ? I.tiles : vars_blocks), dim3(GD::kImageW * GD::kImageParts), 0, st, A, I);
+        } else
+#endif
         hipLaunchKernelGGL((pg::emit_kernel<GD, pg::EMIT_VARS>), dim3(O.tiles < vars_blocks ? O.tiles : vars_blocks), dim3(pg::kThreads), 0,
                            st, A, O);
     } else {
@@ -339,14 +368,13 @@ pg_status error_plan(pg_engine *e, PlanKernel kernel, const pg_scalar *d_value, 
     PG_TRY(ensure_scratch(e, batch));
     hipStream_t st = static_cast<hipStream_t>(stream);
     PG_TRY(enter_stream(e, st));
-    PG_HIP_TRY(hipMemsetAsync(e->d_err_count, 0, sizeof(uint32_t), st));
+    // e->d_err_count is zero between calls: whoever reads it (scan_final_kernel, the bulk decoder) leaves it so
     const uint32_t grid = (uint32_t)((batch + pg::kScanBlock - 1) / pg::kScanBlock);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(pg::kThreads), 0, st, reinterpret_cast<const uint4 *>(d_value), batch,
                        e->d_rows, e->d_vars, d_err_mask, e->d_err_count, e->d_blk_rows, e->d_blk_vars);
     PG_HIP_TRY(hipGetLastError());
-    PG_HIP_TRY(hipMemcpyAsync(&e->h_plan->errs, e->d_err_count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    if (!out) return scan_counts(e, batch, d_row_off, d_var_off, nullptr, nullptr, st);
-    PG_TRY(scan_counts(e, batch, d_row_off, d_var_off, &out->n_gates, &out->n_vars, st));
+    if (!out) return scan_counts(e, batch, d_row_off, d_var_off, nullptr, nullptr, st, true);
+    PG_TRY(scan_counts(e, batch, d_row_off, d_var_off, &out->n_gates, &out->n_vars, st, true));
     const uint32_t errs = e->h_plan->errs;
     if (err_count) *err_count = errs;
     if (errs) return fail(PG_ERR_NON_EXISTING_INVERSE, std::to_string(errs) + " item(s) have no inverse (value = 0)");
@@ -408,7 +436,9 @@ pg_status pg_engine_create(int device, pg_engine **out) {
     if (hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_inv, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_switch, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&e->ev_switch, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->rows, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_rows, hipEventDisableTiming) != hipSuccess) {
         pg_engine_destroy(e);
         return fail(PG_ERR_HIP, "creating the engine's side stream / events failed");
     }
@@ -434,6 +464,8 @@ void pg_engine_destroy(pg_engine *e) {
     if (e->d_prefix) (void)hipFree(e->d_prefix);
     if (e->d_inv) (void)hipFree(e->d_inv);
     if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
+    if (e->rows) { (void)hipStreamSynchronize(e->rows); (void)hipStreamDestroy(e->rows); }
+    if (e->ev_rows) (void)hipEventDestroy(e->ev_rows);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_inv) (void)hipEventDestroy(e->ev_inv);
     if (e->ev_switch) (void)hipEventDestroy(e->ev_switch);
@@ -463,6 +495,7 @@ pg_status pg_scalars_from_canonical_batch(pg_engine *e, const void *d_bytes, uin
                        static_cast<const uint4 *>(d_bytes), batch, reinterpret_cast<uint4 *>(d_out), d_bad_mask, e->d_err_count);
     PG_HIP_TRY(hipGetLastError());
     PG_HIP_TRY(hipMemcpyAsync(&e->h_plan->errs, e->d_err_count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    PG_HIP_TRY(hipMemsetAsync(e->d_err_count, 0, sizeof(uint32_t), st));  // zero between calls (see error_plan)
     PG_HIP_TRY(hipStreamSynchronize(st));
     const uint32_t bad = e->h_plan->errs;
     if (bad_count) *bad_count = bad;
@@ -689,12 +722,9 @@ static pg_status max_bound_ragged_plan_common(pg_engine *e, const pg_scalar *d_m
                        reinterpret_cast<const uint4 *>(d_max_range), batch, e->d_pow2, d_num_bits, e->d_rows, e->d_vars,
                        e->d_blk_rows, e->d_blk_vars);
     PG_HIP_TRY(hipGetLastError());
-    // a max_bound plan has no failing items: zero the error word IN STREAM ORDER (an earlier plan's asynchronous copy into
-    // the same pinned word may still be in flight)
-    PG_HIP_TRY(hipMemsetAsync(e->d_err_count, 0, sizeof(uint32_t), st));
-    PG_HIP_TRY(hipMemcpyAsync(&e->h_plan->errs, e->d_err_count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    if (!out) return scan_counts(e, batch, d_row_off, d_var_off, nullptr, nullptr, st);
-    PG_TRY(scan_counts(e, batch, d_row_off, d_var_off, &out->n_gates, &out->n_vars, st));
+    // a max_bound plan has no failing items: the scan writes errs = 0 with the totals, in stream order
+    if (!out) return scan_counts(e, batch, d_row_off, d_var_off, nullptr, nullptr, st, false);
+    PG_TRY(scan_counts(e, batch, d_row_off, d_var_off, &out->n_gates, &out->n_vars, st, false));
     return PG_OK;
 }
 

@@ -488,6 +488,55 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
     }
 }
 
+// ---- the variable table of a split gadget, as an image -------------------------------------------------------------------
+// The variables of a tile's items are ONE contiguous piece of the table (whatever the items' shapes: the prefix sums say
+// where each item starts).  A workgroup builds that piece in LDS exactly as it will lie in memory -- the kImageParts lanes
+// of an item share its slots out between them (GD::image_part: lanes of one part are consecutive, so the Montgomery
+// multiplication is a few half-waves', the copies of inputs the others') -- and then copies it out linearly, 16 bytes
+// per lane: every wave store is one contiguous KiB, and the copy loop has no index arithmetic at all.  Against the
+// EMIT_VARS launch of emit_kernel (a 32-byte slot per lane as two half-line stores, the slot's value selected from a
+// per-item record on every pass, the constant table filled once per workgroup for a workgroup that lives for one tile).
+template <class GD, class = void>
+struct VarsImage {
+    static constexpr bool ok = false;
+};
+template <class GD>
+struct VarsImage<GD, std::void_t<decltype(GD::kImageW)>> {
+    static constexpr bool ok = true;
+};
+
+template <class GD>
+__global__ __launch_bounds__(GD::kImageW * GD::kImageParts) void vars_image_kernel(const typename GD::Args A, const EmitOut O) {
+    constexpr int W = GD::kImageW;
+    constexpr uint32_t kLanes = W * GD::kImageParts;
+    __shared__ uint4 s_img[W * GD::kUniformVars * 2];
+    const uint32_t tid = threadIdx.x, it = tid % W, part = tid / W;
+    for (uint32_t tile = blockIdx.x; tile < O.tiles; tile += gridDim.x) {
+        const uint64_t w0 = (uint64_t)tile * W;
+        const uint32_t Wt = (uint32_t)((O.batch - w0) < (uint64_t)W ? (O.batch - w0) : (uint64_t)W);
+#if defined(PG_ABLATE_ITEM_PHASE)  // timing-only build (wrong output): the copy alone
+        const uint64_t v0 = w0 * GD::kUniformVars, v1 = (w0 + Wt) * GD::kUniformVars;
+        (void)it; (void)part;
+#else
+        const uint64_t v0 = O.var_off[w0], v1 = O.var_off[w0 + Wt];
+        if (it < Wt) {
+            const uint64_t mine = O.var_off[w0 + it], next = O.var_off[w0 + it + 1];
+            GD::image_part(A, O, w0 + it, part, (uint32_t)(next - mine), s_img + (mine - v0) * 2, O.var_base + mine);
+        }
+#endif
+        lds_barrier();
+        const uint32_t n16 = (uint32_t)(v1 - v0) * 2;
+        uint4 *dst = O.vars + v0 * 2;
+        for (uint32_t o = tid; o < n16; o += kLanes) {
+#if defined(PG_ABLATE_VAR_STORES)  // timing-only build (wrong output): the image without its way out
+            if (s_img[o].x == 0x12345678u && s_img[o].w == 0x9abcdef0u)
+#endif
+            store16(dst + o, s_img[o]);
+        }
+        lds_barrier();  // the image is rewritten by the next tile
+    }
+}
+
 // bare streaming fill: the practical write ceiling the emitters are compared with.  The buffer is split into
 // `streams` equal contiguous parts that every workgroup advances together, 4 KiB per part per pass -- the emitters'
 // shape (five selector columns at once); one single linear stream measures ~18 % lower on MI355X.
@@ -598,9 +647,18 @@ __device__ __forceinline__ void plan_block_sums(uint64_t r, uint64_t v, uint64_t
 // exclusive prefix sums
 constexpr uint32_t kScanDirectBlocks = 4096;
 
+// The totals of the plan -- rows, variables, and the plan kernel's count of failing items (err_count, or NULL for a plan
+// that has none) -- go straight to the engine's pinned result record `host` (a device-visible host address: three
+// 4..8-byte copies cost three copy launches, ~15 us of a 0.65 ms step); err_count is left at zero for the next plan.
+struct PlanTotals {
+    uint64_t n_gates, n_vars;
+    uint32_t errs, pad;
+};
+
 __global__ __launch_bounds__(kThreads) void scan_final_kernel(const uint32_t *rows, const uint32_t *vars, uint64_t n,
                                                              const uint64_t *blk_rows, const uint64_t *blk_vars,
-                                                             uint64_t *row_off, uint64_t *var_off, uint32_t blk_prefixed) {
+                                                             uint64_t *row_off, uint64_t *var_off, uint32_t blk_prefixed,
+                                                             PlanTotals *host, uint32_t *err_count) {
     __shared__ uint64_t s_warp[4];
     const uint64_t base = (uint64_t)blockIdx.x * kScanBlock;
     uint64_t br, bv;
@@ -629,7 +687,15 @@ __global__ __launch_bounds__(kThreads) void scan_final_kernel(const uint32_t *ro
         if (i < n) { row_off[i] = er; var_off[i] = ev; }
         er += r[k];
         ev += v[k];
-        if (i + 1 == n) { row_off[n] = er; var_off[n] = ev; }
+        if (i + 1 == n) {
+            row_off[n] = er;
+            var_off[n] = ev;
+            host->n_gates = er;
+            host->n_vars = ev;
+            host->errs = err_count ? *err_count : 0u;
+            if (err_count) *err_count = 0;
+            __threadfence_system();
+        }
     }
 }
 

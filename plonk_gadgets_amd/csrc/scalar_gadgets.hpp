@@ -385,6 +385,53 @@ struct ScalarMixGD {
         row(R, vbase, O.zero_var, j, r);
         out[0] = r.w[0]; out[1] = r.w[1]; out[2] = r.w[2];
     }
+    // the variable table as an image (emit.hpp, vars_image_kernel): the item's slots, shared out over four waves.  `img` is
+    // where the item's first variable lies in the tile's image, `nvars` how many it has (13: it stopped at its error and
+    // has no inv / one), `vb` its first Variable.
+#ifndef PG_IMAGE_W
+#define PG_IMAGE_W 64
+#endif
+    static constexpr int kImageW = PG_IMAGE_W, kImageParts = 4;
+    __device__ static void put(uint4 *img, uint32_t slot, const Fr &x) {
+        FrVec t;
+        t.f = x;
+        img[2 * slot] = t.v[0];
+        img[2 * slot + 1] = t.v[1];
+    }
+    __device__ static void image_part(const Args &A, const EmitOut &O, uint64_t item, uint32_t part, uint32_t nvars, uint4 *img,
+                                      uint64_t vb) {
+        const bool err = nvars != kUniformVars;
+        const uint32_t tail = err ? 6 : 8;  // one' sy oms out | u z yeq
+        if (part == 0) {  // v, var_assigned = v (scalar.rs:69), the two constants (scalar.rs:83, :41), the results' Variables
+            const Fr v = load_fr(A.v, item);
+            put(img, 0, v);
+            put(img, 5, v);
+            if (!err) put(img, 7, fr_one());
+            put(img, tail, fr_one());
+            if (A.result_vars) {
+                A.result_vars[2 * item] = vb + tail + 3;
+                A.result_vars[2 * item + 1] = vb + tail + 6;
+            }
+        } else if (part == 1) {  // y, s and select_one's three values
+            const Fr y = load_fr(A.y, item), s = load_fr(A.s, item);
+            put(img, 1, y);
+            put(img, 2, s);
+            const Fr sy = fr_mul(y, s), oms = fr_sub(fr_one(), s);  // scalar.rs:43, :45-50
+            put(img, tail + 1, sy);
+            put(img, tail + 2, oms);
+            put(img, tail + 3, fr_add(sy, oms));                    // scalar.rs:53-58
+        } else if (part == 2) {  // a, b and maybe_equal's difference and result
+            const Fr a = load_fr(A.a, item), b = load_fr(A.b, item);
+            put(img, 3, a);
+            put(img, 4, b);
+            const Fr u = fr_sub(a, b);                              // scalar.rs:111-117
+            put(img, tail + 4, u);
+            put(img, tail + 6, fr_is_zero(u) ? fr_one() : fr_zero());  // y = 1 - u z, scalar.rs:126
+        } else {  // the two inverses, from the pre-pass's compact output: element e of item i at [e * batch + i]
+            if (!err) put(img, 6, load_fr(O.inv, item));            // scalar.rs:77
+            put(img, tail + 5, load_fr(O.inv, O.batch + item));     // scalar.rs:122-123 (0 when a = b)
+        }
+    }
     // variable kc of a full-shape item: [v y s a b | va inv one | one' sy oms out | u z yeq]
     __device__ static Fr var_value_full(const Args &, const ItemRec &R, const uint4 *, uint32_t kc) {
         if (kc < 5) return R.d[kc];

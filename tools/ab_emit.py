@@ -17,11 +17,23 @@ VDIR = os.path.join(ROOT, "tools", "variants")
 VARIANTS = {
     "r1": None,  # round 1's library, built by hand from `git archive 937331d` (not rebuilt by `build`)
     "base": [],
+    "no_vars_image": ["-DPG_NO_VARS_IMAGE"],  # the split gadget's variable table through emit_kernel<GD, EMIT_VARS>
     "sequential_prepass": ["-DPG_SEQUENTIAL_PREPASS"],
     "invert_fermat": ["-DPG_INVERT_FERMAT"],
     "sequential_fermat": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_INVERT_FERMAT"],
     "no_periodic": ["-DPG_NO_PERIODIC"],
     "full_barriers": ["-DPG_FULL_BARRIERS"],
+    "img_w64": ["-DPG_IMAGE_W=64"],
+    "split_sequential": ["-DPG_SPLIT_SEQUENTIAL"],  # split gadget: pre-pass, rows, variables one after the other
+    "beside_rows5": ["-DPG_ROWS_WGS_PER_CU=5"],
+    "beside_rows6": ["-DPG_ROWS_WGS_PER_CU=6"],
+    "beside_l512": ["-DPG_INV_LANES_PER_CU=512"],
+    "beside_grp8": ["-DPG_INV_GRP=8"],
+    "abl_item": ["-DPG_ABLATE_ITEM_PHASE"],
+    "abl_item_b5": ["-DPG_ABLATE_ITEM_PHASE", "-DPG_VARS_BLOCKS_PER_CU=5"],
+    "abl_item_b10": ["-DPG_ABLATE_ITEM_PHASE", "-DPG_VARS_BLOCKS_PER_CU=10"],
+    "abl_stores": ["-DPG_ABLATE_VAR_STORES"],
+    "vars_b5": ["-DPG_VARS_BLOCKS_PER_CU=5"],
     "abl_var_stores": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_ABLATE_VAR_STORES"],   # timing only
     "abl_item_phase": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_ABLATE_ITEM_PHASE"],   # timing only
     "abl_both": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_ABLATE_ITEM_PHASE", "-DPG_ABLATE_VAR_STORES"],
