@@ -252,7 +252,8 @@ class Workload:
                 part = [t[c * chunk:(c + 1) * chunk] for t in ins]
                 eng.scalar_mix_plan_async(part[0], roff, voff)  # no host round trip: the buffers hold the worst case
                 eng.scalar_mix_emit(*part, roff, voff, cols, res, 3, 5, 0)
-            self.kernel = "pg::emit_kernel<pg::ScalarMixGD> (+ the plan kernel and the inversion pre-pass)"
+            self.kernel = ("one step: plan + scan, then the inversion pre-pass with pg::emit_kernel<pg::ScalarMixGD, EMIT_ROWS> beside it, "
+                           "then pg::vars_image_kernel<pg::ScalarMixGD>")
             self.desc = ("C3: 2^%d items/GPU x (5 add_input + is_non_zero + conditionally_select_one + maybe_equal), "
                          "one emit launch, 10 rows + 15 vars per item" % log2_batch)
         else:

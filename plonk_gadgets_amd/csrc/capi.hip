@@ -304,10 +304,12 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
         hipStream_t rows_st = rows_beside ? e->rows : st;
         hipLaunchKernelGGL((pg::emit_kernel<GD, pg::EMIT_ROWS>), dim3(R.tiles < max_blocks ? R.tiles : max_blocks), dim3(pg::kThreads), pad,
                            rows_st, A, R);
-        if (rows_beside) {  // join: the variable table, and whatever the caller does next, follow both
+#if defined(PG_VARS_AFTER_ROWS)  // A/B build: the variable table waits for the rows too
+        if (rows_beside) {
             PG_HIP_TRY(hipEventRecord(e->ev_rows, e->rows));
             PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_rows, 0));
         }
+#endif
         // grid of the variable-table launch.  Measured and not kept (tools/ab_emit.py run_c3): 6 / 8 / 16 resident
         // workgroups per CU striding over the tiles; the same with the next tile's loads issued before the current tile's
         // stores (0.713 vs 0.706 ms); lanes 2s, 2s+1 storing the halves of slot s for full-line wave stores (0.30 vs
@@ -326,6 +328,16 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
 #endif
         hipLaunchKernelGGL((pg::emit_kernel<GD, pg::EMIT_VARS>), dim3(O.tiles < vars_blocks ? O.tiles : vars_blocks), dim3(pg::kThreads), 0,
                            st, A, O);
+        // The variable table follows the pre-pass on the caller's stream and does NOT wait for the rows (it writes another
+        // column): it starts while the rows are still streaming and fills the time its own workgroups spend waiting for
+        // their inputs.  Five boxes, fused mix, 2^20 items: 0.60-0.65 ms per call against 0.63-0.68 with the variable table
+        // after the rows and 0.64-0.67 with all three launches one after the other (tools/ab_emit.py run_c3).
+#if !defined(PG_VARS_AFTER_ROWS)
+        if (rows_beside) {  // join: whatever the caller does next follows both streams
+            PG_HIP_TRY(hipEventRecord(e->ev_rows, e->rows));
+            PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_rows, 0));
+        }
+#endif
     } else {
         hipLaunchKernelGGL(pg::emit_kernel<GD>, dim3(O.tiles < max_blocks ? O.tiles : max_blocks), dim3(pg::kThreads), 0, st, A, O);
     }
@@ -428,6 +440,13 @@ pg_status pg_engine_create(int device, pg_engine **out) {
     *e->h_plan = pg_engine::PlanResult{0, 0, 0, 0};
     // the pre-pass is the critical path of a call with small items: highest priority, so its waves are placed ahead of
     // the rows-only emit launch it runs beside
+    // the rows stream has the LOWEST priority: the pre-pass and the variable table are the chain that ends the call, the rows
+    // fill in around them (normal priority: +3 %; highest: +15 % on the fused mix's step, tools/ab_emit.py)
+#if defined(PG_ROWS_STREAM_NORMAL)  // A/B build
+#define PG_ROWS_STREAM_PRIORITY(lo) 0
+#else
+#define PG_ROWS_STREAM_PRIORITY(lo) (lo)
+#endif
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
 #if defined(PG_SIDE_STREAM_NORMAL_PRIORITY)
@@ -437,7 +456,7 @@ pg_status pg_engine_create(int device, pg_engine **out) {
         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_inv, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_switch, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&e->rows, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithPriority(&e->rows, hipStreamNonBlocking, PG_ROWS_STREAM_PRIORITY(prio_lo)) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_rows, hipEventDisableTiming) != hipSuccess) {
         pg_engine_destroy(e);
         return fail(PG_ERR_HIP, "creating the engine's side stream / events failed");

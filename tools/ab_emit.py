@@ -25,6 +25,10 @@ VARIANTS = {
     "full_barriers": ["-DPG_FULL_BARRIERS"],
     "img_w64": ["-DPG_IMAGE_W=64"],
     "split_sequential": ["-DPG_SPLIT_SEQUENTIAL"],  # split gadget: pre-pass, rows, variables one after the other
+    "rows_stream_normal": ["-DPG_ROWS_STREAM_NORMAL"],  # split gadget: the rows stream at normal instead of lowest priority
+    "vars_after_rows": ["-DPG_VARS_AFTER_ROWS"],  # split gadget: the variable table waits for the rows launch as well
+    "vars_after_rows5": ["-DPG_VARS_AFTER_ROWS", "-DPG_ROWS_WGS_PER_CU=5"],
+    "beside_rows4": ["-DPG_ROWS_WGS_PER_CU=4"],
     "beside_rows5": ["-DPG_ROWS_WGS_PER_CU=5"],
     "beside_rows6": ["-DPG_ROWS_WGS_PER_CU=6"],
     "beside_l512": ["-DPG_INV_LANES_PER_CU=512"],

@@ -31,7 +31,7 @@ for w in ("c2", "c3", "c4"):
         f = newest(os.path.join(SRC, f"{kind}_{w}", "*", "*counter_collection.csv"))
         # every kernel of the one step the PMC pass runs (steps = 1, warmup = 0): the emit launch(es), the inversion
         # pre-pass, the plan and its prefix-sum launch
-        keep = [r for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in ("emit_kernel", "batch_invert", "plan_kernel", "scan_"))]
+        keep = [r for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in ("emit_kernel", "vars_image", "batch_invert", "plan_kernel", "scan_"))]
         with open(os.path.join(DST, f"{R}_{w}_pmc_{cn.lower()}.csv"), "w") as o:
             wr = csv.DictWriter(o, fieldnames=list(keep[0].keys()))
             wr.writeheader()
@@ -45,6 +45,21 @@ for w in ("c2", "c3", "c4"):
                                "round": R,
                                "note": "rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate passes; FETCH_SIZE doubled "
                                        "(gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md section HBM)"}}
+    # launches of one step overlap (the fused mix's rows run beside its pre-pass, its variable table beside the rows): the
+    # step's duration is the SPAN of its kernels, not the sum of their durations -- from the kernel trace, last step
+    tr = newest(os.path.join(SRC, f"stats_{w}", "*", "*kernel_trace.csv"))
+    ks = sorted(csv.DictReader(open(tr)), key=lambda r: int(r["Start_Timestamp"]))
+    ks = [r for r in ks if any(k in r["Kernel_Name"] for k in ("emit_kernel", "vars_image", "batch_invert", "plan_kernel", "scan_"))]
+    firsts = [i for i, r in enumerate(ks) if "plan_kernel" in r["Kernel_Name"]] or [i for i, r in enumerate(ks) if "emit_kernel" in r["Kernel_Name"]]
+    step = ks[firsts[-1]:]
+    t0 = int(step[0]["Start_Timestamp"])
+    with open(os.path.join(DST, f"{R}_{w}_step_timeline.txt"), "w") as o:
+        o.write(f"# {w}: kernels of the last step of `bench.py --workload {w} --steps 5` under rocprofv3 --kernel-trace: start .. end (us)\n")
+        for r in step:
+            o.write(f"{(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} .. {(int(r['End_Timestamp']) - t0) / 1e3:9.1f}  {r['Kernel_Name'].split('(')[0][-70:]}\n")
+        span = (max(int(r["End_Timestamp"]) for r in step) - t0) / 1e3
+        o.write(f"# span {span:.1f} us; sum of durations {sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in step) / 1e3:.1f} us\n")
+    print(w, "step span us", span)
     rows = list(csv.DictReader(open(st)))
     for r in rows[:3]:
         print(w, r["Name"][:72], r["Calls"], "avg_us=%.1f" % (float(r["AverageNs"]) / 1e3))
