@@ -30,6 +30,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -53,6 +54,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C4 measurements after the headline")
     ap.add_argument("--allgather-log2-chunk", type=int, default=12, help="N>1: witnesses per rank per gathered chunk")
+    ap.add_argument("--allgather-timeout", type=float, default=240.0, help="N>1: seconds before the gather-inclusive sample is abandoned")
     ap.add_argument("--allgather-chunks", type=int, default=8, help="N>1: chunks in the gather-inclusive sample (0: skip)")
     return ap.parse_args(argv)
 
@@ -344,6 +346,15 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it with --nproc-per-node {args.gpus} "
                          f"(or plainly, and it starts the ranks itself)")
 
+    # stdout carries ONE JSON line: libraries that talk on it (RCCL prints its version banner there when a communicator is
+    # created) are sent to stderr -- fd 1 is pointed at fd 2, and the line goes to a duplicate of the real stdout
+    sys.stdout.flush()
+    out_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(out_fd, (json.dumps(obj) + "\n").encode())
+
     import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
@@ -429,9 +440,41 @@ def main():
             except Exception as ex:  # a secondary figure must never cost the headline line
                 secondary[name] = {"error": repr(ex)}
 
+    line = {
+        "metric": "gadget constraints/sec (range_check 256-bit)" if args.workload == "c2"
+                  else f"gadget constraints/sec ({args.workload})",
+        "value": value,
+        "unit": "constraints/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64x4 (BLS12-381 scalar, Montgomery limbs)",
+        "data": "synthetic (splitmix64 streams, uniform field elements)",
+        "config": config,
+        "roofline": roofline,
+        "hbm_free_gb_at_start": free / 1e9, "hbm_total_gb": total / 1e9,
+    }
+    if secondary:
+        line["secondary"] = secondary
+
     # ---- N > 1: gather-inclusive rate of the chunked all-gather pipeline (bounded sample) -----------------
     allgather = None
+    watchdog = None
     if distributed and backend == "nccl" and args.workload == "c2" and args.allgather_chunks > 0:
+        # the headline is measured; a collective that hangs (a link, a rank that died) must not cost it: after the limit
+        # rank 0 prints the line it has, and every rank leaves
+        def bail():
+            if rank == 0:
+                line["allgather"] = {"error": f"the gather-inclusive sample did not finish within {args.allgather_timeout} s; abandoned"}
+                emit(line)
+            os._exit(0)
+        watchdog = threading.Timer(args.allgather_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
         from plonk_gadgets_amd import distributed as pd
         G = 1031
         gchunk = 1 << args.allgather_log2_chunk
@@ -470,32 +513,14 @@ def main():
         except Exception as ex:
             allgather["variables_only"] = {"error": repr(ex)}
 
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
-        line = {
-            "metric": "gadget constraints/sec (range_check 256-bit)" if args.workload == "c2"
-                      else f"gadget constraints/sec ({args.workload})",
-            "value": value,
-            "unit": "constraints/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u64x4 (BLS12-381 scalar, Montgomery limbs)",
-            "data": "synthetic (splitmix64 streams, uniform field elements)",
-            "config": config,
-            "roofline": roofline,
-            "hbm_free_gb_at_start": free / 1e9, "hbm_total_gb": total / 1e9,
-        }
-        if secondary:
-            line["secondary"] = secondary
         if allgather:
             line["allgather"] = allgather
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample)
-        print(json.dumps(line), flush=True)
+        emit(line)
     if distributed:
         dist.destroy_process_group()
     eng.close()
