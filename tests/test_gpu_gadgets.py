@@ -194,7 +194,10 @@ def mix_inputs(batch, seed, zeros=()):
     return v, y, s, a, b
 
 
-@pytest.mark.parametrize("batch,zeros", [(1, ()), (4, (2,)), (128, ()), (129, (0, 127, 128)), (1000, (5, 500, 999))])
+# 5003 items: past the size where the rows launch runs beside the pre-pass on the engine's second stream, not a multiple of
+# any tile width, and ragged (items that stop at their error, at tile edges of the rows / variable-image launches too)
+@pytest.mark.parametrize("batch,zeros", [(1, ()), (4, (2,)), (128, ()), (129, (0, 127, 128)), (1000, (5, 500, 999)),
+                                         (5003, (0, 63, 64, 255, 256, 257, 1023, 1024, 4095, 4096, 4992, 5002))])
 def test_scalar_mix_batch(engine, batch, zeros):
     from oracle import pyoracle as po
     v, y, s, a, b = mix_inputs(batch, 41, zeros)
