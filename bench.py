@@ -252,10 +252,14 @@ class Workload:
             def launch(c):
                 # the plan (zero test + prefix sums) is part of the pass: the inputs decide the ragged layout
                 part = [t[c * chunk:(c + 1) * chunk] for t in ins]
-                eng.scalar_mix_plan_async(part[0], roff, voff)  # no host round trip: the buffers hold the worst case
-                eng.scalar_mix_emit(*part, roff, voff, cols, res, 3, 5, 0)
-            self.kernel = ("one step: plan + scan, then the inversion pre-pass with pg::emit_kernel<pg::ScalarMixGD, EMIT_ROWS> beside it, "
-                           "then pg::vars_image_kernel<pg::ScalarMixGD>")
+                # no host round trip: the buffers hold the worst case
+                if os.environ.get("PG_C3_SEPARATE_PLAN") == "1":  # (A/B: the plan as its own call ahead of the emit call)
+                    eng.scalar_mix_plan_async(part[0], roff, voff)
+                    eng.scalar_mix_emit(*part, roff, voff, cols, res, 3, 5, 0)
+                else:
+                    eng.scalar_mix_planned(*part, roff, voff, cols, res, None, 3, 5, 0)
+            self.kernel = ("one step (pg_scalar_mix_planned_batch): the inversion pre-pass, beside it plan + scan and "
+                           "pg::emit_kernel<pg::ScalarMixGD, EMIT_ROWS>, then pg::vars_image_kernel<pg::ScalarMixGD>")
             self.desc = ("C3: 2^%d items/GPU x (5 add_input + is_non_zero + conditionally_select_one + maybe_equal), "
                          "one emit launch, 10 rows + 15 vars per item" % log2_batch)
         else:

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <initializer_list>
 #include <new>
+#include <functional>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -114,7 +115,7 @@ struct pg_engine {
     hipEvent_t ev_fork = nullptr, ev_inv = nullptr;
     // a split gadget's rows launch runs on this one (normal priority) beside its pre-pass, which starts first on the caller's
     hipStream_t rows = nullptr;
-    hipEvent_t ev_rows = nullptr;
+    hipEvent_t ev_rows = nullptr, ev_plan = nullptr;
     // the stream the last call was issued on (see enter_stream)
     hipStream_t last_stream = nullptr;
     bool have_last = false;
@@ -224,9 +225,14 @@ pg_status enter_stream(pg_engine *e, hipStream_t st) {
 // on the engine's high-priority side stream.  The two write disjoint bytes (the pre-pass owns the inverse slots of
 // the variable table), so they run concurrently; the caller's stream is made to wait for both before the call's
 // results can be consumed.
+// a plan (its kernels, on the stream it is handed) that a call launches itself: the offsets the emit launches read are then
+// produced inside the call, and a split gadget's pre-pass -- which reads the inputs only -- does not wait for them
+using PlanLaunch = std::function<pg_status(hipStream_t)>;
+
 template <class GD>
 pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, uint64_t batch, uint64_t gate_base,
-                 uint64_t var_base, uint64_t zero_var, const uint64_t *row_off, const uint64_t *var_off, void *stream) {
+                 uint64_t var_base, uint64_t zero_var, const uint64_t *row_off, const uint64_t *var_off, void *stream,
+                 const PlanLaunch *plan = nullptr) {
     if ((batch + GD::W - 1) / GD::W > 0xffffffffull) return fail(PG_ERR_INVALID_ARGUMENT, "batch too large for one call");
     hipStream_t st = static_cast<hipStream_t>(stream);
     PG_TRY(enter_stream(e, st));
@@ -234,6 +240,7 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
     constexpr bool kSplit = pg::Split<GD>::ok;  // the rows, then the variable table (emit.hpp, EmitMode)
     bool side = false;         // the inversion pre-pass runs on the engine's side stream
     bool rows_beside = false;  // split gadget: the rows launch runs on the engine's rows stream, beside the pre-pass
+    bool plan_beside = false;  // ... and so does the plan the call was handed
     if constexpr (GD::kInv > 0) {
         constexpr int GRP = GD::kInvGroup;
         const uint64_t elems = batch * GD::kInv;
@@ -262,7 +269,13 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
             if (rows_beside) {  // fork: the rows launch reads the call's inputs and offsets
                 PG_HIP_TRY(hipEventRecord(e->ev_fork, st));
                 PG_HIP_TRY(hipStreamWaitEvent(e->rows, e->ev_fork, 0));
+                if (plan) {  // the plan goes ahead of the rows on their stream, beside the pre-pass
+                    PG_TRY((*plan)(e->rows));
+                    PG_HIP_TRY(hipEventRecord(e->ev_plan, e->rows));
+                    plan_beside = true;
+                }
             }
+            if (plan && !plan_beside) PG_TRY((*plan)(st));
             hipLaunchKernelGGL((pg::batch_invert_kernel<GD, GRP>), dim3(blocks), dim3(pg::kThreads), 0, st, A, O, elems,
                                (uint32_t)groups, e->d_prefix, compact);
             PG_HIP_TRY(hipGetLastError());
@@ -276,6 +289,7 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
         }
     }
     const uint32_t max_blocks = (uint32_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
+    if (plan && (side || GD::kInv == 0)) PG_TRY((*plan)(st));  // (no caller today: a planned call of a gadget that is not split)
     if constexpr (kSplit) {
         const pg::EmitOut R = make_out(c, batch, GD::kRowsW, gate_base, var_base, zero_var, row_off, var_off);
         // PG_ROWS_WGS_PER_CU > 0 (A/B builds): hold the rows launch to that many workgroups per CU, by asking for LDS it does
@@ -319,6 +333,7 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
 #define PG_VARS_BLOCKS_PER_CU 128
 #endif
         const uint32_t vars_blocks = (uint32_t)e->num_cus * PG_VARS_BLOCKS_PER_CU;
+        if (plan_beside) PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_plan, 0));  // the variable table reads the offsets
 #if !defined(PG_NO_VARS_IMAGE)
         if constexpr (pg::VarsImage<GD>::ok) {
             pg::EmitOut I = make_out(c, batch, GD::kImageW, gate_base, var_base, zero_var, row_off, var_off);
@@ -362,6 +377,17 @@ pg_status scalar_args(const pg_variable *a_var, const pg_scalar *a_val, const pg
     return PG_OK;
 }
 
+// the launches of an asynchronous plan of a gadget with failing items (scratch ensured, arguments checked by the caller)
+template <class PlanKernel>
+pg_status error_plan_launch(pg_engine *e, PlanKernel kernel, const pg_scalar *d_value, uint64_t batch, uint64_t *d_row_off,
+                            uint64_t *d_var_off, uint8_t *d_err_mask, hipStream_t st) {
+    const uint32_t grid = (uint32_t)((batch + pg::kScanBlock - 1) / pg::kScanBlock);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(pg::kThreads), 0, st, reinterpret_cast<const uint4 *>(d_value), batch,
+                       e->d_rows, e->d_vars, d_err_mask, e->d_err_count, e->d_blk_rows, e->d_blk_vars);
+    PG_HIP_TRY(hipGetLastError());
+    return scan_counts(e, batch, d_row_off, d_var_off, nullptr, nullptr, st, true);
+}
+
 // out == NULL: asynchronous form (results through pg_plan_result)
 template <class PlanKernel>
 pg_status error_plan(pg_engine *e, PlanKernel kernel, const pg_scalar *d_value, uint64_t batch, uint64_t *d_row_off,
@@ -380,12 +406,12 @@ pg_status error_plan(pg_engine *e, PlanKernel kernel, const pg_scalar *d_value, 
     PG_TRY(ensure_scratch(e, batch));
     hipStream_t st = static_cast<hipStream_t>(stream);
     PG_TRY(enter_stream(e, st));
+    if (!out) return error_plan_launch(e, kernel, d_value, batch, d_row_off, d_var_off, d_err_mask, st);
     // e->d_err_count is zero between calls: whoever reads it (scan_final_kernel, the bulk decoder) leaves it so
     const uint32_t grid = (uint32_t)((batch + pg::kScanBlock - 1) / pg::kScanBlock);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(pg::kThreads), 0, st, reinterpret_cast<const uint4 *>(d_value), batch,
                        e->d_rows, e->d_vars, d_err_mask, e->d_err_count, e->d_blk_rows, e->d_blk_vars);
     PG_HIP_TRY(hipGetLastError());
-    if (!out) return scan_counts(e, batch, d_row_off, d_var_off, nullptr, nullptr, st, true);
     PG_TRY(scan_counts(e, batch, d_row_off, d_var_off, &out->n_gates, &out->n_vars, st, true));
     const uint32_t errs = e->h_plan->errs;
     if (err_count) *err_count = errs;
@@ -457,7 +483,8 @@ pg_status pg_engine_create(int device, pg_engine **out) {
         hipEventCreateWithFlags(&e->ev_inv, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_switch, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithPriority(&e->rows, hipStreamNonBlocking, PG_ROWS_STREAM_PRIORITY(prio_lo)) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_rows, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&e->ev_rows, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_plan, hipEventDisableTiming) != hipSuccess) {
         pg_engine_destroy(e);
         return fail(PG_ERR_HIP, "creating the engine's side stream / events failed");
     }
@@ -485,6 +512,7 @@ void pg_engine_destroy(pg_engine *e) {
     if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
     if (e->rows) { (void)hipStreamSynchronize(e->rows); (void)hipStreamDestroy(e->rows); }
     if (e->ev_rows) (void)hipEventDestroy(e->ev_rows);
+    if (e->ev_plan) (void)hipEventDestroy(e->ev_plan);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_inv) (void)hipEventDestroy(e->ev_inv);
     if (e->ev_switch) (void)hipEventDestroy(e->ev_switch);
@@ -880,6 +908,32 @@ pg_status pg_scalar_mix_batch(pg_engine *e, const pg_scalar *d_v, const pg_scala
     A.b = reinterpret_cast<const uint4 *>(d_b);
     A.result_vars = d_result_vars;
     return launch<pg::ScalarMixGD>(e, A, out, batch, gate_base, var_base, zero_var, d_row_off, d_var_off, stream);
+}
+
+pg_status pg_scalar_mix_planned_batch(pg_engine *e, const pg_scalar *d_v, const pg_scalar *d_y, const pg_scalar *d_s,
+                                      const pg_scalar *d_a, const pg_scalar *d_b, uint64_t batch, uint64_t *d_row_off,
+                                      uint64_t *d_var_off, uint8_t *d_err_mask, uint64_t gate_base, uint64_t var_base,
+                                      pg_variable zero_var, const pg_columns *out, pg_variable *d_result_vars, void *stream) {
+    if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
+    if (batch == 0) return pg_scalar_mix_plan_async(e, d_v, 0, d_row_off, d_var_off, d_err_mask, stream);
+    const pg_scalar *in[5] = {d_v, d_y, d_s, d_a, d_b};
+    for (const pg_scalar *p : in) PG_TRY(check_scalars(p, "input array"));
+    PG_TRY(check_u64s(d_row_off, "d_row_off"));
+    PG_TRY(check_u64s(d_var_off, "d_var_off"));
+    PG_TRY(check_u64s(d_result_vars, "d_result_vars", true));
+    PG_TRY(check_columns(out));
+    PG_TRY(ensure_scratch(e, batch));
+    pg::ScalarMixArgs A{};
+    A.v = reinterpret_cast<const uint4 *>(d_v);
+    A.y = reinterpret_cast<const uint4 *>(d_y);
+    A.s = reinterpret_cast<const uint4 *>(d_s);
+    A.a = reinterpret_cast<const uint4 *>(d_a);
+    A.b = reinterpret_cast<const uint4 *>(d_b);
+    A.result_vars = d_result_vars;
+    const PlanLaunch plan = [=](hipStream_t st) {
+        return error_plan_launch(e, pg::scalar_mix_plan_kernel, d_v, batch, d_row_off, d_var_off, d_err_mask, st);
+    };
+    return launch<pg::ScalarMixGD>(e, A, out, batch, gate_base, var_base, zero_var, d_row_off, d_var_off, stream, &plan);
 }
 
 pg_status pg_fill_bytes(pg_engine *e, void *d_dst, uint64_t bytes, uint32_t streams, uint64_t pattern, void *stream) {

@@ -423,6 +423,19 @@ class Engine:
         if st != 0:
             raise PgError(st, "pg_scalar_mix_batch")
 
+    def scalar_mix_planned(self, v, y, s, a, b, row_off, var_off, out: Columns, result_vars=None, err_mask=None,
+                           gate_base: int = 0, var_base: int = 0, zero_var: int = 0):
+        """plan + emit in one call (pg_scalar_mix_planned_batch): `out` must hold the worst case, 10 rows and 15 variables
+        per item; the totals are read with plan_result() after a synchronisation"""
+        cols = out.as_c()
+        st = self._lib.pg_scalar_mix_planned_batch(self._h, v.data_ptr(), y.data_ptr(), s.data_ptr(), a.data_ptr(), b.data_ptr(),
+                                                   v.shape[0], row_off.data_ptr(), var_off.data_ptr(),
+                                                   err_mask.data_ptr() if err_mask is not None else None, gate_base, var_base,
+                                                   zero_var, C.byref(cols),
+                                                   result_vars.data_ptr() if result_vars is not None else None, self._stream())
+        if st != 0:
+            raise PgError(st, "pg_scalar_mix_planned_batch")
+
     # ---- asynchronous plans (no host round trip between plan and emit; totals read back later) -----------------
     def max_bound_ragged_plan_async(self, max_range: torch.Tensor, num_bits, row_off, var_off):
         st = self._lib.pg_max_bound_ragged_plan_async(self._h, max_range.data_ptr(), max_range.shape[0], num_bits.data_ptr(),

@@ -485,6 +485,36 @@ def test_fuzz_very_ragged_max_bound(engine):
         assert engine.check_rows(cols) == -1
 
 
+@pytest.mark.parametrize("batch,zeros", [(1, (0,)), (700, (3, 77, 699)), (6000, (0, 64, 255, 256, 4096, 5999))])
+def test_planned_mix_call_matches_plan_then_emit(engine, batch, zeros):
+    """pg_scalar_mix_planned_batch (the plan launched by the call itself, beside the pre-pass for big batches) == the
+    synchronous plan followed by the emit call: offsets, totals, error mask, result Variables, every column"""
+    import plonk_gadgets_amd as pg
+    v, y, s, a, b = mix_inputs(batch, 13, zeros)
+    ins = [dev(x) for x in (v, y, s, a, b)]
+    _, roff, voff = engine.ragged_buffers(batch)
+    err = torch.zeros((batch,), dtype=torch.uint8, device="cuda:0")
+    lay, nerr = engine.scalar_mix_plan(ins[0], roff, voff, err)
+    ref = pg.Columns.allocate(lay.n_gates, lay.n_vars, "cuda:0")
+    ref_res = torch.zeros((batch, 2), dtype=torch.int64, device="cuda:0")
+    engine.scalar_mix_emit(*ins, roff, voff, ref, ref_res, 3, 5, 0)
+    torch.cuda.synchronize()
+    _, roff2, voff2 = engine.ragged_buffers(batch)
+    roff2.fill_(-1); voff2.fill_(-1)
+    err2 = torch.full((batch,), 7, dtype=torch.uint8, device="cuda:0")
+    big = pg.Columns.allocate(10 * batch, 15 * batch, "cuda:0")  # worst case
+    res = torch.zeros((batch, 2), dtype=torch.int64, device="cuda:0")
+    for _ in range(2):  # twice: the second call finds the first one's state on the engine's streams
+        engine.scalar_mix_planned(*ins, roff2, voff2, big, res, err2, 3, 5, 0)
+    torch.cuda.synchronize()
+    lay2, nerr2 = engine.plan_result()
+    assert (lay2.n_gates, lay2.n_vars, nerr2) == (lay.n_gates, lay.n_vars, nerr) == (10 * batch - 2 * len(zeros), 15 * batch - 2 * len(zeros), len(zeros))
+    assert torch.equal(roff2, roff) and torch.equal(voff2, voff) and torch.equal(err2, err) and torch.equal(res, ref_res)
+    for k in COLS:
+        n = lay.n_vars if k == "var_values" else lay.n_gates
+        assert torch.equal(getattr(big, k)[:n], getattr(ref, k)), k
+
+
 def test_async_plans_match_sync_plans(engine):
     """plan_async + emit + (later) plan_result == the synchronous plan: same offsets, same totals, same columns"""
     import sys, os
