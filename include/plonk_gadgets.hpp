@@ -100,6 +100,19 @@ class StandardComposer {
     void reserve(uint64_t gate_capacity, uint64_t var_capacity) { pg_throw(pg_composer_reserve(h, gate_capacity, var_capacity), "reserve"); }
     void auto_grow(bool on = true) { pg_throw(pg_composer_auto_grow(h, on ? 1 : 0), "auto_grow"); }
 
+    // the command queue behind the single calls (plonk_gadgets_hip.h): calls are validated and numbered at once and
+    // recorded; anything that needs the device state flushes them, in order, as few launches.  queue(false) = one launch
+    // per call; flush() sends what is pending; sync() flushes and waits for the composer's stream.
+    void queue(bool on = true) { pg_throw(pg_composer_queue(h, on ? 1 : 0), "queue"); }
+    void flush() { pg_throw(pg_composer_flush(h), "flush"); }
+    void sync() { pg_throw(pg_composer_sync(h), "sync"); }
+    struct QueueStats { uint64_t pending, flushes, launches; };
+    QueueStats queue_stats() const {
+        QueueStats q{};
+        pg_throw(pg_composer_queue_stats(h, &q.pending, &q.flushes, &q.launches), "queue_stats");
+        return q;
+    }
+
     uint64_t circuit_size() const { return pg_composer_circuit_size(h); }
     uint64_t num_variables() const { return pg_composer_num_variables(h); }
     Variable zero_var() const { return Variable{pg_composer_zero_var(h)}; }

@@ -437,12 +437,37 @@ static void scalar_invert() {
     CHECK(!BlsScalar::zero().invert(&inv) && inv == BlsScalar::zero());
 }
 
+// the reference's loop, one call at a time (tests/range_gadgets_tests.rs:29-44): recorded and flushed as few launches, the
+// same columns as with recording off and as the oracle's loop
+static void single_calls_are_queued(Engine &e) {
+    const BlsScalar mn = BlsScalar::from(1000), mx = BlsScalar::from(90000);
+    composer_t *ora = composer_new();
+    StandardComposer queued(e, 1 << 17, 1 << 18), direct(e, 1 << 17, 1 << 18);
+    direct.queue(false);
+    const auto q0 = queued.queue_stats();
+    for (uint64_t i = 0; i < 100; i++) {
+        const BlsScalar w = BlsScalar::from(500 + 997 * i);
+        const var_t ov = ::range_check(ora, to_fr(mn), to_fr(mx), allocated_scalar_allocate(ora, to_fr(w)));
+        const Variable a = range_check(queued, mn, mx, AllocatedScalar::allocate(queued, w));
+        const Variable b = range_check(direct, mn, mx, AllocatedScalar::allocate(direct, w));
+        CHECK(a.index == ov && b.index == ov);
+    }
+    CHECK(queued.queue_stats().pending >= 200);  // nothing has reached the device yet
+    queued.flush();
+    const auto q1 = queued.queue_stats();
+    CHECK(q1.pending == 0 && q1.flushes == q0.flushes + 1 && q1.launches <= q0.launches + 2);
+    CHECK(equals_oracle(queued, ora) && equals_oracle(direct, ora));
+    CHECK(queued.check() == -1 && direct.check() == -1);
+    composer_free(ora);
+}
+
 int main() {
     Engine e(0);
     struct { const char *name; std::function<void()> fn; } tests[] = {
         {"counting_scalar_bits", [&] { counting_scalar_bits(); }},
         {"scalar_invert", [&] { scalar_invert(); }},
         {"batched_appends_equal_loops", [&] { batched_appends_equal_loops(e); }},
+        {"single_calls_are_queued", [&] { single_calls_are_queued(e); }},
         {"scalar_decomposition_test", [&] { scalar_decomposition_test(e); }},
         {"max_bound_test", [&] { max_bound_test(e); }},
         {"range_check_test", [&] { range_check_test(e); }},

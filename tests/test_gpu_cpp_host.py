@@ -28,5 +28,6 @@ def test_cpp_reference_suite_on_gpu():
     print(p.stdout[-4000:], p.stderr[-2000:])
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     for name in ("counting_scalar_bits", "scalar_decomposition_test", "max_bound_test", "range_check_test", "test_maybe_equal",
-                 "test_conditionally_select_0", "test_conditionally_select_1", "test_is_not_zero"):
+                 "test_conditionally_select_0", "test_conditionally_select_1", "test_is_not_zero", "single_calls_are_queued",
+                 "batched_appends_equal_loops"):
         assert f"test {name} ... ok" in p.stdout
