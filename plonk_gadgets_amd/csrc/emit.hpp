@@ -506,7 +506,12 @@ struct VarsImage<GD, std::void_t<decltype(GD::kImageW)>> {
 };
 
 template <class GD>
-__global__ __launch_bounds__(GD::kImageW * GD::kImageParts) void vars_image_kernel(const typename GD::Args A, const EmitOut O) {
+// 5 waves per SIMD = as many workgroups per CU as the 30 KB images allow: the compiler is held to 96 registers (it takes
+// 122 when left alone, which is 4 workgroups per CU): -2.4 % / -4.5 % on the fused mix's step on two boxes; 6 and 8: +15 %
+#ifndef PG_IMAGE_WAVES_PER_SIMD
+#define PG_IMAGE_WAVES_PER_SIMD 5
+#endif
+__global__ __launch_bounds__(GD::kImageW * GD::kImageParts, PG_IMAGE_WAVES_PER_SIMD) void vars_image_kernel(const typename GD::Args A, const EmitOut O) {
     constexpr int W = GD::kImageW;
     constexpr uint32_t kLanes = W * GD::kImageParts;
     __shared__ uint4 s_img[W * GD::kUniformVars * 2];

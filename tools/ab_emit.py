@@ -33,6 +33,7 @@ VARIANTS = {
     "beside_rows6": ["-DPG_ROWS_WGS_PER_CU=6"],
     "beside_l512": ["-DPG_INV_LANES_PER_CU=512"],
     "beside_grp8": ["-DPG_INV_GRP=8"],
+    "image_waves1": ["-DPG_IMAGE_WAVES_PER_SIMD=1"],  # variable-image kernel: registers left to the compiler (122: 4 workgroups per CU)
     "abl_item": ["-DPG_ABLATE_ITEM_PHASE"],
     "abl_item_b5": ["-DPG_ABLATE_ITEM_PHASE", "-DPG_VARS_BLOCKS_PER_CU=5"],
     "abl_item_b10": ["-DPG_ABLATE_ITEM_PHASE", "-DPG_VARS_BLOCKS_PER_CU=10"],
