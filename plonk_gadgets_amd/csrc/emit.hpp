@@ -506,10 +506,10 @@ struct VarsImage<GD, std::void_t<decltype(GD::kImageW)>> {
 };
 
 template <class GD>
-// 5 waves per SIMD = as many workgroups per CU as the 30 KB images allow: the compiler is held to 96 registers (it takes
-// 122 when left alone, which is 4 workgroups per CU): -2.4 % / -4.5 % on the fused mix's step on two boxes; 6 and 8: +15 %
+// (asked for 5 waves per SIMD -- as many workgroups per CU as the 30 KB images allow -- the compiler takes 80 registers
+// instead of 122: no difference on the step, 0.590 vs 0.581 ms with the A/B order rotated)
 #ifndef PG_IMAGE_WAVES_PER_SIMD
-#define PG_IMAGE_WAVES_PER_SIMD 5
+#define PG_IMAGE_WAVES_PER_SIMD 1
 #endif
 __global__ __launch_bounds__(GD::kImageW * GD::kImageParts, PG_IMAGE_WAVES_PER_SIMD) void vars_image_kernel(const typename GD::Args A, const EmitOut O) {
     constexpr int W = GD::kImageW;

@@ -25,7 +25,7 @@ VARIANTS = {
     "full_barriers": ["-DPG_FULL_BARRIERS"],
     "img_w64": ["-DPG_IMAGE_W=64"],
     "split_sequential": ["-DPG_SPLIT_SEQUENTIAL"],  # split gadget: pre-pass, rows, variables one after the other
-    "rows_stream_normal": ["-DPG_ROWS_STREAM_NORMAL"],  # split gadget: the rows stream at normal instead of lowest priority
+    "rows_stream_low": ["-DPG_ROWS_STREAM_LOW"],  # split gadget: the rows stream at the lowest instead of normal priority
     "vars_after_rows": ["-DPG_VARS_AFTER_ROWS"],  # split gadget: the variable table waits for the rows launch as well
     "vars_after_rows5": ["-DPG_VARS_AFTER_ROWS", "-DPG_ROWS_WGS_PER_CU=5"],
     "beside_rows4": ["-DPG_ROWS_WGS_PER_CU=4"],
@@ -33,7 +33,7 @@ VARIANTS = {
     "beside_rows6": ["-DPG_ROWS_WGS_PER_CU=6"],
     "beside_l512": ["-DPG_INV_LANES_PER_CU=512"],
     "beside_grp8": ["-DPG_INV_GRP=8"],
-    "image_waves1": ["-DPG_IMAGE_WAVES_PER_SIMD=1"],  # variable-image kernel: registers left to the compiler (122: 4 workgroups per CU)
+    "image_waves5": ["-DPG_IMAGE_WAVES_PER_SIMD=5"],  # variable-image kernel held to 80 registers (5 workgroups per CU, what its LDS allows)
     "abl_item": ["-DPG_ABLATE_ITEM_PHASE"],
     "abl_item_b5": ["-DPG_ABLATE_ITEM_PHASE", "-DPG_VARS_BLOCKS_PER_CU=5"],
     "abl_item_b10": ["-DPG_ABLATE_ITEM_PHASE", "-DPG_VARS_BLOCKS_PER_CU=10"],
@@ -128,7 +128,9 @@ def run_c3(log2_chunk=20, rounds=4):
     nbytes = chunk * 2320
     times = {n: [] for n in libs}
     for r in range(rounds + 1):
-        for name, (lib, h) in libs.items():
+        order = list(libs.items())
+        order = order[r % len(order):] + order[:r % len(order)]  # rotate: whoever runs first in a round pays for it (~3 %)
+        for name, (lib, h) in order:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
             st = lib.pg_scalar_mix_batch(h, *[t.data_ptr() for t in ins], chunk, roff.data_ptr(), voff.data_ptr(), 3, 5, 0,
@@ -185,7 +187,9 @@ def run_c4(log2_chunk=19, rounds=4):
     cc = cols.as_c()
     times = {n: [] for n in libs}
     for r in range(rounds + 1):
-        for name, (lib, h) in libs.items():
+        order = list(libs.items())
+        order = order[r % len(order):] + order[:r % len(order)]  # rotate: whoever runs first in a round pays for it (~3 %)
+        for name, (lib, h) in order:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
             st = lib.pg_max_bound_ragged_batch(h, mr.data_ptr(), wt.data_ptr(), chunk, nb.data_ptr(), roff.data_ptr(),
@@ -233,7 +237,9 @@ def run(log2_chunk=18, rounds=4, mn_int=0, mx_int=2**254):
     times = {n: [] for n in libs}
     nbytes = chunk * (G * 184 + V * 32)
     for r in range(rounds + 1):
-        for name, (lib, h) in libs.items():
+        order = list(libs.items())
+        order = order[r % len(order):] + order[:r % len(order)]  # rotate: whoever runs first in a round pays for it (~3 %)
+        for name, (lib, h) in order:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
             st = lib.pg_range_check_batch(h, C.byref(mn.c), C.byref(mx.c), wit.data_ptr(), chunk, 3, 5, C.byref(cc),
