@@ -101,8 +101,9 @@ struct pg_engine {
     // scratch of the ragged plans (grow-only): per-item counts, block sums, error counter
     uint32_t *d_rows = nullptr, *d_vars = nullptr;
     uint64_t *d_blk_rows = nullptr, *d_blk_vars = nullptr;
+    unsigned long long *d_blk_agg = nullptr;  // single-launch plans (emit.hpp, PlanScan): published block totals; [blocks] = blocks done
     uint32_t *d_err_count = nullptr;
-    uint64_t scratch_items = 0;
+    uint64_t scratch_items = 0, scratch_blocks = 0;
     // totals of the last plan, written by async copies into pinned host memory (read after a synchronisation)
     using PlanResult = pg::PlanTotals;
     PlanResult *h_plan = nullptr;
@@ -131,6 +132,7 @@ pg_status ensure_scratch(pg_engine *e, uint64_t batch) {
     if (e->d_vars) { (void)hipFree(e->d_vars); e->d_vars = nullptr; }
     if (e->d_blk_rows) { (void)hipFree(e->d_blk_rows); e->d_blk_rows = nullptr; }
     if (e->d_blk_vars) { (void)hipFree(e->d_blk_vars); e->d_blk_vars = nullptr; }
+    if (e->d_blk_agg) { (void)hipFree(e->d_blk_agg); e->d_blk_agg = nullptr; }
     e->scratch_items = 0;
     const uint64_t items = batch < 1024 ? 1024 : batch;
     const uint64_t nblk = (items + pg::kScanBlock - 1) / pg::kScanBlock;
@@ -138,6 +140,9 @@ pg_status ensure_scratch(pg_engine *e, uint64_t batch) {
     PG_HIP_TRY(hipMalloc(&e->d_vars, items * sizeof(uint32_t)));
     PG_HIP_TRY(hipMalloc(&e->d_blk_rows, nblk * sizeof(uint64_t)));
     PG_HIP_TRY(hipMalloc(&e->d_blk_vars, nblk * sizeof(uint64_t)));
+    PG_HIP_TRY(hipMalloc(&e->d_blk_agg, (nblk + 1) * sizeof(unsigned long long)));
+    PG_HIP_TRY(hipMemset(e->d_blk_agg, 0, (nblk + 1) * sizeof(unsigned long long)));  // zero between launches: the plan kernels leave them so
+    e->scratch_blocks = nblk;
     if (!e->d_err_count) {
         PG_HIP_TRY(hipMalloc(&e->d_err_count, sizeof(uint32_t)));
         PG_HIP_TRY(hipMemset(e->d_err_count, 0, sizeof(uint32_t)));  // zero between calls (see error_plan)
@@ -146,21 +151,53 @@ pg_status ensure_scratch(pg_engine *e, uint64_t batch) {
     return PG_OK;
 }
 
+// what a plan kernel is handed to finish the prefix sums itself (up to kPlanFusedBlocks blocks; beyond, fused = 0 and
+// scan_counts launches the two-level scan)
+pg::PlanScan plan_scan(pg_engine *e, uint64_t batch, uint64_t *d_row_off, uint64_t *d_var_off, bool with_errs) {
+    const uint64_t nblk = (batch + pg::kScanBlock - 1) / pg::kScanBlock;
+    pg::PlanScan P{};
+    P.agg = e->d_blk_agg;
+    P.blocks_cap = (uint32_t)e->scratch_blocks;
+    P.blk_rows = e->d_blk_rows;
+    P.blk_vars = e->d_blk_vars;
+    P.row_off = d_row_off;
+    P.var_off = d_var_off;
+    P.host = e->h_plan;
+    P.err_count = with_errs ? e->d_err_count : nullptr;
+#if defined(PG_PLAN_TWO_LAUNCHES)  // A/B build
+    P.fused = 0;
+#else
+    P.fused = nblk <= pg::kPlanFusedBlocks ? 1u : 0u;
+#endif
+    return P;
+}
+
+pg_status plan_totals(pg_engine *e, uint64_t *n_rows, uint64_t *n_vars) {
+    if (e->h_plan->pad) {
+        e->h_plan->pad = 0;
+        return fail(PG_ERR_HIP, "a plan's look-back gave up waiting for another block's totals");
+    }
+    *n_rows = e->h_plan->n_gates;
+    *n_vars = e->h_plan->n_vars;
+    return PG_OK;
+}
+
 // counts in e->d_rows / e->d_vars and their block sums in e->d_blk_* (both left by the plan kernel) -> exclusive prefix
-// sums; totals copied back (the synchronous form synchronises the stream)
+// sums; totals copied back (the synchronous form synchronises the stream).  Nothing to launch after a fused plan.
 pg_status scan_counts(pg_engine *e, uint64_t batch, uint64_t *d_row_off, uint64_t *d_var_off, uint64_t *n_rows,
                       uint64_t *n_vars, hipStream_t st, bool with_errs) {
     const uint32_t nblk = (uint32_t)((batch + pg::kScanBlock - 1) / pg::kScanBlock);
-    const uint32_t prefixed = nblk > pg::kScanDirectBlocks ? 1u : 0u;
-    if (prefixed)
-        hipLaunchKernelGGL(pg::scan_top_kernel, dim3(1), dim3(pg::kThreads), 0, st, e->d_blk_rows, e->d_blk_vars, nblk);
-    hipLaunchKernelGGL(pg::scan_final_kernel, dim3(nblk), dim3(pg::kThreads), 0, st, e->d_rows, e->d_vars, batch,
-                       e->d_blk_rows, e->d_blk_vars, d_row_off, d_var_off, prefixed, e->h_plan, with_errs ? e->d_err_count : nullptr);
-    PG_HIP_TRY(hipGetLastError());
+    if (!plan_scan(e, batch, d_row_off, d_var_off, with_errs).fused) {
+        const uint32_t prefixed = nblk > pg::kScanDirectBlocks ? 1u : 0u;
+        if (prefixed)
+            hipLaunchKernelGGL(pg::scan_top_kernel, dim3(1), dim3(pg::kThreads), 0, st, e->d_blk_rows, e->d_blk_vars, nblk);
+        hipLaunchKernelGGL(pg::scan_final_kernel, dim3(nblk), dim3(pg::kThreads), 0, st, e->d_rows, e->d_vars, batch,
+                           e->d_blk_rows, e->d_blk_vars, d_row_off, d_var_off, prefixed, e->h_plan, with_errs ? e->d_err_count : nullptr);
+        PG_HIP_TRY(hipGetLastError());
+    }
     if (n_rows) {  // synchronous form
         PG_HIP_TRY(hipStreamSynchronize(st));
-        *n_rows = e->h_plan->n_gates;
-        *n_vars = e->h_plan->n_vars;
+        PG_TRY(plan_totals(e, n_rows, n_vars));
     }
     return PG_OK;
 }
@@ -383,7 +420,7 @@ pg_status error_plan_launch(pg_engine *e, PlanKernel kernel, const pg_scalar *d_
                             uint64_t *d_var_off, uint8_t *d_err_mask, hipStream_t st) {
     const uint32_t grid = (uint32_t)((batch + pg::kScanBlock - 1) / pg::kScanBlock);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(pg::kThreads), 0, st, reinterpret_cast<const uint4 *>(d_value), batch,
-                       e->d_rows, e->d_vars, d_err_mask, e->d_err_count, e->d_blk_rows, e->d_blk_vars);
+                       e->d_rows, e->d_vars, d_err_mask, e->d_err_count, plan_scan(e, batch, d_row_off, d_var_off, true));
     PG_HIP_TRY(hipGetLastError());
     return scan_counts(e, batch, d_row_off, d_var_off, nullptr, nullptr, st, true);
 }
@@ -410,7 +447,7 @@ pg_status error_plan(pg_engine *e, PlanKernel kernel, const pg_scalar *d_value, 
     // e->d_err_count is zero between calls: whoever reads it (scan_final_kernel, the bulk decoder) leaves it so
     const uint32_t grid = (uint32_t)((batch + pg::kScanBlock - 1) / pg::kScanBlock);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(pg::kThreads), 0, st, reinterpret_cast<const uint4 *>(d_value), batch,
-                       e->d_rows, e->d_vars, d_err_mask, e->d_err_count, e->d_blk_rows, e->d_blk_vars);
+                       e->d_rows, e->d_vars, d_err_mask, e->d_err_count, plan_scan(e, batch, d_row_off, d_var_off, true));
     PG_HIP_TRY(hipGetLastError());
     PG_TRY(scan_counts(e, batch, d_row_off, d_var_off, &out->n_gates, &out->n_vars, st, true));
     const uint32_t errs = e->h_plan->errs;
@@ -506,6 +543,7 @@ void pg_engine_destroy(pg_engine *e) {
     if (e->d_blk_rows) (void)hipFree(e->d_blk_rows);
     if (e->d_blk_vars) (void)hipFree(e->d_blk_vars);
     if (e->d_err_count) (void)hipFree(e->d_err_count);
+    if (e->d_blk_agg) (void)hipFree(e->d_blk_agg);
     if (e->d_prefix) (void)hipFree(e->d_prefix);
     if (e->d_inv) (void)hipFree(e->d_inv);
     if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
@@ -766,7 +804,7 @@ static pg_status max_bound_ragged_plan_common(pg_engine *e, const pg_scalar *d_m
     const uint32_t grid = (uint32_t)((batch + pg::kScanBlock - 1) / pg::kScanBlock);
     hipLaunchKernelGGL(pg::max_bound_plan_kernel, dim3(grid), dim3(pg::kThreads), 0, st,
                        reinterpret_cast<const uint4 *>(d_max_range), batch, e->d_pow2, d_num_bits, e->d_rows, e->d_vars,
-                       e->d_blk_rows, e->d_blk_vars);
+                       plan_scan(e, batch, d_row_off, d_var_off, false));
     PG_HIP_TRY(hipGetLastError());
     // a max_bound plan has no failing items: the scan writes errs = 0 with the totals, in stream order
     if (!out) return scan_counts(e, batch, d_row_off, d_var_off, nullptr, nullptr, st, false);
@@ -788,8 +826,7 @@ pg_status pg_max_bound_ragged_plan_async(pg_engine *e, const pg_scalar *d_max_ra
 pg_status pg_plan_result(pg_engine *e, pg_layout *out, uint64_t *err_count) {
     if (!e || !out) return fail(PG_ERR_INVALID_ARGUMENT, "NULL argument");
     std::memset(out, 0, sizeof *out);
-    out->n_gates = e->h_plan->n_gates;
-    out->n_vars = e->h_plan->n_vars;
+    PG_TRY(plan_totals(e, &out->n_gates, &out->n_vars));
     if (err_count) *err_count = e->h_plan->errs;
     return e->h_plan->errs ? fail(PG_ERR_NON_EXISTING_INVERSE, std::to_string(e->h_plan->errs) + " item(s) have no inverse")
                            : PG_OK;

@@ -637,6 +637,127 @@ __global__ __launch_bounds__(kThreads) void scan_top_kernel(uint64_t *blk_rows, 
     }
 }
 
+// The totals of the plan -- rows, variables, and the plan kernel's count of failing items (err_count, or NULL for a plan
+// that has none) -- go straight to the engine's pinned result record `host` (a device-visible host address: three
+// 4..8-byte copies cost three copy launches, ~15 us of a 0.65 ms step); err_count is left at zero for the next plan.
+struct PlanTotals {
+    uint64_t n_gates, n_vars;
+    uint32_t errs, pad;
+};
+
+
+// ---- the plan in ONE launch (batches up to kPlanFusedBlocks blocks) -------------------------------------------------
+// A plan kernel that has its threads' four counts in registers finishes the prefix sums itself: every block publishes its
+// totals, adds up the totals of the blocks before it back to the nearest one that has already published its inclusive
+// prefix (decoupled look-back: a block waits only for blocks of lower index, which were dispatched before it and publish
+// before they wait, so the lowest unpublished block can always run), publishes its own inclusive prefix and writes its
+// items' offsets; the block of the last item writes the totals.  The block that finishes last writes the error count to
+// the host record and puts the published words, the counter and the error count back to zero: nothing to clear between launches, so a launch can be replayed from a HIP
+// graph.  Saves the second launch, its dependency and the per-item counts (8 B per item written and read back).
+//
+// NO FENCES.  On this part a release / acquire at agent scope writes back / invalidates the whole L2 of the XCD (the L2s
+// of the eight XCDs are not coherent with each other for ordinary memory): with one per block the first version of this
+// kernel took 470 us beside the rows' store stream.  So a block's totals and its "published" bit travel in ONE 64-bit
+// word that is only ever touched by relaxed read-modify-write atomics (which execute at the coherence point): nothing
+// has to be ordered against anything else.  Every wait is bounded (kPlanSpinLimit polls); a plan that gives up says so in
+// PlanTotals::pad.
+struct PlanScan {
+    unsigned long long *agg;      // per block: flags | rows << 31 | variables (zero between launches); [blocks_cap] = blocks done
+    uint64_t *blk_rows, *blk_vars;  // block sums for the two-launch scan (fused == 0)
+    uint64_t *row_off, *var_off;  // the call's outputs (batch + 1 entries each)
+    PlanTotals *host;
+    uint32_t *err_count;          // the plan kernel's count of failing items, or NULL
+    uint32_t blocks_cap;          // index of the done counter in agg
+    uint32_t fused;               // 0: leave the counts and block sums to scan_final_kernel (more blocks than kPlanFusedBlocks)
+};
+// a published word: kAggA = the block's own totals, kAggP = its INCLUSIVE prefix (a look-back stops there); 31 bits each
+// for rows and variables, which bounds the fused path: 2048 blocks x 1024 items x 517 < 2^31
+constexpr unsigned long long kAggA = 1ull << 63, kAggP = 1ull << 62;
+constexpr uint32_t kPlanFusedBlocks = 2048;
+constexpr uint32_t kPlanSpinLimit = 1u << 22;
+
+__device__ __forceinline__ unsigned long long plan_rmw_read(unsigned long long *p) {
+    return __hip_atomic_fetch_add(p, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void plan_publish(unsigned long long *p, unsigned long long flag, uint64_t rows, uint64_t vars) {
+    __hip_atomic_exchange(p, flag | rows << 31 | vars, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t wave_sum(uint64_t x) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d, 64);
+    return x;
+}
+
+__device__ __forceinline__ void plan_finish(const PlanScan &P, const uint32_t r[4], const uint32_t v[4], uint64_t batch) {
+    __shared__ uint64_t s_w[4], s_pref[2];
+    __shared__ uint32_t s_last;
+    const uint32_t tid = threadIdx.x, b = blockIdx.x, nblk = gridDim.x;
+    uint64_t tr, tv;
+    const uint64_t er = block_exclusive_scan((uint64_t)r[0] + r[1] + r[2] + r[3], s_w, tr);
+    const uint64_t ev = block_exclusive_scan((uint64_t)v[0] + v[1] + v[2] + v[3], s_w, tv);
+    if (tid == 0 && b > 0) plan_publish(&P.agg[b], kAggA, tr, tv);
+    if (tid < 64) {  // wave 0 looks back, 64 predecessors at a time, nearest first, until one of them holds a prefix
+        uint64_t pr = 0, pv = 0;
+        bool gave_up = false;
+        int64_t base = (int64_t)b - 1;
+        for (bool more = b > 0; more; base -= 64) {
+            const int64_t j = base - (int64_t)tid;
+            unsigned long long x = kAggP;  // before block 0: the empty prefix
+            if (j >= 0) {
+                x = plan_rmw_read(&P.agg[j]);
+                for (uint32_t polls = 0; !(x >> 62); x = plan_rmw_read(&P.agg[j])) {
+                    if (++polls > kPlanSpinLimit) { gave_up = true; x = kAggP; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            const uint64_t has_prefix = __ballot((x & kAggP) != 0);
+            const uint32_t first = has_prefix ? (uint32_t)__ffsll((unsigned long long)has_prefix) - 1 : 64u;  // the nearest one
+            const bool take = tid <= first;
+            pr += wave_sum(take ? (x >> 31) & 0x7fffffffull : 0);
+            pv += wave_sum(take ? x & 0x7fffffffull : 0);
+            more = has_prefix == 0;
+        }
+        if (__ballot(gave_up) && tid == 0) P.host->pad = 1;
+        if (tid == 0) {
+            s_pref[0] = pr;
+            s_pref[1] = pv;
+            plan_publish(&P.agg[b], kAggP, pr + tr, pv + tv);
+        }
+    }
+    __syncthreads();
+    uint64_t ro = s_pref[0] + er, vo = s_pref[1] + ev;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint64_t i = (uint64_t)b * kScanBlock + tid * 4 + k;
+        if (i < batch) { P.row_off[i] = ro; P.var_off[i] = vo; }
+        ro += r[k];
+        vo += v[k];
+        if (i + 1 == batch) {  // the last item: the totals
+            P.row_off[batch] = ro;
+            P.var_off[batch] = vo;
+            P.host->n_gates = ro;
+            P.host->n_vars = vo;
+        }
+    }
+    // the last block to get here has every block's error count behind it: a block's own atomics have been performed
+    // (workgroup-scope fence = the waves wait for their outstanding memory operations) before it counts itself
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0)
+        s_last = __hip_atomic_fetch_add(&P.agg[P.blocks_cap], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    for (uint32_t j = tid; j < nblk; j += kThreads) __hip_atomic_exchange(&P.agg[j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+        P.host->errs = P.err_count ? __hip_atomic_exchange(P.err_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        __hip_atomic_exchange(&P.agg[P.blocks_cap], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// what every plan kernel ends with: its threads' four row / variable counts -> offsets (fused) or counts + block sums
+__device__ __forceinline__ void plan_store(const PlanScan &P, const uint32_t r[4], const uint32_t v[4], uint64_t batch, uint32_t *rows,
+                                           uint32_t *vars);
+
 // block sums straight from a plan kernel: thread t of plan block b owns items b * kScanBlock + 4 t .. + 3 (the
 // indexing of scan_final_kernel) and hands in the sums of its four counts -- the separate block-sums launch is gone
 __device__ __forceinline__ void plan_block_sums(uint64_t r, uint64_t v, uint64_t *blk_rows, uint64_t *blk_vars) {
@@ -647,18 +768,24 @@ __device__ __forceinline__ void plan_block_sums(uint64_t r, uint64_t v, uint64_t
     if (threadIdx.x == 0) { blk_rows[blockIdx.x] = tr; blk_vars[blockIdx.x] = tv; }
 }
 
+__device__ __forceinline__ void plan_store(const PlanScan &P, const uint32_t r[4], const uint32_t v[4], uint64_t batch, uint32_t *rows,
+                                           uint32_t *vars) {
+    if (P.fused) {
+        plan_finish(P, r, v, batch);
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x * 4 + k;
+        if (i < batch) { rows[i] = r[k]; vars[i] = v[k]; }
+    }
+    plan_block_sums((uint64_t)r[0] + r[1] + r[2] + r[3], (uint64_t)v[0] + v[1] + v[2] + v[3], P.blk_rows, P.blk_vars);
+}
+
 // blk_prefixed = 0: blk_* hold the block SUMS and every block adds up the ones before it itself (no scan_top launch;
 // the host takes this route up to kScanDirectBlocks blocks = 4 M items); 1: scan_top_kernel has turned them into
 // exclusive prefix sums
 constexpr uint32_t kScanDirectBlocks = 4096;
-
-// The totals of the plan -- rows, variables, and the plan kernel's count of failing items (err_count, or NULL for a plan
-// that has none) -- go straight to the engine's pinned result record `host` (a device-visible host address: three
-// 4..8-byte copies cost three copy launches, ~15 us of a 0.65 ms step); err_count is left at zero for the next plan.
-struct PlanTotals {
-    uint64_t n_gates, n_vars;
-    uint32_t errs, pad;
-};
 
 __global__ __launch_bounds__(kThreads) void scan_final_kernel(const uint32_t *rows, const uint32_t *vars, uint64_t n,
                                                              const uint64_t *blk_rows, const uint64_t *blk_vars,

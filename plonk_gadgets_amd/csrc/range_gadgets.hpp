@@ -449,9 +449,8 @@ struct DecompositionGD {
 
 // plan of a ragged max_bound batch: ladder bits and row/variable counts per item (range.rs:87-90)
 __global__ __launch_bounds__(kThreads) void max_bound_plan_kernel(const uint4 *max_range, uint64_t batch, const uint4 *pow2,
-                                                                 uint32_t *num_bits, uint32_t *rows, uint32_t *vars,
-                                                                 uint64_t *blk_rows, uint64_t *blk_vars) {
-    uint64_t sr = 0, sv = 0;
+                                                                 uint32_t *num_bits, uint32_t *rows, uint32_t *vars, const PlanScan P) {
+    uint32_t r[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x * 4 + k;
@@ -468,13 +467,11 @@ __global__ __launch_bounds__(kThreads) void max_bound_plan_kernel(const uint4 *m
             uint32_t n = raw_bit_length(fr_from_mont(p.f));
             if (n < 1) n = 1;
             num_bits[i] = n;
-            rows[i] = 2 * n + 5;
-            vars[i] = n + 262;
-            sr += 2 * n + 5;
-            sv += n + 262;
+            r[k] = 2 * n + 5;
+            v[k] = n + 262;
         }
     }
-    plan_block_sums(sr, sv, blk_rows, blk_vars);  // the block sums of the prefix-sum pass, same launch
+    plan_store(P, r, v, batch, rows, vars);  // the prefix sums, same launch
 }
 
 // engine table: mont(2^i) by repeated doubling (one thread; runs once per engine)

@@ -235,22 +235,19 @@ struct IsNonZeroGD {
 // plan kernels: per-item counts + the block sums of the prefix-sum pass in one launch (grid = blocks of kScanBlock items)
 __global__ __launch_bounds__(kThreads) void is_non_zero_plan_kernel(const uint4 *value, uint64_t batch, uint32_t *rows,
                                                                    uint32_t *vars, uint8_t *err_mask, uint32_t *err_count,
-                                                                   uint64_t *blk_rows, uint64_t *blk_vars) {
-    uint64_t sr = 0, sv = 0;
+                                                                   const PlanScan P) {
+    uint32_t r[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x * 4 + k;
         if (i < batch) {
             const bool err = fr_is_zero(load_fr(value, i));
-            rows[i] = err ? 1 : 3;
-            vars[i] = err ? 1 : 3;
-            sr += err ? 1 : 3;
-            sv += err ? 1 : 3;
+            r[k] = v[k] = err ? 1 : 3;
             if (err_mask) err_mask[i] = err ? 1 : 0;
             if (err) atomicAdd(err_count, 1u);
         }
     }
-    plan_block_sums(sr, sv, blk_rows, blk_vars);
+    plan_store(P, r, v, batch, rows, vars);
 }
 
 // ---- the fused mix (BASELINE config C3) ---------------------------------------------
@@ -447,24 +444,21 @@ struct ScalarMixGD {
     }
 };
 
-__global__ __launch_bounds__(kThreads) void scalar_mix_plan_kernel(const uint4 *v, uint64_t batch, uint32_t *rows, uint32_t *vars,
-                                                                  uint8_t *err_mask, uint32_t *err_count, uint64_t *blk_rows,
-                                                                  uint64_t *blk_vars) {
-    uint64_t sr = 0, sv = 0;
+__global__ __launch_bounds__(kThreads) void scalar_mix_plan_kernel(const uint4 *v_in, uint64_t batch, uint32_t *rows, uint32_t *vars,
+                                                                  uint8_t *err_mask, uint32_t *err_count, const PlanScan P) {
+    uint32_t r[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x * 4 + k;
         if (i < batch) {
-            const bool err = fr_is_zero(load_fr(v, i));
-            rows[i] = err ? 8 : 10;
-            vars[i] = err ? 13 : 15;
-            sr += err ? 8 : 10;
-            sv += err ? 13 : 15;
+            const bool err = fr_is_zero(load_fr(v_in, i));
+            r[k] = err ? 8 : 10;
+            v[k] = err ? 13 : 15;
             if (err_mask) err_mask[i] = err ? 1 : 0;
             if (err) atomicAdd(err_count, 1u);
         }
     }
-    plan_block_sums(sr, sv, blk_rows, blk_vars);
+    plan_store(P, r, v, batch, rows, vars);
 }
 
 }  // namespace pg

@@ -202,3 +202,45 @@ def test_calls_that_move_to_another_stream(engine):
         for k in SEL + WIRES + ("var_values",):
             assert np.array_equal(got[k], ora_small[k]), k
         assert engine.check_rows(big[0], var_base=5, zero_var=0) == -1
+
+
+@pytest.mark.parametrize("batch", [1, 1023, 1025, 65 * 1024 + 7, 2_000_000, 2_500_000])
+def test_plans_against_a_host_prefix_sum(engine, batch):
+    """the plans' prefix sums -- one launch with a decoupled look-back up to 2048 blocks of 1024 items, the two-level scan
+    beyond (2.5 M items) -- against numpy's cumsum, for the mix (zeros sprinkled everywhere, at block edges too) and for the
+    ragged max_bound; totals and error count through the result record; twice, so that the second launch finds what the
+    first one left behind"""
+    rng = np.random.default_rng(batch)
+    v = np.zeros((batch, 4), dtype=np.uint64)
+    v[:, 0] = 1
+    zeros = np.unique(np.concatenate([rng.integers(0, batch, size=min(batch, 1000)), np.array([0, batch - 1]),
+                                      np.arange(1023, batch, 1024)[:64], np.arange(1024, batch, 1024)[:64]]))
+    v[zeros] = 0
+    dv = dev(v)
+    _, roff, voff = engine.ragged_buffers(batch)
+    err = torch.zeros((batch,), dtype=torch.uint8, device="cuda:0")
+    rows = np.where((v == 0).all(axis=1), 8, 10).astype(np.uint64)
+    vars_ = np.where((v == 0).all(axis=1), 13, 15).astype(np.uint64)
+    for _ in range(2):
+        roff.fill_(-1); voff.fill_(-1)
+        lay, nerr = engine.scalar_mix_plan(dv, roff, voff, err)
+        assert nerr == len(zeros) and (lay.n_gates, lay.n_vars) == (int(rows.sum()), int(vars_.sum()))
+        assert np.array_equal(roff.cpu().numpy().view(np.uint64), np.concatenate([[0], np.cumsum(rows)]).astype(np.uint64))
+        assert np.array_equal(voff.cpu().numpy().view(np.uint64), np.concatenate([[0], np.cumsum(vars_)]).astype(np.uint64))
+        assert np.array_equal(err.cpu().numpy().nonzero()[0], zeros)
+    # asynchronous form, then the result record
+    roff.fill_(-1)
+    engine.scalar_mix_plan_async(dv, roff, voff)
+    torch.cuda.synchronize()
+    lay2, nerr2 = engine.plan_result()
+    assert (lay2.n_gates, lay2.n_vars, nerr2) == (lay.n_gates, lay.n_vars, nerr)
+    assert int(roff[-1].item()) == lay.n_gates
+    if batch <= 2_000_000:
+        import bench
+        mr, _ = bench.c4_inputs(batch, seed=3)
+        nb, roff, voff = engine.ragged_buffers(batch)
+        lay = engine.max_bound_ragged_plan(dev(mr), nb, roff, voff)
+        n = nb.cpu().numpy().astype(np.uint64)
+        assert np.array_equal(roff.cpu().numpy().view(np.uint64), np.concatenate([[0], np.cumsum(2 * n + 5)]).astype(np.uint64))
+        assert np.array_equal(voff.cpu().numpy().view(np.uint64), np.concatenate([[0], np.cumsum(n + 262)]).astype(np.uint64))
+        assert (lay.n_gates, lay.n_vars) == (int((2 * n + 5).sum()), int((n + 262).sum()))
