@@ -624,21 +624,25 @@ def test_device_inversion_edge_values(engine):
     assert err.cpu().numpy().tolist() == errs and nerr == 1
 
 
-def test_calls_can_be_captured_in_a_hip_graph(engine):
+@pytest.mark.parametrize("planned", [False, True])
+def test_calls_can_be_captured_in_a_hip_graph(engine, planned):
     """after one warm-up call (scratch allocated) the asynchronous plan + emit of the ragged mix -- five kernels on the
     caller's stream, the inversion pre-pass on the engine's side stream, forked and joined with events -- records into a
     HIP graph; replays write the same bytes as the eager calls, also for new inputs in the same buffers"""
     import plonk_gadgets_amd as pg
     batch = 3000
-    v, y, s, a, b = mix_inputs(batch, 77, zeros=(5, 2999))
+    v, y, s, a, b = mix_inputs(batch, 77, zeros=(5, 2999))  # (3 blocks of the plan kernel: its look-back is replayed too)
     ins = [dev(x) for x in (v, y, s, a, b)]
     _, roff, voff = engine.ragged_buffers(batch)
     res = torch.empty((batch, 2), dtype=torch.int64, device="cuda:0")
     cols = pg.Columns.allocate(10 * batch, 15 * batch, "cuda:0")
 
     def step():
-        engine.scalar_mix_plan_async(ins[0], roff, voff)
-        engine.scalar_mix_emit(*ins, roff, voff, cols, res, 3, 5, 0)
+        if planned:  # the same in one call (the plan on the engine's rows stream for big batches, here on the caller's)
+            engine.scalar_mix_planned(*ins, roff, voff, cols, res, None, 3, 5, 0)
+        else:
+            engine.scalar_mix_plan_async(ins[0], roff, voff)
+            engine.scalar_mix_emit(*ins, roff, voff, cols, res, 3, 5, 0)
 
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
