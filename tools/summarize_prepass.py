@@ -24,6 +24,8 @@ def kernel_key(name):
             if mode in name:
                 return tag
         return "emit_kernel<EMIT_ALL>"
+    if "vars_image" in name:
+        return "vars_image_kernel"
     if "plan_kernel" in name:
         return "plan_kernel"
     if "scan_" in name:
