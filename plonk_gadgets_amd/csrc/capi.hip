@@ -361,13 +361,10 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
             PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_rows, 0));
         }
 #endif
-        // grid of the variable-table launch.  Measured and not kept (tools/ab_emit.py run_c3): 6 / 8 / 16 resident
-        // workgroups per CU striding over the tiles; the same with the next tile's loads issued before the current tile's
-        // stores (0.713 vs 0.706 ms); lanes 2s, 2s+1 storing the halves of slot s for full-line wave stores (0.30 vs
-        // 0.19 ms for this launch: twice the passes and LDS reads) -- the launch is bound by neither its loads' latency
-        // nor its dispatch rate nor partial lines.
+        // grid of the variable-table launch: resident workgroups (5 per CU is what the 30 KB images allow; 4 and 8 measure
+        // the same) striding over the tiles, see vars_image_kernel
 #ifndef PG_VARS_BLOCKS_PER_CU
-#define PG_VARS_BLOCKS_PER_CU 128
+#define PG_VARS_BLOCKS_PER_CU 5
 #endif
         const uint32_t vars_blocks = (uint32_t)e->num_cus * PG_VARS_BLOCKS_PER_CU;
         if (plan_beside) PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_plan, 0));  // the variable table reads the offsets

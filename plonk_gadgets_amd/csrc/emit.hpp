@@ -491,7 +491,7 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
 // ---- the variable table of a split gadget, as an image -------------------------------------------------------------------
 // The variables of a tile's items are ONE contiguous piece of the table (whatever the items' shapes: the prefix sums say
 // where each item starts).  A workgroup builds that piece in LDS exactly as it will lie in memory -- the kImageParts lanes
-// of an item share its slots out between them (GD::image_part: lanes of one part are consecutive, so the Montgomery
+// of an item share its slots out between them (GD::image_load / image_build: lanes of one part are consecutive, so the Montgomery
 // multiplication is a few half-waves', the copies of inputs the others') -- and then copies it out linearly, 16 bytes
 // per lane: every wave store is one contiguous KiB, and the copy loop has no index arithmetic at all.  Against the
 // EMIT_VARS launch of emit_kernel (a 32-byte slot per lane as two half-line stores, the slot's value selected from a
@@ -505,40 +505,50 @@ struct VarsImage<GD, std::void_t<decltype(GD::kImageW)>> {
     static constexpr bool ok = true;
 };
 
-template <class GD>
 // (asked for 5 waves per SIMD -- as many workgroups per CU as the 30 KB images allow -- the compiler takes 80 registers
 // instead of 122: no difference on the step, 0.590 vs 0.581 ms with the A/B order rotated)
 #ifndef PG_IMAGE_WAVES_PER_SIMD
 #define PG_IMAGE_WAVES_PER_SIMD 1
 #endif
+template <class GD>
 __global__ __launch_bounds__(GD::kImageW * GD::kImageParts, PG_IMAGE_WAVES_PER_SIMD) void vars_image_kernel(const typename GD::Args A, const EmitOut O) {
     constexpr int W = GD::kImageW;
     constexpr uint32_t kLanes = W * GD::kImageParts;
     __shared__ uint4 s_img[W * GD::kUniformVars * 2];
     const uint32_t tid = threadIdx.x, it = tid % W, part = tid / W;
+    // Resident workgroups stride over the tiles, and a tile's reads (its offsets, the part's one or two scalars per lane)
+    // are in flight, in registers, while the tile before it is built and stored: a workgroup that lives for one tile spends
+    // 72 % of its cycles waiting for that round trip (profiles/r02g_c3_prepass_counters.json); -2.2 % / -3.5 % on the
+    // fused mix's step.
+    struct Tile {
+        typename GD::ImageLoads L;
+        uint64_t v0, v1, mine, next;
+    };
+    auto fetch = [&](uint32_t tile, Tile &t) {
+        const uint64_t w0 = (uint64_t)tile * W;
+        const uint32_t Wt = (uint32_t)((O.batch - w0) < (uint64_t)W ? (O.batch - w0) : (uint64_t)W);
+        const uint32_t i = it < Wt ? it : Wt - 1;  // lanes past the end re-read the last item (not used)
+        t.v0 = O.var_off[w0];
+        t.v1 = O.var_off[w0 + Wt];
+        t.mine = O.var_off[w0 + i];
+        t.next = O.var_off[w0 + i + 1];
+        GD::image_load(A, O, w0 + i, part, t.L);
+    };
+    Tile cur, nxt;
+    if (blockIdx.x < O.tiles) fetch(blockIdx.x, cur);
     for (uint32_t tile = blockIdx.x; tile < O.tiles; tile += gridDim.x) {
         const uint64_t w0 = (uint64_t)tile * W;
         const uint32_t Wt = (uint32_t)((O.batch - w0) < (uint64_t)W ? (O.batch - w0) : (uint64_t)W);
-#if defined(PG_ABLATE_ITEM_PHASE)  // timing-only build (wrong output): the copy alone
-        const uint64_t v0 = w0 * GD::kUniformVars, v1 = (w0 + Wt) * GD::kUniformVars;
-        (void)it; (void)part;
-#else
-        const uint64_t v0 = O.var_off[w0], v1 = O.var_off[w0 + Wt];
-        if (it < Wt) {
-            const uint64_t mine = O.var_off[w0 + it], next = O.var_off[w0 + it + 1];
-            GD::image_part(A, O, w0 + it, part, (uint32_t)(next - mine), s_img + (mine - v0) * 2, O.var_base + mine);
-        }
-#endif
+        const bool more = tile + gridDim.x < O.tiles;
+        if (more) fetch(tile + gridDim.x, nxt);
+        if (it < Wt)
+            GD::image_build(A, w0 + it, part, (uint32_t)(cur.next - cur.mine), s_img + (cur.mine - cur.v0) * 2, O.var_base + cur.mine, cur.L);
         lds_barrier();
-        const uint32_t n16 = (uint32_t)(v1 - v0) * 2;
-        uint4 *dst = O.vars + v0 * 2;
-        for (uint32_t o = tid; o < n16; o += kLanes) {
-#if defined(PG_ABLATE_VAR_STORES)  // timing-only build (wrong output): the image without its way out
-            if (s_img[o].x == 0x12345678u && s_img[o].w == 0x9abcdef0u)
-#endif
-            store16(dst + o, s_img[o]);
-        }
+        const uint32_t n16 = (uint32_t)(cur.v1 - cur.v0) * 2;
+        uint4 *dst = O.vars + cur.v0 * 2;
+        for (uint32_t o = tid; o < n16; o += kLanes) store16(dst + o, s_img[o]);
         lds_barrier();  // the image is rewritten by the next tile
+        if (more) cur = nxt;
     }
 }
 

@@ -395,14 +395,33 @@ struct ScalarMixGD {
         img[2 * slot] = t.v[0];
         img[2 * slot + 1] = t.v[1];
     }
-    __device__ static void image_part(const Args &A, const EmitOut &O, uint64_t item, uint32_t part, uint32_t nvars, uint4 *img,
-                                      uint64_t vb) {
+    // what a part's lane reads from memory (image_load: loads only, so that a tile's reads can be in flight while the
+    // tile before it is built and stored) and what it makes of it (image_build)
+    struct ImageLoads {
+        Fr f0, f1;
+    };
+    __device__ static void image_load(const Args &A, const EmitOut &O, uint64_t item, uint32_t part, ImageLoads &L) {
+        if (part == 0) {
+            L.f0 = load_fr(A.v, item);
+            L.f1 = L.f0;
+        } else if (part == 1) {
+            L.f0 = load_fr(A.y, item);
+            L.f1 = load_fr(A.s, item);
+        } else if (part == 2) {
+            L.f0 = load_fr(A.a, item);
+            L.f1 = load_fr(A.b, item);
+        } else {  // the two inverses, from the pre-pass's compact output: element e of item i at [e * batch + i]
+            L.f0 = load_fr(O.inv, item);
+            L.f1 = load_fr(O.inv, O.batch + item);
+        }
+    }
+    __device__ static void image_build(const Args &A, uint64_t item, uint32_t part, uint32_t nvars, uint4 *img, uint64_t vb,
+                                       const ImageLoads &L) {
         const bool err = nvars != kUniformVars;
         const uint32_t tail = err ? 6 : 8;  // one' sy oms out | u z yeq
         if (part == 0) {  // v, var_assigned = v (scalar.rs:69), the two constants (scalar.rs:83, :41), the results' Variables
-            const Fr v = load_fr(A.v, item);
-            put(img, 0, v);
-            put(img, 5, v);
+            put(img, 0, L.f0);
+            put(img, 5, L.f0);
             if (!err) put(img, 7, fr_one());
             put(img, tail, fr_one());
             if (A.result_vars) {
@@ -410,23 +429,21 @@ struct ScalarMixGD {
                 A.result_vars[2 * item + 1] = vb + tail + 6;
             }
         } else if (part == 1) {  // y, s and select_one's three values
-            const Fr y = load_fr(A.y, item), s = load_fr(A.s, item);
-            put(img, 1, y);
-            put(img, 2, s);
-            const Fr sy = fr_mul(y, s), oms = fr_sub(fr_one(), s);  // scalar.rs:43, :45-50
+            put(img, 1, L.f0);
+            put(img, 2, L.f1);
+            const Fr sy = fr_mul(L.f0, L.f1), oms = fr_sub(fr_one(), L.f1);  // scalar.rs:43, :45-50
             put(img, tail + 1, sy);
             put(img, tail + 2, oms);
-            put(img, tail + 3, fr_add(sy, oms));                    // scalar.rs:53-58
+            put(img, tail + 3, fr_add(sy, oms));                              // scalar.rs:53-58
         } else if (part == 2) {  // a, b and maybe_equal's difference and result
-            const Fr a = load_fr(A.a, item), b = load_fr(A.b, item);
-            put(img, 3, a);
-            put(img, 4, b);
-            const Fr u = fr_sub(a, b);                              // scalar.rs:111-117
+            put(img, 3, L.f0);
+            put(img, 4, L.f1);
+            const Fr u = fr_sub(L.f0, L.f1);                                  // scalar.rs:111-117
             put(img, tail + 4, u);
-            put(img, tail + 6, fr_is_zero(u) ? fr_one() : fr_zero());  // y = 1 - u z, scalar.rs:126
-        } else {  // the two inverses, from the pre-pass's compact output: element e of item i at [e * batch + i]
-            if (!err) put(img, 6, load_fr(O.inv, item));            // scalar.rs:77
-            put(img, tail + 5, load_fr(O.inv, O.batch + item));     // scalar.rs:122-123 (0 when a = b)
+            put(img, tail + 6, fr_is_zero(u) ? fr_one() : fr_zero());         // y = 1 - u z, scalar.rs:126
+        } else {
+            if (!err) put(img, 6, L.f0);                                      // scalar.rs:77
+            put(img, tail + 5, L.f1);                                         // scalar.rs:122-123 (0 when a = b)
         }
     }
     // variable kc of a full-shape item: [v y s a b | va inv one | one' sy oms out | u z yeq]

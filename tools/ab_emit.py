@@ -34,10 +34,7 @@ VARIANTS = {
     "beside_l512": ["-DPG_INV_LANES_PER_CU=512"],
     "beside_grp8": ["-DPG_INV_GRP=8"],
     "image_waves5": ["-DPG_IMAGE_WAVES_PER_SIMD=5"],  # variable-image kernel held to 80 registers (5 workgroups per CU, what its LDS allows)
-    "abl_item": ["-DPG_ABLATE_ITEM_PHASE"],
-    "abl_item_b5": ["-DPG_ABLATE_ITEM_PHASE", "-DPG_VARS_BLOCKS_PER_CU=5"],
-    "abl_item_b10": ["-DPG_ABLATE_ITEM_PHASE", "-DPG_VARS_BLOCKS_PER_CU=10"],
-    "abl_stores": ["-DPG_ABLATE_VAR_STORES"],
+    "vars_blocks_128": ["-DPG_VARS_BLOCKS_PER_CU=128"],  # variable-image kernel: one workgroup per tile (prefetch never engages)
     "vars_b5": ["-DPG_VARS_BLOCKS_PER_CU=5"],
     "abl_var_stores": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_ABLATE_VAR_STORES"],   # timing only
     "abl_item_phase": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_ABLATE_ITEM_PHASE"],   # timing only
