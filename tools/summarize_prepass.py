@@ -71,7 +71,9 @@ res = {"what": f"rocprofv3 --pmc passes (own runs, kernels serialised by the pro
                f"python3 bench.py --workload {W} --steps 3 --warmup 1; averages per dispatch; SQ_* cycle counters are quad-cycles",
        "after": generation(-1)}
 if n_gen > 1:
-    res["before (the round-1 kernels, measured at the start of this round with the same script)"] = generation(0)
+    label = ("before (the round-1 kernels, measured at the start of this round with the same script)" if R == "r02" else
+             "before (the older generation of files in the directory: the same script run before the last kernel change)")
+    res[label] = generation(0)
 dst = os.path.join(ROOT, "profiles", f"{R}_{W}_prepass_counters.json")
 json.dump(res, open(dst, "w"), indent=1)
 for gen, d in res.items():
