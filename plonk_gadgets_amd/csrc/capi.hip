@@ -337,7 +337,8 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
 #ifndef PG_ROWS_WGS_PER_CU
 #define PG_ROWS_WGS_PER_CU 0
 #endif
-        if (PG_ROWS_WGS_PER_CU > 0) {
+#if PG_ROWS_WGS_PER_CU > 0
+        {
             static const size_t static_lds = [] {
                 hipFuncAttributes a{};
                 return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(pg::emit_kernel<GD, pg::EMIT_ROWS>)) == hipSuccess
@@ -346,6 +347,7 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
             const size_t want = (160 * 1024 / PG_ROWS_WGS_PER_CU) & ~(size_t)1023;  // per workgroup, so that exactly that many fit
             if (static_lds && static_lds < want && want <= 64 * 1024) pad = (uint32_t)(want - static_lds);
         }
+#endif
         // The rows are store traffic and the pre-pass integer arithmetic, and the rows need nothing the pre-pass computes:
         // beside each other they finish ~0.05-0.1 ms earlier than one after the other (fused mix, 2^20 items: pre-pass
         // 170 -> 320 us, rows 356 -> 461 us, together 473 instead of 527 us; tools/c3_timeline.sh).  What matters is WHO
