@@ -244,3 +244,51 @@ def test_plans_against_a_host_prefix_sum(engine, batch):
         assert np.array_equal(roff.cpu().numpy().view(np.uint64), np.concatenate([[0], np.cumsum(2 * n + 5)]).astype(np.uint64))
         assert np.array_equal(voff.cpu().numpy().view(np.uint64), np.concatenate([[0], np.cumsum(n + 262)]).astype(np.uint64))
         assert (lay.n_gates, lay.n_vars) == (int((2 * n + 5).sum()), int((n + 262).sum()))
+
+
+def test_fuzz_mix_sizes_and_error_densities(engine):
+    """the fused mix over random batch sizes (1 .. 70 000: below and above the size where the launches overlap, any
+    remainder modulo the tile widths 64 / 256 and the plan's 1024-item blocks) and random densities of failing items,
+    every column and the plan's outputs against the faithful oracle (small batches) or against the call's own two-step
+    form (large ones) -- the planned call, whose plan runs beside the pre-pass"""
+    import bench
+    import plonk_gadgets_amd as pg
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(20261004)
+    for trial in range(24):
+        batch = int(rng.choice([rng.integers(1, 300), rng.integers(300, 5000), rng.integers(5000, 70000)]))
+        density = float(rng.choice([0.0, 0.001, 0.05, 0.5, 1.0]))
+        v, y, s, a, b = bench.mix_inputs(batch, seed=1000 + trial)
+        zeros = np.nonzero(rng.random(batch) < density)[0]
+        v[zeros] = 0
+        ins = [dev(x) for x in (v, y, s, a, b)]
+        _, roff, voff = engine.ragged_buffers(batch)
+        big = pg.Columns.allocate(10 * batch, 15 * batch, "cuda:0")
+        res = torch.zeros((batch, 2), dtype=torch.int64, device="cuda:0")
+        err = torch.zeros((batch,), dtype=torch.uint8, device="cuda:0")
+        engine.scalar_mix_planned(*ins, roff, voff, big, res, err, 3, 5, 0)
+        torch.cuda.synchronize()
+        lay, nerr = engine.plan_result()
+        assert nerr == len(zeros) and np.array_equal(err.cpu().numpy().nonzero()[0], zeros), (trial, batch, density)
+        assert (lay.n_gates, lay.n_vars) == (10 * batch - 2 * len(zeros), 15 * batch - 2 * len(zeros))
+        got = big.to_numpy()
+        if batch <= 5000:
+            ora = po.scalar_mix_batch(v, y, s, a, b)
+            for k in SEL + WIRES:
+                assert np.array_equal(got[k][:lay.n_gates], ora[k]), (trial, batch, density, k)
+            assert np.array_equal(got["var_values"][:lay.n_vars], ora["var_values"]), (trial, batch, density)
+            assert np.array_equal(res.cpu().numpy().view(np.uint64).reshape(-1, 2), ora["result_vars"].reshape(-1, 2))
+        else:
+            _, roff2, voff2 = engine.ragged_buffers(batch)
+            lay2, nerr2 = engine.scalar_mix_plan(ins[0], roff2, voff2)
+            ref = pg.Columns.allocate(lay2.n_gates, lay2.n_vars, "cuda:0")
+            res2 = torch.zeros((batch, 2), dtype=torch.int64, device="cuda:0")
+            engine.scalar_mix_emit(*ins, roff2, voff2, ref, res2, 3, 5, 0)
+            torch.cuda.synchronize()
+            assert (lay2.n_gates, lay2.n_vars, nerr2) == (lay.n_gates, lay.n_vars, nerr)
+            assert torch.equal(roff, roff2) and torch.equal(voff, voff2) and torch.equal(res, res2)
+            exp = ref.to_numpy()
+            for k in SEL + WIRES + ("var_values",):
+                n = lay.n_vars if k == "var_values" else lay.n_gates
+                assert np.array_equal(got[k][:n], exp[k]), (trial, batch, density, k)
+            assert engine.check_rows(ref, var_base=5, zero_var=0) == -1
