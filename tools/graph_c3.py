@@ -23,9 +23,12 @@ def main():
     res = torch.empty((batch, 2), dtype=torch.int64, device=dev)
     cols = pg.Columns.allocate(10 * batch, 15 * batch, dev)
 
-    def step():
-        eng.scalar_mix_plan_async(ins[0], roff, voff)
-        eng.scalar_mix_emit(*ins, roff, voff, cols, res, 3, 5, 0)
+    def step():  # (the planned call; PG_C3_SEPARATE_PLAN=1: the plan as its own call)
+        if os.environ.get("PG_C3_SEPARATE_PLAN") == "1":
+            eng.scalar_mix_plan_async(ins[0], roff, voff)
+            eng.scalar_mix_emit(*ins, roff, voff, cols, res, 3, 5, 0)
+        else:
+            eng.scalar_mix_planned(*ins, roff, voff, cols, res, None, 3, 5, 0)
 
     def timed(fn, reps=20):
         fn()
