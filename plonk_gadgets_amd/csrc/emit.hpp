@@ -318,6 +318,32 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                         const uint32_t rl = tid >> 1, j = rl - (rl / R) * R;
                         uint4 v[5];
                         GD::selectors(A, s_item[0], j, s_table, tid & 1, v);
+#if !defined(PG_COLUMNS_IN_STEP)
+                        // A lane's five stores of one pass would go to the same row of five arrays of the same size: whether
+                        // those five addresses fall on the same memory channel is then decided by the arrays' base
+                        // addresses, once, for the whole call (tools/column_skew.py: up to 25 % between placements of the
+                        // same columns).  The values of a lane do not depend on the pass, so column c starts c fifths of the
+                        // tile further on and wraps: the five streams are that far apart in their arrays, by an amount
+                        // that is not a power of two.  -3 % on the fused mix's step on two boxes.  (The uniform big-item
+                        // sweep could do the same by whole items; on a box where C2 already runs at 6.84 TB/s it LOSES
+                        // 2.3 % -- an average instead of a lucky placement -- so it does not.)
+                        const uint32_t passes = (total_rows * 2 + LS - 1) / LS;
+                        uint4 *base[5];
+                        uint32_t at[5];
+#pragma unroll
+                        for (int c = 0; c < 5; c++) {
+                            base[c] = O.q[c] + (row0 * 2 + tid);
+                            at[c] = (uint32_t)(((uint64_t)c * passes) / 5);
+                        }
+                        for (uint32_t p = 0; p < passes; p++) {
+#pragma unroll
+                            for (int c = 0; c < 5; c++) {
+                                const uint32_t off = at[c] * LS;
+                                if (off + tid < total_rows * 2) store16(base[c] + off, v[c]);
+                                at[c] = at[c] + 1 == passes ? 0 : at[c] + 1;
+                            }
+                        }
+#else
                         uint4 *dst[5];
 #pragma unroll
                         for (int c = 0; c < 5; c++) dst[c] = O.q[c] + (row0 * 2 + tid);
@@ -328,6 +354,7 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                                 dst[c] += LS;
                             }
                         }
+#endif
                     }
                     // wires: two rows per lane; a pass of LW lanes covers 2 LW / R whole items
                     constexpr uint32_t LW = periodic_wire_lanes(R), IPW = 2 * LW / R;

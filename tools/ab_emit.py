@@ -36,6 +36,7 @@ VARIANTS = {
     "image_waves5": ["-DPG_IMAGE_WAVES_PER_SIMD=5"],  # variable-image kernel held to 80 registers (5 workgroups per CU, what its LDS allows)
     "vars_blocks_128": ["-DPG_VARS_BLOCKS_PER_CU=128"],  # variable-image kernel: one workgroup per tile (prefetch never engages)
     "vars_b5": ["-DPG_VARS_BLOCKS_PER_CU=5"],
+    "columns_in_step": ["-DPG_COLUMNS_IN_STEP"],  # periodic selector sweep: all five columns at the same row in every pass
     "abl_var_stores": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_ABLATE_VAR_STORES"],   # timing only
     "abl_item_phase": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_ABLATE_ITEM_PHASE"],   # timing only
     "abl_both": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_ABLATE_ITEM_PHASE", "-DPG_ABLATE_VAR_STORES"],
