@@ -15,7 +15,7 @@ import plonk_gadgets_amd as pg
 from plonk_gadgets_amd.engine import Columns
 
 
-ALIGN = 1 << 22  # with "delta" placement: every column starts at a multiple of 4 MiB plus c * delta
+ALIGN = 1 << int(os.environ.get("PG_SKEW_ALIGN_LOG2", "22"))  # "delta" placement: every column starts at a multiple of this plus c * delta
 
 
 def skewed(n_gates, n_vars, skew_bytes, dev, controlled=False):
