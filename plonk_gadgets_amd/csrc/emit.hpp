@@ -425,10 +425,22 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
             // ---- selector sweep: 16 B per lane, 128 rows x 5 columns per pass ---
             {
                 const uint32_t total = total_rows * 2;
-                const uint32_t h = tid & 1;
-                uint32_t it = 0, j = tid >> 1;
+                // A wave's store is one contiguous KiB; it should also START on a 128-byte line.  A tile begins wherever its
+                // first row falls (any multiple of 32 bytes when items are ragged), and a stream of KiB pieces that straddle
+                // lines writes 11-17 % slower than one that does not (tools/fill_stride.py).  So the sweep runs over the
+                // tile's 16-byte units counted from the line boundary before its first one: `mis` lanes of the first pass
+                // have nothing to store, and every wave store of every pass starts on a line.
+#if defined(PG_UNALIGNED_SWEEPS)  // A/B build
+                const uint32_t mis = 0;
+#else
+                const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(O.q[0] + row0 * 2) >> 4) & 7u);
+#endif
+                const uint32_t v0 = tid < mis ? tid + kThreads : tid;  // the first unit (counted from the line) this lane stores
+                const uint32_t h = (v0 - mis) & 1;
+                uint32_t it = 0, j = (v0 - mis) >> 1;
                 if constexpr (!GD::kRagged) { it = j / G; j -= it * G; }
-                for (uint32_t idx = tid; idx < total; idx += kThreads) {
+                for (uint32_t u = v0; u < total + mis; u += kThreads) {
+                    const uint32_t idx = u - mis;
                     if constexpr (GD::kRagged) {
                         const uint32_t r = idx >> 1;
                         it = find_item<W >= 64, kUniR>(s_roff, Wt, r, it, uni_rows);
@@ -452,8 +464,15 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                 // pair rows so that every pair starts on a 16-byte boundary
                 const uint32_t shift = (uint32_t)((reinterpret_cast<uintptr_t>(col) >> 3) & 1);
                 const uint32_t pairs = (total_rows + shift + 1) >> 1;
+                // ... and pairs are counted from the 128-byte line before the first one (see the selector sweep)
+#if defined(PG_UNALIGNED_SWEEPS)
+                const uint32_t pmis = 0;
+#else
+                const uint32_t pmis = (uint32_t)(((reinterpret_cast<uintptr_t>(col) - 8 * shift) >> 4) & 7u);
+#endif
                 uint32_t it = 0;
-                for (uint32_t p = tid; p < pairs; p += kThreads) {
+                for (uint32_t pv = tid < pmis ? tid + kThreads : tid; pv < pairs + pmis; pv += kThreads) {
+                    const uint32_t p = pv - pmis;
                     const int64_t r0 = (int64_t)2 * p - shift;
                     uint64_t val[2];
 #pragma unroll
@@ -491,9 +510,18 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
 
         // ---- variable sweep: one scalar (2 x 16 B) per lane ----------------
         if constexpr (kVars) {
-            uint32_t it = 0, k = tid;
+            // slots are counted from the 128-byte line before the tile's first one (see the selector sweep): a wave's two
+            // stores then cover whole lines between them
+#if defined(PG_UNALIGNED_SWEEPS)
+            const uint32_t smis = 0;
+#else
+            const uint32_t smis = (uint32_t)((reinterpret_cast<uintptr_t>(O.vars + var0 * 2) >> 5) & 3u);
+#endif
+            const uint32_t sv0 = tid < smis ? tid + kThreads : tid;
+            uint32_t it = 0, k = sv0 - smis;
             if constexpr (!GD::kRagged) { it = k / V; k -= it * V; }
-            for (uint32_t s = tid; s < total_vars; s += kThreads) {
+            for (uint32_t sv = sv0; sv < total_vars + smis; sv += kThreads) {
+                const uint32_t s = sv - smis;
                 if constexpr (GD::kRagged) {
                     it = find_item<W >= 64, kUniV>(s_voff, Wt, s, it, uni_vars);
                     k = uni_vars ? s - it * kUniV : s - s_voff[it];

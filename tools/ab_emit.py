@@ -37,6 +37,7 @@ VARIANTS = {
     "vars_blocks_128": ["-DPG_VARS_BLOCKS_PER_CU=128"],  # variable-image kernel: one workgroup per tile (prefetch never engages)
     "vars_b5": ["-DPG_VARS_BLOCKS_PER_CU=5"],
     "columns_in_step": ["-DPG_COLUMNS_IN_STEP"],  # periodic selector sweep: all five columns at the same row in every pass
+    "unaligned_sweeps": ["-DPG_UNALIGNED_SWEEPS"],  # generic sweeps start at the tile's first unit wherever it falls in a 128-byte line
     "abl_var_stores": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_ABLATE_VAR_STORES"],   # timing only
     "abl_item_phase": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_ABLATE_ITEM_PHASE"],   # timing only
     "abl_both": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_ABLATE_ITEM_PHASE", "-DPG_ABLATE_VAR_STORES"],
