@@ -470,7 +470,7 @@ pg_status pg_range_check_sharded_batch(pg_engine *e, const pg_scalar *min_range,
                                        pg_variable *d_result_vars /* may be NULL */, pg_shard *shard, void *stream);
 
 /* A packed chunk: the nine arrays of one call back to back in ONE buffer (offsets in 8-byte words, every section
- * 16-byte aligned), so that a chunk is a single collective.  pg_columns_in_packed gives the pg_columns view to emit into. */
+ * starting on a 128-byte line of a buffer that does), so that a chunk is a single collective.  pg_columns_in_packed gives the pg_columns view to emit into. */
 typedef struct pg_packed {
     uint64_t q_words[5], w_words[3], var_words; /* offsets of q_m..q_c, w_l..w_o, var_values */
     uint64_t total_words, n_gates, n_vars;

@@ -275,7 +275,7 @@ def gather_columns(cols: Columns, result_vars: torch.Tensor | None, gates_per_ra
 # ---- packed chunks: one collective per chunk -----------------------------------------
 
 def packed_layout(n_gates: int, n_vars: int):
-    """offsets (in int64 words) of the 9 arrays inside one packed chunk buffer; every section 16-byte aligned
+    """offsets (in int64 words) of the 9 arrays inside one packed chunk buffer; every section starts on a 128-byte line
     (pg_packed_layout)"""
     p = _lib.PackedC()
     st = _lib.load().pg_packed_layout(n_gates, n_vars, C.byref(p))

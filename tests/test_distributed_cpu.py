@@ -231,7 +231,7 @@ def test_packed_layout_alignment():
     from plonk_gadgets_amd import distributed as pd
     for ng, nv in ((87, 562), (1031, 1034), (2, 3)):
         off, sizes, total = pd.packed_layout(ng, nv)
-        assert all(o % 2 == 0 for o in off.values()) and total % 2 == 0  # 16-byte aligned sections (int64 words)
+        assert all(o % 16 == 0 for o in off.values()) and total % 16 == 0  # sections start on 128-byte lines (int64 words)
         flat = torch.zeros(total, dtype=torch.int64)
         cols = pd.columns_in(flat, ng, nv)
         assert cols.q_m.shape == (ng, 4) and cols.w_o.shape == (ng,) and cols.var_values.shape == (nv, 4)
@@ -267,9 +267,9 @@ def test_shard_entry_points_of_the_c_abi():
     p, cc = _lib.PackedC(), _lib.ColumnsC()
     assert lib.pg_packed_layout(7, 9, C.byref(p)) == 0
     assert lib.pg_columns_in_packed(buf.data_ptr(), 7, 9, C.byref(cc)) == 0
-    assert cc.q_m == buf.data_ptr() and cc.q_l - cc.q_m == 8 * 28 and cc.w_l - cc.q_c == 8 * 28
-    assert cc.w_r - cc.w_l == 8 * 8 and cc.var_values == buf.data_ptr() + 8 * p.var_words
-    assert p.total_words == 5 * 28 + 3 * 8 + 36
+    assert cc.q_m == buf.data_ptr() and cc.q_l - cc.q_m == 8 * 32 and cc.w_l - cc.q_c == 8 * 32  # 28 words, up to a line
+    assert cc.w_r - cc.w_l == 8 * 16 and cc.var_values == buf.data_ptr() + 8 * p.var_words
+    assert p.total_words == 5 * 32 + 3 * 16 + 48
     assert lib.pg_columns_in_packed(buf.data_ptr() + 8, 7, 9, C.byref(cc)) == 2  # misaligned
 
 
