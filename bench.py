@@ -258,8 +258,9 @@ class Workload:
                     eng.scalar_mix_emit(*part, roff, voff, cols, res, 3, 5, 0)
                 else:
                     eng.scalar_mix_planned(*part, roff, voff, cols, res, None, 3, 5, 0)
-            self.kernel = ("one step (pg_scalar_mix_planned_batch): the inversion pre-pass, beside it plan + scan and "
-                           "pg::emit_kernel<pg::ScalarMixGD, EMIT_ROWS>, then pg::vars_image_kernel<pg::ScalarMixGD>")
+            self.kernel = ("one step (pg_scalar_mix_planned_batch): pg::scalar_mix_vars_kernel<true> (prefix sums, inversions, "
+                           "variable table), then pg::rows_periodic_kernel<pg::ScalarMixGD> (+ the generic rows launch for "
+                           "tiles with a failing item)")
             self.desc = ("C3: 2^%d items/GPU x (5 add_input + is_non_zero + conditionally_select_one + maybe_equal), "
                          "one emit launch, 10 rows + 15 vars per item" % log2_batch)
         else:

@@ -245,8 +245,8 @@ pg_status pg_scalar_mix_batch(pg_engine *e, const pg_scalar *d_v, const pg_scala
 /* Plan and emit in ONE call, for callers whose buffers hold the worst case (`out`: 10 rows and 15 variables per item;
  * d_row_off / d_var_off: batch + 1 entries, written by the call).  Same result as pg_scalar_mix_plan_async followed by
  * pg_scalar_mix_batch on the same stream; the totals and the error count are read with pg_plan_result after the stream has
- * been synchronised.  What the single call buys: the inversion pre-pass reads the inputs only, so it starts at once and
- * the plan's two short launches run beside it instead of ahead of everything (~6 % of a 2^20-item step). */
+ * been synchronised.  What the single call buys: no plan launch at all -- the launch that inverts reads every v anyway and
+ * makes the prefix sums on its way (~7 % of a 2^20-item step). */
 pg_status pg_scalar_mix_planned_batch(pg_engine *e, const pg_scalar *d_v, const pg_scalar *d_y, const pg_scalar *d_s,
                                       const pg_scalar *d_a, const pg_scalar *d_b, uint64_t batch, uint64_t *d_row_off,
                                       uint64_t *d_var_off, uint8_t *d_err_mask /* may be NULL */, uint64_t gate_base,

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -107,16 +108,13 @@ struct pg_engine {
     // totals of the last plan, written by async copies into pinned host memory (read after a synchronisation)
     using PlanResult = pg::PlanTotals;
     PlanResult *h_plan = nullptr;
-    // scratch of the inversion pre-pass (grow-only): running products, 32 B per element
+    // scratch of the inversions (grow-only): the pre-pass parks an element and its running product (64 B per element),
+    // the fused mix one running product per item (32 B)
     uint4 *d_prefix = nullptr;
-    uint4 *d_inv = nullptr;  // compact inverses of a split gadget's call (32 B per element)
     uint64_t inv_elems = 0;
     // the pre-pass runs on its own stream beside the rows-only emit launch
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_inv = nullptr;
-    // a split gadget's rows launch runs on this one (normal priority) beside its pre-pass, which starts first on the caller's
-    hipStream_t rows = nullptr;
-    hipEvent_t ev_rows = nullptr, ev_plan = nullptr;
     // the stream the last call was issued on (see enter_stream)
     hipStream_t last_stream = nullptr;
     bool have_last = false;
@@ -135,7 +133,9 @@ pg_status ensure_scratch(pg_engine *e, uint64_t batch) {
     if (e->d_blk_agg) { (void)hipFree(e->d_blk_agg); e->d_blk_agg = nullptr; }
     e->scratch_items = 0;
     const uint64_t items = batch < 1024 ? 1024 : batch;
-    const uint64_t nblk = (items + pg::kScanBlock - 1) / pg::kScanBlock;
+    // (the published words: one per block of a plan kernel, or per wave of the fused mix's planning launch -- at most 2048
+    // of those up to 2 M items, one per 1024 items beyond)
+    const uint64_t nblk = std::max<uint64_t>((items + pg::kScanBlock - 1) / pg::kScanBlock, 2048);
     PG_HIP_TRY(hipMalloc(&e->d_rows, items * sizeof(uint32_t)));
     PG_HIP_TRY(hipMalloc(&e->d_vars, items * sizeof(uint32_t)));
     PG_HIP_TRY(hipMalloc(&e->d_blk_rows, nblk * sizeof(uint64_t)));
@@ -219,7 +219,6 @@ pg::EmitOut make_out(const pg_columns *c, uint64_t batch, int W, uint64_t gate_b
     O.zero_var = zero_var;
     O.row_off = row_off;
     O.var_off = var_off;
-    O.inv = nullptr;
     O.batch = batch;
     O.tiles = (uint32_t)((batch + W - 1) / W);
     return O;
@@ -229,10 +228,9 @@ pg_status ensure_inv_scratch(pg_engine *e, uint64_t elems) {
     if (elems <= e->inv_elems) return PG_OK;
     PG_HIP_TRY(hipSetDevice(e->device));
     if (e->d_prefix) { (void)hipFree(e->d_prefix); e->d_prefix = nullptr; }
-    if (e->d_inv) { (void)hipFree(e->d_inv); e->d_inv = nullptr; }
     e->inv_elems = 0;
-    PG_HIP_TRY(hipMalloc(&e->d_prefix, elems * 4 * sizeof(uint4)));  // per element: the element and its running product
-    PG_HIP_TRY(hipMalloc(&e->d_inv, elems * 2 * sizeof(uint4)));
+    // per element: the element and its running product; + 64 x 16 bytes that the fused mix's masked lanes store to
+    PG_HIP_TRY(hipMalloc(&e->d_prefix, (elems * 4 + 64) * sizeof(uint4)));
     e->inv_elems = elems;
     return PG_OK;
 }
@@ -262,139 +260,88 @@ pg_status enter_stream(pg_engine *e, hipStream_t st) {
 // on the engine's high-priority side stream.  The two write disjoint bytes (the pre-pass owns the inverse slots of
 // the variable table), so they run concurrently; the caller's stream is made to wait for both before the call's
 // results can be consumed.
-// a plan (its kernels, on the stream it is handed) that a call launches itself: the offsets the emit launches read are then
-// produced inside the call, and a split gadget's pre-pass -- which reads the inputs only -- does not wait for them
-using PlanLaunch = std::function<pg_status(hipStream_t)>;
+// A split gadget (small items: the fused mix) = ONE launch that inverts and writes the variable table
+// (scalar_mix_vars_kernel: integer arithmetic, bound by the multiplier) and then the rows, a pure store stream of 1.9 GB per
+// 2^20 items.  The rows need nothing the arithmetic computes, and still the launches run ONE AFTER THE OTHER: side by
+// side on the same compute units each slows the other down by more than the overlap gains, in every order and priority
+// tried -- even with the arithmetic launch stripped of all its memory traffic -- and on disjoint compute units (CU-masked
+// streams) the rows lack store bandwidth, which is per CU (profiles/NOTES_r03.md has the measurements).
+// `planned`: the arithmetic launch makes the call's prefix sums itself (d_row_off / d_var_off are outputs, as are the
+// engine's plan totals); otherwise it reads them.
+pg_status launch_mix(pg_engine *e, const pg::ScalarMixArgs &A, const pg_columns *c, uint64_t batch, uint64_t gate_base,
+                     uint64_t var_base, uint64_t zero_var, const uint64_t *row_off, const uint64_t *var_off, hipStream_t st,
+                     const pg::MixPlan *planned) {
+    using GD = pg::ScalarMixGD;
+    PG_TRY(ensure_inv_scratch(e, batch));
+    // geometry of the arithmetic launch: a wave owns 32 * ipl consecutive items; two waves per SIMD is what it is built for
+    const uint64_t waves_wanted = (uint64_t)e->num_cus * 4 * 2;
+    uint64_t ipl = (batch + waves_wanted * 32 - 1) / (waves_wanted * 32);
+    if (ipl < 1) ipl = 1;
+    if (ipl > pg::kMixMaxIpl) ipl = pg::kMixMaxIpl;
+    const uint64_t waves = (batch + 32 * ipl - 1) / (32 * ipl);
+    const pg::EmitOut V = make_out(c, batch, GD::W, gate_base, var_base, zero_var, row_off, var_off);
+    const pg::EmitOut R = make_out(c, batch, GD::kRowsW, gate_base, var_base, zero_var, row_off, var_off);
+    const uint32_t max_blocks = (uint32_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
+    const dim3 grid(R.tiles < max_blocks ? R.tiles : max_blocks), vgrid((uint32_t)((waves + pg::kMixWaves - 1) / pg::kMixWaves));
+    const dim3 vblock(pg::kMixWaves * 64);
+    uint4 *sink = e->d_prefix + e->inv_elems * 4;
+    if (planned) {
+        pg::MixPlan P = *planned;
+        P.nwaves = (uint32_t)waves;
+        hipLaunchKernelGGL(pg::scalar_mix_vars_kernel<true>, vgrid, vblock, 0, st, A, V, (uint32_t)ipl, e->d_prefix, sink, P);
+    } else
+        hipLaunchKernelGGL(pg::scalar_mix_vars_kernel<false>, vgrid, vblock, 0, st, A, V, (uint32_t)ipl, e->d_prefix, sink,
+                           pg::MixPlan{});
+    hipLaunchKernelGGL(pg::rows_periodic_kernel<GD>, grid, dim3(pg::kThreads), 0, st, A, R);
+    // the tiles that hold an item of another shape (none, unless an item stopped at its error): every other workgroup of
+    // this launch reads two offsets and leaves
+    hipLaunchKernelGGL((pg::emit_kernel<GD, pg::EMIT_ROWS>), grid, dim3(pg::kThreads), 0, st, A, R);
+    PG_HIP_TRY(hipGetLastError());
+    return PG_OK;
+}
 
 template <class GD>
 pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, uint64_t batch, uint64_t gate_base,
                  uint64_t var_base, uint64_t zero_var, const uint64_t *row_off, const uint64_t *var_off, void *stream,
-                 const PlanLaunch *plan = nullptr) {
+                 const pg::MixPlan *planned = nullptr) {
     if ((batch + GD::W - 1) / GD::W > 0xffffffffull) return fail(PG_ERR_INVALID_ARGUMENT, "batch too large for one call");
     hipStream_t st = static_cast<hipStream_t>(stream);
     PG_TRY(enter_stream(e, st));
-    pg::EmitOut O = make_out(c, batch, GD::W, gate_base, var_base, zero_var, row_off, var_off);
-    constexpr bool kSplit = pg::Split<GD>::ok;  // the rows, then the variable table (emit.hpp, EmitMode)
-    bool side = false;         // the inversion pre-pass runs on the engine's side stream
-    bool rows_beside = false;  // split gadget: the rows launch runs on the engine's rows stream, beside the pre-pass
-    bool plan_beside = false;  // ... and so does the plan the call was handed
-    if constexpr (GD::kInv > 0) {
-        constexpr int GRP = GD::kInvGroup;
-        const uint64_t elems = batch * GD::kInv;
-        PG_TRY(ensure_inv_scratch(e, elems));
-        const uint64_t lanes_wanted = (uint64_t)e->num_cus * PG_INV_LANES_PER_CU;
-        uint64_t per_lane = (elems + lanes_wanted - 1) / lanes_wanted;
-        if (per_lane < 1) per_lane = 1;
-        if (per_lane > PG_INV_MAX_PER_LANE) per_lane = PG_INV_MAX_PER_LANE;
-        const uint64_t groups = (per_lane + GRP - 1) / GRP;  // a lane owns groups * GRP elements
-        const uint64_t lanes = (elems + groups * GRP - 1) / (groups * GRP);
-        const uint32_t blocks = (uint32_t)((lanes + pg::kThreads - 1) / pg::kThreads);
-        uint4 *compact = kSplit ? e->d_inv : nullptr;
-        O.inv = compact;
-#if defined(PG_SEQUENTIAL_PREPASS)  // A/B build: the pre-pass on the caller's stream, ahead of the emit kernel
-        side = false;
-#else
-        // a handful of elements (the single-gadget calls of pg_composer): two event hops cost more than the overlap buys.
-        // A split gadget (small items) keeps its pre-pass on the caller's stream, where it STARTS FIRST, and sends the rows
-        // launch -- which needs nothing the pre-pass computes -- to the engine's rows stream to run beside it (below).
-        side = elems >= 2048 && !kSplit;
-#endif
-#if !defined(PG_SPLIT_SEQUENTIAL)  // (A/B build: pre-pass, rows, variable table one after the other on the caller's stream)
-        if constexpr (kSplit) rows_beside = elems >= 2048;
-#endif
-        if (!side) {
-            if (rows_beside) {  // fork: the rows launch reads the call's inputs and offsets
-                PG_HIP_TRY(hipEventRecord(e->ev_fork, st));
-                PG_HIP_TRY(hipStreamWaitEvent(e->rows, e->ev_fork, 0));
-                if (plan) {  // the plan goes ahead of the rows on their stream, beside the pre-pass
-                    PG_TRY((*plan)(e->rows));
-                    PG_HIP_TRY(hipEventRecord(e->ev_plan, e->rows));
-                    plan_beside = true;
-                }
-            }
-            if (plan && !plan_beside) PG_TRY((*plan)(st));
-            hipLaunchKernelGGL((pg::batch_invert_kernel<GD, GRP>), dim3(blocks), dim3(pg::kThreads), 0, st, A, O, elems,
-                               (uint32_t)groups, e->d_prefix, compact);
-            PG_HIP_TRY(hipGetLastError());
-        } else {
-            PG_HIP_TRY(hipEventRecord(e->ev_fork, st));  // the pre-pass reads the call's inputs: order it after the stream
-            PG_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-            hipLaunchKernelGGL((pg::batch_invert_kernel<GD, GRP>), dim3(blocks), dim3(pg::kThreads), 0, e->side, A, O, elems,
-                               (uint32_t)groups, e->d_prefix, compact);
-            PG_HIP_TRY(hipGetLastError());
-            PG_HIP_TRY(hipEventRecord(e->ev_inv, e->side));
-        }
-    }
-    const uint32_t max_blocks = (uint32_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
-    if (plan && (side || GD::kInv == 0)) PG_TRY((*plan)(st));  // (no caller today: a planned call of a gadget that is not split)
-    if constexpr (kSplit) {
-        const pg::EmitOut R = make_out(c, batch, GD::kRowsW, gate_base, var_base, zero_var, row_off, var_off);
-        // PG_ROWS_WGS_PER_CU > 0 (A/B builds): hold the rows launch to that many workgroups per CU, by asking for LDS it does
-        // not use, to leave registers for the pre-pass's fat waves.  Measured on the fused mix (tools/ab_emit.py): 2, 3 and
-        // 4 per CU all LOSE (0.77 / 0.79 / 0.82 ms against 0.74 unlimited) -- unlike the big-item emitters this launch needs
-        // its full residency to reach 7 TB/s, and the pre-pass gains less than the rows lose.  Default: off.
-        uint32_t pad = 0;
-#ifndef PG_ROWS_WGS_PER_CU
-#define PG_ROWS_WGS_PER_CU 0
-#endif
-#if PG_ROWS_WGS_PER_CU > 0
-        {
-            static const size_t static_lds = [] {
-                hipFuncAttributes a{};
-                return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(pg::emit_kernel<GD, pg::EMIT_ROWS>)) == hipSuccess
-                           ? a.sharedSizeBytes : (size_t)0;
-            }();
-            const size_t want = (160 * 1024 / PG_ROWS_WGS_PER_CU) & ~(size_t)1023;  // per workgroup, so that exactly that many fit
-            if (static_lds && static_lds < want && want <= 64 * 1024) pad = (uint32_t)(want - static_lds);
-        }
-#endif
-        // The rows are store traffic and the pre-pass integer arithmetic, and the rows need nothing the pre-pass computes:
-        // beside each other they finish ~0.05-0.1 ms earlier than one after the other (fused mix, 2^20 items: pre-pass
-        // 170 -> 320 us, rows 356 -> 461 us, together 473 instead of 527 us; tools/c3_timeline.sh).  What matters is WHO
-        // STARTS FIRST: with the pre-pass on a second stream (round 1 / early round 2, even at high priority) the rows'
-        // workgroups own every SIMD's registers before the pre-pass's fat waves (168 registers) are placed, and it becomes
-        // resident a hundred microseconds late; on the caller's stream it is dispatched first and the rows fill in around it.
-        hipStream_t rows_st = rows_beside ? e->rows : st;
-        hipLaunchKernelGGL((pg::emit_kernel<GD, pg::EMIT_ROWS>), dim3(R.tiles < max_blocks ? R.tiles : max_blocks), dim3(pg::kThreads), pad,
-                           rows_st, A, R);
-#if defined(PG_VARS_AFTER_ROWS)  // A/B build: the variable table waits for the rows too
-        if (rows_beside) {
-            PG_HIP_TRY(hipEventRecord(e->ev_rows, e->rows));
-            PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_rows, 0));
-        }
-#endif
-        // grid of the variable-table launch: resident workgroups (5 per CU is what the 30 KB images allow; 4 and 8 measure
-        // the same) striding over the tiles, see vars_image_kernel
-#ifndef PG_VARS_BLOCKS_PER_CU
-#define PG_VARS_BLOCKS_PER_CU 5
-#endif
-        const uint32_t vars_blocks = (uint32_t)e->num_cus * PG_VARS_BLOCKS_PER_CU;
-        if (plan_beside) PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_plan, 0));  // the variable table reads the offsets
-#if !defined(PG_NO_VARS_IMAGE)
-        if constexpr (pg::VarsImage<GD>::ok) {
-            pg::EmitOut I = make_out(c, batch, GD::kImageW, gate_base, var_base, zero_var, row_off, var_off);
-            I.inv = O.inv;
-            hipLaunchKernelGGL(pg::vars_image_kernel<GD>, dim3(I.tiles < vars_blocks ? I.tiles : vars_blocks), dim3(GD::kImageW * GD::kImageParts), 0, st, A, I);
-        } else
-#endif
-        hipLaunchKernelGGL((pg::emit_kernel<GD, pg::EMIT_VARS>), dim3(O.tiles < vars_blocks ? O.tiles : vars_blocks), dim3(pg::kThreads), 0,
-                           st, A, O);
-        // The variable table follows the pre-pass on the caller's stream and does NOT wait for the rows (it writes another
-        // column): it starts while the rows are still streaming and fills the time its own workgroups spend waiting for
-        // their inputs.  Five boxes, fused mix, 2^20 items: 0.60-0.65 ms per call against 0.63-0.68 with the variable table
-        // after the rows and 0.64-0.67 with all three launches one after the other (tools/ab_emit.py run_c3).
-#if !defined(PG_VARS_AFTER_ROWS)
-        if (rows_beside) {  // join: whatever the caller does next follows both streams
-            PG_HIP_TRY(hipEventRecord(e->ev_rows, e->rows));
-            PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_rows, 0));
-        }
-#endif
+    if constexpr (pg::Split<GD>::ok) {
+        return launch_mix(e, A, c, batch, gate_base, var_base, zero_var, row_off, var_off, st, planned);
     } else {
+        pg::EmitOut O = make_out(c, batch, GD::W, gate_base, var_base, zero_var, row_off, var_off);
+        bool side = false;  // the inversion pre-pass runs on the engine's side stream
+        if constexpr (GD::kInv > 0) {
+            constexpr int GRP = GD::kInvGroup;
+            const uint64_t elems = batch * GD::kInv;
+            PG_TRY(ensure_inv_scratch(e, elems));
+            const uint64_t lanes_wanted = (uint64_t)e->num_cus * PG_INV_LANES_PER_CU;
+            uint64_t per_lane = (elems + lanes_wanted - 1) / lanes_wanted;
+            if (per_lane < 1) per_lane = 1;
+            if (per_lane > PG_INV_MAX_PER_LANE) per_lane = PG_INV_MAX_PER_LANE;
+            const uint64_t groups = (per_lane + GRP - 1) / GRP;  // a lane owns groups * GRP elements
+            const uint64_t lanes = (elems + groups * GRP - 1) / (groups * GRP);
+            const uint32_t blocks = (uint32_t)((lanes + pg::kThreads - 1) / pg::kThreads);
+            // a handful of elements (the single-gadget calls of pg_composer): two event hops cost more than the overlap buys
+            side = elems >= 2048;
+            hipStream_t inv_st = st;
+            if (side) {
+                PG_HIP_TRY(hipEventRecord(e->ev_fork, st));  // the pre-pass reads the call's inputs: order it after the stream
+                PG_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+                inv_st = e->side;
+            }
+            hipLaunchKernelGGL((pg::batch_invert_kernel<GD, GRP>), dim3(blocks), dim3(pg::kThreads), 0, inv_st, A, O, elems,
+                               (uint32_t)groups, e->d_prefix);
+            PG_HIP_TRY(hipGetLastError());
+            if (side) PG_HIP_TRY(hipEventRecord(e->ev_inv, e->side));
+        }
+        const uint32_t max_blocks = (uint32_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
         hipLaunchKernelGGL(pg::emit_kernel<GD>, dim3(O.tiles < max_blocks ? O.tiles : max_blocks), dim3(pg::kThreads), 0, st, A, O);
+        PG_HIP_TRY(hipGetLastError());
+        if (side) PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_inv, 0));  // join
+        return PG_OK;
     }
-    PG_HIP_TRY(hipGetLastError());
-    if (side) PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_inv, 0));  // join
-    return PG_OK;
 }
 
 pg_status scalar_args(const pg_variable *a_var, const pg_scalar *a_val, const pg_variable *b_var,
@@ -502,12 +449,6 @@ pg_status pg_engine_create(int device, pg_engine **out) {
     *e->h_plan = pg_engine::PlanResult{0, 0, 0, 0};
     // the pre-pass is the critical path of a call with small items: highest priority, so its waves are placed ahead of
     // the rows-only emit launch it runs beside
-    // the rows stream has normal priority (highest: +15 % on the fused mix's step; lowest: no difference, 0.590 vs 0.583 ms)
-#if defined(PG_ROWS_STREAM_LOW)  // A/B build
-#define PG_ROWS_STREAM_PRIORITY(lo) (lo)
-#else
-#define PG_ROWS_STREAM_PRIORITY(lo) 0
-#endif
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
 #if defined(PG_SIDE_STREAM_NORMAL_PRIORITY)
@@ -516,10 +457,7 @@ pg_status pg_engine_create(int device, pg_engine **out) {
     if (hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_inv, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_switch, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithPriority(&e->rows, hipStreamNonBlocking, PG_ROWS_STREAM_PRIORITY(prio_lo)) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_rows, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_plan, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&e->ev_switch, hipEventDisableTiming) != hipSuccess) {
         pg_engine_destroy(e);
         return fail(PG_ERR_HIP, "creating the engine's side stream / events failed");
     }
@@ -544,11 +482,7 @@ void pg_engine_destroy(pg_engine *e) {
     if (e->d_err_count) (void)hipFree(e->d_err_count);
     if (e->d_blk_agg) (void)hipFree(e->d_blk_agg);
     if (e->d_prefix) (void)hipFree(e->d_prefix);
-    if (e->d_inv) (void)hipFree(e->d_inv);
     if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
-    if (e->rows) { (void)hipStreamSynchronize(e->rows); (void)hipStreamDestroy(e->rows); }
-    if (e->ev_rows) (void)hipEventDestroy(e->ev_rows);
-    if (e->ev_plan) (void)hipEventDestroy(e->ev_plan);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_inv) (void)hipEventDestroy(e->ev_inv);
     if (e->ev_switch) (void)hipEventDestroy(e->ev_switch);
@@ -965,10 +899,14 @@ pg_status pg_scalar_mix_planned_batch(pg_engine *e, const pg_scalar *d_v, const 
     A.a = reinterpret_cast<const uint4 *>(d_a);
     A.b = reinterpret_cast<const uint4 *>(d_b);
     A.result_vars = d_result_vars;
-    const PlanLaunch plan = [=](hipStream_t st) {
-        return error_plan_launch(e, pg::scalar_mix_plan_kernel, d_v, batch, d_row_off, d_var_off, d_err_mask, st);
-    };
-    return launch<pg::ScalarMixGD>(e, A, out, batch, gate_base, var_base, zero_var, d_row_off, d_var_off, stream, &plan);
+    pg::MixPlan P{};  // the call plans itself: the launch that inverts also makes the prefix sums (scalar_gadgets.hpp)
+    P.agg = e->d_blk_agg;
+    P.cap = (uint32_t)e->scratch_blocks;
+    P.row_off = d_row_off;
+    P.var_off = d_var_off;
+    P.err_mask = d_err_mask;
+    P.host = e->h_plan;
+    return launch<pg::ScalarMixGD>(e, A, out, batch, gate_base, var_base, zero_var, d_row_off, d_var_off, stream, &P);
 }
 
 pg_status pg_fill_bytes(pg_engine *e, void *d_dst, uint64_t bytes, uint32_t streams, uint64_t pattern, void *stream) {

@@ -42,7 +42,6 @@ struct EmitOut {
     uint64_t zero_var;             // composer.zero_var (fourth wire / assert_equal's output wire)
     const uint64_t *row_off;       // ragged only: [batch+1] exclusive prefix sums, relative to the call
     const uint64_t *var_off;
-    const uint4 *inv;              // split gadgets: the pre-pass's compact output, inverse e of item i at [e * batch + i]
     uint64_t batch;
     uint32_t tiles;
 };
@@ -74,6 +73,12 @@ __device__ __forceinline__ void lds_barrier() {
 #else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
+}
+
+// a value every lane of the wave holds, moved to scalar registers
+__device__ __forceinline__ uint64_t uniform64(uint64_t x) {
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x) |
+           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32;
 }
 
 __device__ __forceinline__ Fr lds_fr(const uint4 *table, uint32_t id) {
@@ -137,8 +142,8 @@ __device__ __forceinline__ uint32_t find_item(const uint32_t *off, uint32_t Wt, 
 //   void wires(A, O, rec, item, item_var_base, j, uint64_t out[3])
 //   Fr   var_value(A, rec, table, k)
 //   bool is_inv_slot(A, rec, k)          item-variable k holds an inverse (written by the pre-pass, not here)
-//   kSplit / RowRec / kRowsW             optional: the gadget is emitted as EMIT_ROWS + EMIT_VARS (below)
-//   kPeriodic / var_value_full(A, rec, table, k)   optional: tiles of full-shape items take the periodic sweeps (below)
+//   kSplit / RowRec / kRowsW             optional: the rows are written by launches of their own (EmitMode, below)
+//   kPeriodic                            optional: the rows of full-shape tiles by rows_periodic_kernel (below)
 //   int  kInv; inv_operands / inv_combine / inv_slot                        the pre-pass's view (invert.hpp)
 template <class GD, bool RAGGED = GD::kRagged>
 struct UniformShape {
@@ -149,12 +154,8 @@ struct UniformShape<GD, true> {
     static constexpr uint32_t rows = GD::kUniformRows, vars = GD::kUniformVars;
 };
 
-// kPeriodic (optional, ragged gadgets with small items): in a tile whose items all have the full shape, selectors depend
-// on the row-within-item alone and wires are `constant` or `item's first variable + constant`.  The sweeps of such a
-// tile then use a lane count that is a multiple of the item size, so that a lane meets the SAME row-within-item on
-// every pass: selector values, wire offsets and the variable's slot are computed once per tile and the loops are bare
-// stores (the generic sweeps spend ~30 vector + ~20 scalar instructions per 16-byte store on finding the item, the
-// row and the constants again -- measured on the fused mix: SQ_INSTS_VALU, profiles/).
+// kPeriodic (optional, ragged gadgets with small items): tiles of full-shape items have their rows written by
+// rows_periodic_kernel (below)
 template <class GD, class = void>
 struct Periodic {
     static constexpr bool ok = false;
@@ -180,15 +181,15 @@ constexpr uint32_t periodic_wire_lanes(uint32_t R) {
 //                   item record they are a function of the public inputs and the numbering, not of the witnesses, so a
 //                   rank can regenerate another rank's rows instead of receiving them (distributed.VariablesOnlyPipeline)
 //   EMIT_ROWS       selectors and wire indices of a gadget whose rows DO depend on its inputs, but only through a cheap
-//                   per-item shape (GD::RowRec, GD::item_rows): a lean pure-store launch (no arithmetic, a few bytes of
-//                   LDS per item, GD::kRowsW items per tile) that shares the chip with the inversion pre-pass
-//   EMIT_VARS       the variable table alone, inverse slots included: the item phase reads the item's inverses from the
-//                   pre-pass's compact output (O.inv) into its record
-// A gadget with GD::kSplit is emitted as pre-pass, EMIT_ROWS, EMIT_VARS, in that order on the caller's stream: for
-// small items the all-in-one launch is a poor streaming writer -- its tile is bounded by the LDS the item records take
-// (64 items = 148 KB of output for the fused mix), so a workgroup's global round trips before its first store are never
-// amortised -- while four fifths of its bytes (the rows) need no record at all.
-enum EmitMode : int { EMIT_ALL = 0, EMIT_STRUCTURE = 1, EMIT_ROWS = 2, EMIT_VARS = 3 };
+//                   per-item shape (GD::RowRec, GD::item_rows), over tiles of GD::kRowsW items.  For a periodic gadget
+//                   (below) this launch writes only the tiles that hold an item of another shape; the full-shape tiles --
+//                   all of them, unless an item stopped at its error -- are rows_periodic_kernel's
+// A gadget with GD::kSplit (small items: the fused mix) is emitted as rows launches beside ONE launch of its own that
+// inverts and writes the variable table (scalar_gadgets.hpp, scalar_mix_vars_kernel): for small items the all-in-one
+// launch is a poor streaming writer -- its tile is bounded by the LDS the item records take (64 items = 148 KB of output
+// for the fused mix), so a workgroup's global round trips before its first store are never amortised -- while four
+// fifths of its bytes (the rows) need no record at all.
+enum EmitMode : int { EMIT_ALL = 0, EMIT_STRUCTURE = 1, EMIT_ROWS = 2 };
 
 template <class GD, class = void>
 struct Split {
@@ -215,8 +216,7 @@ struct EmitShape<GD, EMIT_ROWS> {
 template <class GD, int MODE = EMIT_ALL>
 __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(const typename GD::Args A, const EmitOut O) {
     static_assert(MODE != EMIT_STRUCTURE || !(GD::kRagged || GD::kRecInRows), "rows of this gadget depend on its inputs");
-    constexpr bool kRows = MODE != EMIT_VARS;                     // selector and wire sweeps
-    constexpr bool kVars = MODE == EMIT_ALL || MODE == EMIT_VARS;  // item arithmetic and the variable sweep
+    constexpr bool kVars = MODE == EMIT_ALL;  // item arithmetic and the variable sweep
     constexpr int W = EmitShape<GD, MODE>::W;
     using Rec = typename EmitShape<GD, MODE>::Rec;
     constexpr uint32_t kTable = GD::kUsePow2 ? kTableEntries : T_POW;  // gadgets without a ladder need the 8 constants only
@@ -244,6 +244,9 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
 #endif
         const uint64_t w0 = (uint64_t)tile * W;
         const uint32_t Wt = (uint32_t)((O.batch - w0) < (uint64_t)W ? (O.batch - w0) : (uint64_t)W);
+        if constexpr (MODE == EMIT_ROWS && Periodic<GD>::ok) {  // a tile of full-shape items: rows_periodic_kernel's
+            if (O.row_off[w0 + Wt] - O.row_off[w0] == (uint64_t)Wt * UniformShape<GD>::rows) continue;
+        }
         uint64_t row0, var0;  // tile's first row / variable relative to the call
         uint32_t G = 0, V = 0;
         // The tile's global loads are ISSUED together and waited for once: its offsets (ragged), then whatever the item
@@ -273,17 +276,9 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
         // ---- item phase: one lane per item --------------------------------
         // With rows to write: first what they depend on (an item's shape: ladder length, stopped-early flag), so that
         // after ONE barrier every wave can store rows; the witness-dependent arithmetic (loads, Montgomery conversions)
-        // then occupies the first lanes only, beside the other waves' selector and wire sweeps.  Without (EMIT_VARS):
-        // the whole record at once, its loads in flight together with the offsets'.
-        if constexpr ((GD::kRagged || GD::kRecInRows) && kRows && MODE != EMIT_STRUCTURE) {
+        // then occupies the first lanes only, beside the other waves' selector and wire sweeps.
+        if constexpr ((GD::kRagged || GD::kRecInRows) && MODE != EMIT_STRUCTURE) {
             for (uint32_t i = tid; i < Wt; i += kThreads) GD::item_rows(A, O, w0 + i, s_table, s_item[i]);
-        }
-        if constexpr (kVars && !kRows) {
-#if defined(PG_ABLATE_ITEM_PHASE)  // timing-only build (wrong output): no item phase in the variables-only launch
-            if (tid < Wt) s_item[tid].err = 0;
-#else
-            if (tid < Wt) GD::item(A, O, w0 + tid, s_table, s_item[tid]);
-#endif
         }
         if constexpr (GD::kRagged) {
             if (tid <= Wt) {
@@ -297,8 +292,8 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                 }
             }
         }
-        if constexpr (GD::kRagged || GD::kRecInRows || !kRows) lds_barrier();
-        if constexpr (kVars && kRows) {
+        if constexpr (GD::kRagged || GD::kRecInRows) lds_barrier();
+        if constexpr (kVars) {
             if (tid < Wt) GD::item(A, O, w0 + tid, s_table, s_item[tid]);
         }
 
@@ -307,121 +302,7 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
         constexpr uint32_t kUniR = UniformShape<GD>::rows, kUniV = UniformShape<GD>::vars;
         const bool uni_rows = kUniR != 0 && total_rows == Wt * kUniR, uni_vars = kUniV != 0 && total_vars == Wt * kUniV;
 
-#if !defined(PG_NO_PERIODIC)
-        if constexpr (Periodic<GD>::ok && MODE != EMIT_STRUCTURE) {
-            if (uni_rows && uni_vars) {  // every item of the tile has the full shape
-                constexpr uint32_t R = kUniR, VV = kUniV;
-                if constexpr (kRows) {
-                    // selectors: lanes 2r, 2r+1 hold the halves of row r; IPP whole items per pass
-                    constexpr uint32_t IPP = (kThreads / 2) / R, LS = IPP * R * 2;
-                    if (tid < LS) {
-                        const uint32_t rl = tid >> 1, j = rl - (rl / R) * R;
-                        uint4 v[5];
-                        GD::selectors(A, s_item[0], j, s_table, tid & 1, v);
-#if !defined(PG_COLUMNS_IN_STEP)
-                        // A lane's five stores of one pass would go to the same row of five arrays of the same size: whether
-                        // those five addresses fall on the same memory channel is then decided by the arrays' base
-                        // addresses, once, for the whole call (tools/column_skew.py: up to 25 % between placements of the
-                        // same columns).  The values of a lane do not depend on the pass, so column c starts c fifths of the
-                        // tile further on and wraps: the five streams are that far apart in their arrays, by an amount
-                        // that is not a power of two.  -3 % on the fused mix's step on two boxes.  (The uniform big-item
-                        // sweep could do the same by whole items; on a box where C2 already runs at 6.84 TB/s it LOSES
-                        // 2.3 % -- an average instead of a lucky placement -- so it does not.)
-                        const uint32_t passes = (total_rows * 2 + LS - 1) / LS;
-                        uint4 *base[5];
-                        uint32_t at[5];
-#pragma unroll
-                        for (int c = 0; c < 5; c++) {
-                            base[c] = O.q[c] + (row0 * 2 + tid);
-                            at[c] = (uint32_t)(((uint64_t)c * passes) / 5);
-                        }
-                        for (uint32_t p = 0; p < passes; p++) {
-#pragma unroll
-                            for (int c = 0; c < 5; c++) {
-                                const uint32_t off = at[c] * LS;
-                                if (off + tid < total_rows * 2) store16(base[c] + off, v[c]);
-                                at[c] = at[c] + 1 == passes ? 0 : at[c] + 1;
-                            }
-                        }
-#else
-                        uint4 *dst[5];
-#pragma unroll
-                        for (int c = 0; c < 5; c++) dst[c] = O.q[c] + (row0 * 2 + tid);
-                        for (uint32_t idx = tid; idx < total_rows * 2; idx += LS) {
-#pragma unroll
-                            for (int c = 0; c < 5; c++) {
-                                store16(dst[c], v[c]);
-                                dst[c] += LS;
-                            }
-                        }
-#endif
-                    }
-                    // wires: two rows per lane; a pass of LW lanes covers 2 LW / R whole items
-                    constexpr uint32_t LW = periodic_wire_lanes(R), IPW = 2 * LW / R;
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        uint64_t *col = O.w[c] + row0;
-                        const uint32_t shift = (uint32_t)((reinterpret_cast<uintptr_t>(col) >> 3) & 1);
-                        if (tid < LW) {
-                            uint64_t wbase[2], slope[2];
-#pragma unroll
-                            for (int k = 0; k < 2; k++) {
-                                const int32_t r = (int32_t)(2 * tid + k) - (int32_t)shift;
-                                const uint32_t rr = r < 0 ? 0u : (uint32_t)r, it = rr / R, j = rr - it * R;
-                                const uint64_t vb = O.var_base + var0 + (uint64_t)it * VV;
-                                uint64_t a[3], b[3];
-                                GD::wires(A, O, s_item[0], w0 + it, vb, j, a);
-                                GD::wires(A, O, s_item[0], w0 + it, vb + 1, j, b);
-                                wbase[k] = a[c];
-                                slope[k] = b[c] - a[c];  // 1: a Variable of the item; 0: a constant (zero_var)
-                            }
-                            const uint64_t step = (uint64_t)IPW * VV;
-                            uint64_t adv = 0;
-                            for (int64_t r0 = (int64_t)2 * tid - shift; r0 < (int64_t)total_rows; r0 += 2 * LW, adv += step) {
-                                const uint64_t v0 = wbase[0] + slope[0] * adv, v1 = wbase[1] + slope[1] * adv;
-                                if (r0 >= 0 && r0 + 1 < (int64_t)total_rows) {
-                                    store16(reinterpret_cast<uint4 *>(col + r0),
-                                            make_uint4((uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32)));
-                                } else {
-                                    if (r0 >= 0) col[r0] = v0;
-                                    if (r0 + 1 < (int64_t)total_rows) col[r0 + 1] = v1;
-                                }
-                            }
-                        }
-                    }
-                }
-                lds_barrier();  // item records visible
-                if constexpr (kVars) {
-                    // variables: lane = (item, slot); IPV whole items per pass
-                    constexpr uint32_t IPV = kThreads / VV, LV = IPV * VV;
-                    if (tid < LV) {
-                        const uint32_t it0 = tid / VV, k = tid - it0 * VV;
-                        const bool is_inv = GD::is_inv_slot(A, s_item[0], k);
-                        uint4 *dst = O.vars + (var0 + tid) * 2;
-                        // EMIT_ALL: the inverse slots are the pre-pass's, written in place.  EMIT_VARS (split gadgets): the item
-                        // phase has fetched the item's inverses from the pre-pass's compact output into its record, and this
-                        // launch writes every slot -- whole lines
-                        if (MODE == EMIT_VARS || !is_inv) {
-                            for (uint32_t it = it0; it < Wt; it += IPV, dst += 2 * LV) {
-                                FrVec val;
-                                val.f = GD::var_value_full(A, s_item[it], s_table, k);  // k is the lane's for the whole tile
-#if defined(PG_ABLATE_VAR_STORES)  // timing-only build (wrong output): the sweep without its stores
-                                if (val.v[0].x == 0x12345678u && val.v[1].y == 0x9abcdef0u) store16(dst, val.v[0]);
-#else
-                                store16(dst, val.v[0]);
-                                store16(dst + 1, val.v[1]);
-#endif
-                            }
-                        }
-                    }
-                }
-                lds_barrier();  // records and offsets are rewritten by the next tile
-                continue;
-            }
-        }
-#endif
-
-        if constexpr (kRows) {
+        {
             // ---- selector sweep: 16 B per lane, 128 rows x 5 columns per pass ---
             {
                 const uint32_t total = total_rows * 2;
@@ -527,7 +408,7 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                     k = uni_vars ? s - it * kUniV : s - s_voff[it];
                 }
                 uint4 *dst = O.vars + (var0 + s) * 2;
-                if (MODE == EMIT_VARS || !GD::is_inv_slot(A, s_item[it], k)) {  // (see the periodic sweep)
+                if (!GD::is_inv_slot(A, s_item[it], k)) {  // the pre-pass's, written in place
                     FrVec val;
                     val.f = GD::var_value(A, s_item[it], s_table, k);
                     store16(dst, val.v[0]);
@@ -543,67 +424,108 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
     }
 }
 
-// ---- the variable table of a split gadget, as an image -------------------------------------------------------------------
-// The variables of a tile's items are ONE contiguous piece of the table (whatever the items' shapes: the prefix sums say
-// where each item starts).  A workgroup builds that piece in LDS exactly as it will lie in memory -- the kImageParts lanes
-// of an item share its slots out between them (GD::image_load / image_build: lanes of one part are consecutive, so the Montgomery
-// multiplication is a few half-waves', the copies of inputs the others') -- and then copies it out linearly, 16 bytes
-// per lane: every wave store is one contiguous KiB, and the copy loop has no index arithmetic at all.  Against the
-// EMIT_VARS launch of emit_kernel (a 32-byte slot per lane as two half-line stores, the slot's value selected from a
-// per-item record on every pass, the constant table filled once per workgroup for a workgroup that lives for one tile).
-template <class GD, class = void>
-struct VarsImage {
-    static constexpr bool ok = false;
-};
-template <class GD>
-struct VarsImage<GD, std::void_t<decltype(GD::kImageW)>> {
-    static constexpr bool ok = true;
-};
-
-// (asked for 5 waves per SIMD -- as many workgroups per CU as the 30 KB images allow -- the compiler takes 80 registers
-// instead of 122: no difference on the step, 0.590 vs 0.581 ms with the A/B order rotated)
-#ifndef PG_IMAGE_WAVES_PER_SIMD
-#define PG_IMAGE_WAVES_PER_SIMD 1
+// ---- the rows of a periodic gadget's full-shape tiles ----------------------------------------------------------------
+// In a tile whose items all have the gadget's full shape (GD::kPeriodic: ragged gadgets with small items), selectors depend
+// on the row-within-item alone and wires are `constant` or `item's first variable + constant`.  The sweeps use a lane
+// count that is a multiple of the item size, so that a lane meets the SAME row-within-item on every pass: selector values
+// are computed once per workgroup, wire offsets once per tile, and the loops are bare stores (the generic sweeps spend
+// ~30 vector + ~20 scalar instructions per 16-byte store on finding the item, the row and the constants again).  The
+// launch is a pure store stream: no item phase, no per-item record, 128 bytes of LDS (the constants), and few enough
+// registers to keep its residency beside the fat waves of the gadget's inverting launch, which it shares the chip with.
+// Tiles that hold an item of another shape (is_non_zero stopped at its error, scalar.rs:79) are left to
+// emit_kernel<GD, EMIT_ROWS>, which skips the ones written here: both read the shape off the call's prefix sums.
+#ifndef PG_ROWS_WAVES_PER_SIMD
+#define PG_ROWS_WAVES_PER_SIMD 8
 #endif
 template <class GD>
-__global__ __launch_bounds__(GD::kImageW * GD::kImageParts, PG_IMAGE_WAVES_PER_SIMD) void vars_image_kernel(const typename GD::Args A, const EmitOut O) {
-    constexpr int W = GD::kImageW;
-    constexpr uint32_t kLanes = W * GD::kImageParts;
-    __shared__ uint4 s_img[W * GD::kUniformVars * 2];
-    const uint32_t tid = threadIdx.x, it = tid % W, part = tid / W;
-    // Resident workgroups stride over the tiles, and a tile's reads (its offsets, the part's one or two scalars per lane)
-    // are in flight, in registers, while the tile before it is built and stored: a workgroup that lives for one tile spends
-    // 72 % of its cycles waiting for that round trip (profiles/r02g_c3_prepass_counters.json); -2.2 % / -3.5 % on the
-    // fused mix's step.
-    struct Tile {
-        typename GD::ImageLoads L;
-        uint64_t v0, v1, mine, next;
-    };
-    auto fetch = [&](uint32_t tile, Tile &t) {
-        const uint64_t w0 = (uint64_t)tile * W;
-        const uint32_t Wt = (uint32_t)((O.batch - w0) < (uint64_t)W ? (O.batch - w0) : (uint64_t)W);
-        const uint32_t i = it < Wt ? it : Wt - 1;  // lanes past the end re-read the last item (not used)
-        t.v0 = O.var_off[w0];
-        t.v1 = O.var_off[w0 + Wt];
-        t.mine = O.var_off[w0 + i];
-        t.next = O.var_off[w0 + i + 1];
-        GD::image_load(A, O, w0 + i, part, t.L);
-    };
-    Tile cur, nxt;
-    if (blockIdx.x < O.tiles) fetch(blockIdx.x, cur);
+__global__ __launch_bounds__(kThreads, PG_ROWS_WAVES_PER_SIMD) void rows_periodic_kernel(const typename GD::Args A, const EmitOut O) {
+    constexpr int W = GD::kRowsW;
+    constexpr uint32_t R = GD::kUniformRows, VV = GD::kUniformVars;
+    __shared__ uint4 s_table[T_POW * 2];
+    const uint32_t tid = threadIdx.x;
+#if defined(PG_ROWS_SETPRIO)
+    __builtin_amdgcn_s_setprio(PG_ROWS_SETPRIO);
+#endif
+    fill_common_table(s_table, nullptr, tid, T_POW);
+    GD::fill_table(A, s_table, tid);
+    lds_barrier();
+    typename GD::RowRec full{};  // the shape record of a full item
+
+    // selectors: lanes 2r, 2r+1 hold the halves of row r; IPP whole items per pass.  What a lane stores is the same on
+    // every pass of every tile
+    constexpr uint32_t IPP = (kThreads / 2) / R, LS = IPP * R * 2;
+    uint4 v[5];
+    {
+        const uint32_t rl = (tid < LS ? tid : 0) >> 1;
+        GD::selectors(A, full, rl - (rl / R) * R, s_table, tid & 1, v);
+    }
+    constexpr uint32_t LW = periodic_wire_lanes(R), IPW = 2 * LW / R;  // wires: two rows per lane, IPW whole items per pass
+
     for (uint32_t tile = blockIdx.x; tile < O.tiles; tile += gridDim.x) {
         const uint64_t w0 = (uint64_t)tile * W;
         const uint32_t Wt = (uint32_t)((O.batch - w0) < (uint64_t)W ? (O.batch - w0) : (uint64_t)W);
-        const bool more = tile + gridDim.x < O.tiles;
-        if (more) fetch(tile + gridDim.x, nxt);
-        if (it < Wt)
-            GD::image_build(A, w0 + it, part, (uint32_t)(cur.next - cur.mine), s_img + (cur.mine - cur.v0) * 2, O.var_base + cur.mine, cur.L);
-        lds_barrier();
-        const uint32_t n16 = (uint32_t)(cur.v1 - cur.v0) * 2;
-        uint4 *dst = O.vars + cur.v0 * 2;
-        for (uint32_t o = tid; o < n16; o += kLanes) store16(dst + o, s_img[o]);
-        lds_barrier();  // the image is rewritten by the next tile
-        if (more) cur = nxt;
+        // (the three offsets are the same for every lane, but the compiler cannot load them through the scalar cache -- the
+        // columns' stores might alias them -- and would make the wire sweep wait for them behind EVERY selector store of the
+        // tile: vmcnt counts loads and stores alike.  Made scalar here, they are waited for before the first store.)
+        const uint64_t row0 = uniform64(O.row_off[w0]), var0 = uniform64(O.var_off[w0]), row1 = uniform64(O.row_off[w0 + Wt]);
+        const uint32_t total_rows = Wt * R;
+        if (row1 - row0 != total_rows) continue;  // an item of another shape: the generic launch's tile
+
+        if (tid < LS) {
+            // A lane's five stores of one pass would go to the same row of five arrays of the same size: whether those five
+            // addresses fall on the same memory channel is then decided by the arrays' base addresses, once, for the whole
+            // call (up to 25 % between placements of the same columns, profiles/NOTES_r02.md).  The values of a lane do not
+            // depend on the pass, so column c starts c fifths of the tile further on and wraps: the five streams are that far
+            // apart in their arrays, by an amount that is not a power of two (-3 % on the fused mix's step).
+            const uint32_t passes = (total_rows * 2 + LS - 1) / LS;
+            uint4 *base[5];
+            uint32_t at[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                base[c] = O.q[c] + (row0 * 2 + tid);
+                at[c] = (uint32_t)(((uint64_t)c * passes) / 5);
+            }
+            for (uint32_t p = 0; p < passes; p++) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    const uint32_t off = at[c] * LS;
+                    if (off + tid < total_rows * 2) store16(base[c] + off, v[c]);
+                    at[c] = at[c] + 1 == passes ? 0 : at[c] + 1;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            uint64_t *col = O.w[c] + row0;
+            // pair rows so that every pair starts on a 16-byte boundary
+            const uint32_t shift = (uint32_t)((reinterpret_cast<uintptr_t>(col) >> 3) & 1);
+            if (tid < LW) {
+                uint64_t wbase[2], slope[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int32_t r = (int32_t)(2 * tid + k) - (int32_t)shift;
+                    const uint32_t rr = r < 0 ? 0u : (uint32_t)r, it = rr / R, j = rr - it * R;
+                    const uint64_t vb = O.var_base + var0 + (uint64_t)it * VV;
+                    uint64_t a[3], b[3];
+                    GD::wires(A, O, full, w0 + it, vb, j, a);
+                    GD::wires(A, O, full, w0 + it, vb + 1, j, b);
+                    wbase[k] = a[c];
+                    slope[k] = b[c] - a[c];  // 1: a Variable of the item; 0: a constant (zero_var)
+                }
+                const uint64_t step = (uint64_t)IPW * VV;
+                uint64_t adv = 0;
+                for (int64_t r0 = (int64_t)2 * tid - shift; r0 < (int64_t)total_rows; r0 += 2 * LW, adv += step) {
+                    const uint64_t v0 = wbase[0] + slope[0] * adv, v1 = wbase[1] + slope[1] * adv;
+                    if (r0 >= 0 && r0 + 1 < (int64_t)total_rows) {
+                        store16(reinterpret_cast<uint4 *>(col + r0),
+                                make_uint4((uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32)));
+                    } else {
+                        if (r0 >= 0) col[r0] = v0;
+                        if (r0 + 1 < (int64_t)total_rows) col[r0 + 1] = v1;
+                    }
+                }
+            }
+        }
     }
 }
 

@@ -52,11 +52,9 @@ __device__ __forceinline__ void inv_locate(uint64_t s, uint64_t batch, uint64_t 
 // The split is what lets a lane have a whole group's loads in flight at once: every load of the group is issued
 // unconditionally (out-of-range lanes re-read the call's last element and are masked later) before the first
 // dependent instruction.
-// compact != NULL (split gadgets): the inverses go to compact[e * batch + item] -- whole coalesced lines; the gadget's
-// variable-table launch copies them into place -- instead of their (scattered, 32-byte) slots in the variable table
 template <class GD, int GRP>
 __global__ __launch_bounds__(kThreads) void batch_invert_kernel(const typename GD::Args A, const EmitOut O, uint64_t n_elems,
-                                                               uint32_t groups, uint4 *scratch, uint4 *compact) {
+                                                               uint32_t groups, uint4 *scratch) {
     static_assert(GRP % 2 == 0, "the unwind works on half groups");
     constexpr int HB = GRP / 2;  // the unwind's group: x AND its prefix are live, twice (current + prefetched)
     const uint64_t T = (uint64_t)gridDim.x * kThreads;
@@ -152,7 +150,7 @@ __global__ __launch_bounds__(kThreads) void batch_invert_kernel(const typename G
             uint64_t item;
             uint32_t e;
             inv_locate<GD::kInv>(s, batch, item, e);
-            uint4 *slot = compact ? compact + 2 * s : GD::inv_slot(A, O, item, e);  // s == e * batch + item
+            uint4 *slot = GD::inv_slot(A, O, item, e);
             if (slot) {
                 slot[0] = o.v[0];
                 slot[1] = o.v[1];

@@ -259,207 +259,372 @@ struct ScalarMixArgs {
     uint64_t *result_vars;  // [batch][2]: select_one's output, maybe_equal's output
 };
 
+// The mix is a split gadget (emit.hpp): its ROWS depend on one bit per item (did is_non_zero stop at its error,
+// scalar.rs:79) and are written by the two rows launches; its VARIABLES by scalar_mix_vars_kernel below.  This policy
+// class is the rows' view.
 struct ScalarMixGD {
     using Args = ScalarMixArgs;
-    // what the item's lane computes once: the five inputs and the four derived values that are not constants (the
-    // variable sweep is then an LDS -> HBM copy: a wave that met one slot needing arithmetic would pay it for all 64
-    // lanes).  Kept to 368 bytes: the records bound how many workgroups share a CU, and the variable-table launch lives
-    // on that overlap (6 per CU instead of 4 with one slot per variable).
-    struct alignas(16) ItemRec {
-        Fr d[11];  // v y s a b | sy oms out | u | v^-1 (a-b)^-1  (the inverses: read back from the pre-pass's compact output)
-        uint32_t err, yeq, pad[2];
-    };
-#ifndef PG_MIX_W
-#define PG_MIX_W 64
-#endif
-    static constexpr int W = PG_MIX_W;
-    static constexpr int kInv = 2;
-    static constexpr int kInvGroup = PG_INV_GRP;
-    // element 0: v (is_non_zero, scalar.rs:73); element 1: a - b (maybe_equal, scalar.rs:121) -- pointers selected, not branches
-    __device__ static void inv_operands(const Args &A, const EmitOut &, uint64_t item, uint32_t e, FrVec &p, FrVec &q, uint32_t &) {
-        const uint4 *pp = e ? A.a : A.v, *qp = e ? A.b : A.v;
-        p.f = load_fr(pp, item);
-        q.f = load_fr(qp, item);
-    }
-    __device__ static Fr inv_combine(const Args &, uint32_t e, const Fr &p, const Fr &q, uint32_t) {
-        const Fr d = fr_sub(p, q);
-        Fr r;
-#pragma unroll
-        for (int i = 0; i < 4; i++) r.l[i] = e ? d.l[i] : p.l[i];
-        return r;
-    }
-    // item variables: [v y s a b | va inv one | one' sy oms out | u z yeq]; an item with v = 0 has no inv / one
-    __device__ static uint4 *inv_slot(const Args &A, const EmitOut &O, uint64_t item, uint32_t e) {
-        const bool err = fr_is_zero(load_fr(A.v, item));
-        if (e == 0) return err ? nullptr : O.vars + 2 * (O.var_off[item] + 6);
-        return O.vars + 2 * (O.var_off[item] + 5 + (err ? 1 : 3) + 4 + 1);
-    }
-    __device__ static bool is_inv_slot(const Args &, const ItemRec &R, uint32_t k) {
-        const uint32_t nz = R.err ? 1 : 3;
-        return (!R.err && k == 6) || k == 5 + nz + 4 + 1;
-    }
-    static constexpr bool kRagged = true, kRecInRows = true, kUsePow2 = false;
-    static constexpr uint32_t kUniformRows = 10, kUniformVars = 15;  // an item whose v is not 0
-    // full-shape items: selectors are a function of the row, wires are the item's own variables (+ zero_var)
-    static constexpr bool kPeriodic = true;
-    // emitted as two launches (emit.hpp, EmitMode): the rows -- which depend on one bit per item -- as a lean store-only
-    // launch over tiles of kRowsW items, then the variable table
-    static constexpr bool kSplit = true;
-    static constexpr int kRowsW = 256;
     struct RowRec {
         uint32_t err;
     };
+    using ItemRec = RowRec;
+    static constexpr int W = 256, kRowsW = 256;
+    static constexpr bool kRagged = true, kRecInRows = true, kUsePow2 = false;
+    static constexpr uint32_t kUniformRows = 10, kUniformVars = 15;  // an item whose v is not 0
+    static constexpr bool kPeriodic = true, kSplit = true;
     __device__ static void fill_table(const Args &, uint4 *, uint32_t) {}
-    // the rows of an item depend on one bit: did is_non_zero stop at its error (scalar.rs:79)?
-    template <class R>
-    __device__ static void item_rows(const Args &A, const EmitOut &, uint64_t item, const uint4 *, R &rec) {
-        rec.err = fr_is_zero(load_fr(A.v, item)) ? 1u : 0u;
+    // the shape of an item, read off the call's prefix sums (the plan made them from v = 0, scalar.rs:73)
+    __device__ static void item_rows(const Args &, const EmitOut &O, uint64_t item, const uint4 *, RowRec &rec) {
+        rec.err = O.row_off[item + 1] - O.row_off[item] != kUniformRows ? 1u : 0u;
     }
-    // what an item's lane reads from memory, apart from the arithmetic on it
-    struct Loads {
-        Fr v, y, s, a, b, inv0, inv1;
-        uint64_t var_off;
-    };
-    __device__ static void item_load(const Args &A, const EmitOut &O, uint64_t item, Loads &L) {
-        L.v = load_fr(A.v, item);
-        L.y = load_fr(A.y, item);
-        L.s = load_fr(A.s, item);
-        L.a = load_fr(A.a, item);
-        L.b = load_fr(A.b, item);
-        L.var_off = O.var_off[item];
-        // the item's two inverses, if the pre-pass has run (the variables-only launch of the split): element e of item i
-        // sits at [e * batch + i] of its compact output
-        const uint4 *inv = O.inv ? O.inv : A.v;  // (no pre-pass output: any readable address, the values are not used)
-        L.inv0 = load_fr(inv, O.inv ? item : 0);
-        L.inv1 = load_fr(inv, O.inv ? O.batch + item : 0);
-    }
-    __device__ static void item_from(const Args &A, const EmitOut &O, uint64_t item, ItemRec &R, const Loads &L) {
-        const uint32_t err = fr_is_zero(L.v) ? 1u : 0u;
-        R.err = err;  // what item_rows writes when there are rows to emit; a variables-only launch has no item_rows
-        R.d[0] = L.v; R.d[1] = L.y; R.d[2] = L.s; R.d[3] = L.a; R.d[4] = L.b;  // 5 x add_input (and var_assigned = v, scalar.rs:69)
-        const Fr sy = fr_mul(L.y, L.s), oms = fr_sub(fr_one(), L.s);
-        R.d[5] = sy;                                                  // scalar.rs:43
-        R.d[6] = oms;                                                 // scalar.rs:45-50
-        R.d[7] = fr_add(sy, oms);                                     // scalar.rs:53-58
-        const Fr u = fr_sub(L.a, L.b);
-        R.d[8] = u;                                                   // scalar.rs:111-117
-        R.d[9] = L.inv0;                                              // scalar.rs:77 (0 for an item that stopped at its error: never stored)
-        R.d[10] = L.inv1;                                             // scalar.rs:122-123
-        R.yeq = fr_is_zero(u) ? 1u : 0u;                              // y = 1 - u z, scalar.rs:126
-        if (A.result_vars) {
-            const uint64_t vb = O.var_base + L.var_off;
-            const uint64_t nz = err ? 1 : 3;
-            A.result_vars[2 * item] = vb + 5 + nz + 3;
-            A.result_vars[2 * item + 1] = vb + 5 + nz + 4 + 2;
-        }
-    }
-    __device__ static void item(const Args &A, const EmitOut &O, uint64_t item, const uint4 *, ItemRec &R) {
-        Loads L;
-        item_load(A, O, item, L);
-        // every load of the item (and the tile's offsets, issued just before) is in flight before the first use: left to
-        // itself the scheduler interleaves the record's LDS writes with the loads and the ten loads leave in three
-        // batches, each waited for -- three global round trips where one will do, in a workgroup that lives for little else
-        __builtin_amdgcn_sched_barrier(0);
-        item_from(A, O, item, R, L);
-    }
-    template <class R_>
-    __device__ static void row(const R_ &R, uint64_t vbase, uint64_t zero_var, uint32_t j, RowOut &r) {
+    // item variables: [v y s a b | va inv one | one' sy oms out | u z yeq]; an item with v = 0 has no inv / one
+    __device__ static void row(const RowRec &R, uint64_t vbase, uint64_t zero_var, uint32_t j, RowOut &r) {
         const uint32_t nz = R.err ? 1 : 3;
         if (j < nz) is_non_zero_row(j, vbase + 0, vbase + 5, zero_var, r);
         else if (j < nz + 4) select_one_row(j - nz, vbase + 1, vbase + 2, vbase + 5 + nz, r);
         else maybe_equal_row(j - nz - 4, vbase + 3, vbase + 4, vbase + 5 + nz + 4, r);
     }
-    template <class R_>
-    __device__ static void selectors(const Args &, const R_ &R, uint32_t j, const uint4 *table, uint32_t h, uint4 out[5]) {
+    __device__ static void selectors(const Args &, const RowRec &R, uint32_t j, const uint4 *table, uint32_t h, uint4 out[5]) {
         RowOut r;
         row(R, 0, 0, j, r);
         row_values(r, table, h, out);
     }
-    template <class R_>
-    __device__ static void wires(const Args &, const EmitOut &O, const R_ &R, uint64_t, uint64_t vbase, uint32_t j,
+    __device__ static void wires(const Args &, const EmitOut &O, const RowRec &R, uint64_t, uint64_t vbase, uint32_t j,
                                  uint64_t out[3]) {
         RowOut r;
         row(R, vbase, O.zero_var, j, r);
         out[0] = r.w[0]; out[1] = r.w[1]; out[2] = r.w[2];
     }
-    // the variable table as an image (emit.hpp, vars_image_kernel): the item's slots, shared out over four waves.  `img` is
-    // where the item's first variable lies in the tile's image, `nvars` how many it has (13: it stopped at its error and
-    // has no inv / one), `vb` its first Variable.
-#ifndef PG_IMAGE_W
-#define PG_IMAGE_W 64
-#endif
-    static constexpr int kImageW = PG_IMAGE_W, kImageParts = 4;
-    __device__ static void put(uint4 *img, uint32_t slot, const Fr &x) {
-        FrVec t;
-        t.f = x;
-        img[2 * slot] = t.v[0];
-        img[2 * slot + 1] = t.v[1];
-    }
-    // what a part's lane reads from memory (image_load: loads only, so that a tile's reads can be in flight while the
-    // tile before it is built and stored) and what it makes of it (image_build)
-    struct ImageLoads {
-        Fr f0, f1;
-    };
-    __device__ static void image_load(const Args &A, const EmitOut &O, uint64_t item, uint32_t part, ImageLoads &L) {
-        if (part == 0) {
-            L.f0 = load_fr(A.v, item);
-            L.f1 = L.f0;
-        } else if (part == 1) {
-            L.f0 = load_fr(A.y, item);
-            L.f1 = load_fr(A.s, item);
-        } else if (part == 2) {
-            L.f0 = load_fr(A.a, item);
-            L.f1 = load_fr(A.b, item);
-        } else {  // the two inverses, from the pre-pass's compact output: element e of item i at [e * batch + i]
-            L.f0 = load_fr(O.inv, item);
-            L.f1 = load_fr(O.inv, O.batch + item);
-        }
-    }
-    __device__ static void image_build(const Args &A, uint64_t item, uint32_t part, uint32_t nvars, uint4 *img, uint64_t vb,
-                                       const ImageLoads &L) {
-        const bool err = nvars != kUniformVars;
-        const uint32_t tail = err ? 6 : 8;  // one' sy oms out | u z yeq
-        if (part == 0) {  // v, var_assigned = v (scalar.rs:69), the two constants (scalar.rs:83, :41), the results' Variables
-            put(img, 0, L.f0);
-            put(img, 5, L.f0);
-            if (!err) put(img, 7, fr_one());
-            put(img, tail, fr_one());
-            if (A.result_vars) {
-                A.result_vars[2 * item] = vb + tail + 3;
-                A.result_vars[2 * item + 1] = vb + tail + 6;
-            }
-        } else if (part == 1) {  // y, s and select_one's three values
-            put(img, 1, L.f0);
-            put(img, 2, L.f1);
-            const Fr sy = fr_mul(L.f0, L.f1), oms = fr_sub(fr_one(), L.f1);  // scalar.rs:43, :45-50
-            put(img, tail + 1, sy);
-            put(img, tail + 2, oms);
-            put(img, tail + 3, fr_add(sy, oms));                              // scalar.rs:53-58
-        } else if (part == 2) {  // a, b and maybe_equal's difference and result
-            put(img, 3, L.f0);
-            put(img, 4, L.f1);
-            const Fr u = fr_sub(L.f0, L.f1);                                  // scalar.rs:111-117
-            put(img, tail + 4, u);
-            put(img, tail + 6, fr_is_zero(u) ? fr_one() : fr_zero());         // y = 1 - u z, scalar.rs:126
-        } else {
-            if (!err) put(img, 6, L.f0);                                      // scalar.rs:77
-            put(img, tail + 5, L.f1);                                         // scalar.rs:122-123 (0 when a = b)
-        }
-    }
-    // variable kc of a full-shape item: [v y s a b | va inv one | one' sy oms out | u z yeq]
-    __device__ static Fr var_value_full(const Args &, const ItemRec &R, const uint4 *, uint32_t kc) {
-        if (kc < 5) return R.d[kc];
-        if (kc == 5) return R.d[0];                          // var_assigned
-        if (kc == 7 || kc == 8) return fr_one();             // scalar.rs:83, :41
-        if (kc >= 9 && kc <= 12) return R.d[kc - 4];         // sy oms out u
-        if (kc == 14) return R.yeq ? fr_one() : fr_zero();
-        return R.d[kc == 6 ? 9 : 10];                        // 6: v^-1, 13: (a - b)^-1 (asked for by the variables-only launch)
-    }
-    // an item that stopped at its error has no inv / one: its variables 6.. are the full shape's 8..
-    __device__ static Fr var_value(const Args &A, const ItemRec &R, const uint4 *t, uint32_t k) {
-        return var_value_full(A, R, t, (R.err && k >= 6) ? k + 2 : k);
-    }
 };
+
+// ---- the mix's variable table: inversion and writing in ONE launch ---------------------------------------------------
+// Every item needs two inverses (v^-1 for is_non_zero, scalar.rs:73-77; (a - b)^-1 for maybe_equal, scalar.rs:121-123) and
+// 15 (13) variables that are its inputs, those inverses and three cheap values.  A WAVE owns 32 * ipl consecutive items
+// and works on 32 of them per step, TWO LANES PER ITEM: lane p < 32 has the item's v side (v, y, s; the chain of the v's),
+// lane 32 + p its a - b side (a, b; the chain of the differences).  Every lane runs Montgomery's trick on its own chain of
+// ipl elements without the elements or their inverses ever leaving the lane:
+//   forward  step m: load the element; the lane's running product BEFORE it goes to `scratch` (32 bytes per element: the
+//            one thing that is parked in memory); multiply the element in (zeros are skipped and keep a zero inverse,
+//            unwrap_or(zero), scalar.rs:122)
+//   one inversion per lane (fr_invert_or_zero)
+//   backward step m: load the element again with the rest of the item's inputs and the parked product; two multiplications
+//            give the inverse and move the running inverse on, one more (v side) gives y * s; between them the two lanes now
+//            hold ALL of the item's variables
+//   the wave lays the variables of its 32 items out in a private LDS image exactly as they lie in memory (ragged: an item
+//   that stopped at its error has 13; ballots give every lane its item's offset), and copies the image out linearly -- 16
+//   bytes per lane, every wave store one contiguous KiB.
+// Waves never wait for each other: no barrier, no LDS shared between waves.  Two lanes per item is what keeps the
+// registers down (a lane carries half an item and its prefetch): the launch has to leave room on every SIMD for the rows
+// launch's waves, which run beside it (capi.hip, launch_mix) -- with one lane per item (230 registers, two waves per SIMD)
+// not one rows wave fitted and the two launches simply ran one after the other.  Inputs are read once per pass, the parked
+// products are 64 B per item each way: against the three-launch form this replaces (pre-pass with 128 B per element of
+// scratch traffic, a compact inverse array, a variable-table launch that read all five inputs again) the step's reads fell
+// from 3.5 x the inputs to 2 x and nothing waits for a pre-pass any more.  Geometry: ipl = 16 at 2^20 items = 2048 waves =
+// two per SIMD, which is what the multiplier needs (one wave alone issues every other cycle).
+constexpr uint32_t kMixMaxIpl = 32;  // steps per wave at most (beyond: more workgroups than fit at once)
+
+__device__ __forceinline__ void mix_load16(FrVec &d, const uint4 *col, uint64_t i) {
+    d.v[0] = col[2 * i];
+    d.v[1] = col[2 * i + 1];
+}
+__device__ __forceinline__ Fr fr_select(bool c, const Fr &a, const Fr &b) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    return r;
+}
+__device__ __forceinline__ void mix_put(uint4 *img, uint32_t slot, const Fr &x) {
+    FrVec t;
+    t.f = x;
+    img[2 * slot] = t.v[0];
+    img[2 * slot + 1] = t.v[1];
+}
+
+#ifndef PG_MIX_VARS_VGPRS
+#define PG_MIX_VARS_VGPRS 256  // two waves per SIMD (the 15 KB images allow no more)
+#endif
+// A note on waiting.  gfx950 counts a wave's loads AND stores in one counter (vmcnt), in issue order: "wait for the data
+// I prefetched a step ago" also waits for every store issued before that prefetch, and -- unless the number of stores
+// issued since is a compile-time constant -- for those as well.  Beside the rows launch, which keeps the memory system's
+// write queues full, an acknowledged store is tens of microseconds away; a step that waits for its own last stores
+// crawls (this launch: 250 us alone, 370-580 us beside the rows, before).  So every step issues a FIXED number of memory
+// instructions, none of them under a lane mask the compiler would branch around (a lane with nothing to store stores to
+// `sink`, 16 bytes per lane that nobody reads), and the loops are entered with nothing in flight: the compiler can then
+// count, and waits for a step's prefetch with the step's stores still on their way (s_waitcnt vmcnt(17), not 0).
+//
+// PLAN: the launch also makes the call's prefix sums (pg_scalar_mix_planned_batch), which are nothing but the count of
+// items with v = 0 before each item: rows before item i = 10 i - 2 e_i, variables 15 i - 2 e_i.  A wave counts its own in
+// the forward pass, publishes the count and adds up its predecessors' -- the single-pass scan of the plan kernels
+// (emit.hpp, plan_finish: one 64-bit word per wave that carries the count and two flag bits, touched by relaxed atomics
+// only; a wave waits for waves of lower index, which were dispatched before it; every wait is bounded; the last wave to
+// finish zeroes the words) -- while nothing else needs the result: it is first used in the backward pass, an inversion
+// later.  The offsets are written beside the variables, the totals by the wave that owns the last item.
+struct MixPlan {
+    unsigned long long *agg;      // per wave: flags | count of failing items (zero between launches); [cap] = waves done
+    uint64_t *row_off, *var_off;  // the call's outputs, batch + 1 entries each
+    uint8_t *err_mask;            // per item: it stopped at is_non_zero's error (optional)
+    PlanTotals *host;
+    uint32_t cap, nwaves;
+};
+
+#ifndef PG_MIX_WAVES
+#define PG_MIX_WAVES 8  // waves per workgroup = chains per inversion (8 x 15 KB of images: one workgroup per CU, two waves per SIMD)
+#endif
+constexpr int kMixWaves = PG_MIX_WAVES;
+
+template <bool PLAN>
+__global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_MIX_VARS_VGPRS))) void scalar_mix_vars_kernel(
+    const ScalarMixArgs A, const EmitOut O, uint32_t ipl, uint4 *scratch, uint4 *sink, const MixPlan P) {
+    __shared__ uint4 s_img[kMixWaves][32 * 15 * 2];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 31;
+    const bool bside = lane >= 32;  // the a - b side of item p
+    const uint64_t gw = (uint64_t)blockIdx.x * kMixWaves + wave;  // the wave's index in the launch
+    const uint64_t chunk0 = gw * 32 * ipl;                         // the wave's first item
+    // (the launch's last workgroup may hold waves without items: they take no step, but stand at the two barriers)
+    if (chunk0 >= O.batch) ipl = 0;
+    const uint64_t last = O.batch - 1;
+    uint4 *img = s_img[wave];
+    // (a lane's loads are unconditional: where a side has nothing to read it re-reads what it has -- a cache hit)
+    const uint4 *in0 = bside ? A.a : A.v, *in1 = bside ? A.b : A.y, *in2 = bside ? A.b : A.s, *fw1 = bside ? A.b : A.v;
+    uint4 *park = scratch + (bside ? O.batch : 0);  // [2][2][batch] 16-byte halves: a half-wave's store is 512 contiguous bytes
+    sink += lane;
+
+    // ---- forward: running products ------------------------------------------------------------------------------
+    Fr acc = fr_one();
+    uint32_t errs = 0;  // PLAN: the wave's items with v = 0
+    {
+        FrVec c0, c1, n0, n1;
+        auto fetch = [&](uint32_t m, FrVec &d0, FrVec &d1) {
+            uint64_t i = chunk0 + (uint64_t)m * 32 + p;
+            i = i < last ? i : last;  // lanes past the end re-read the last item (masked below)
+#if defined(PG_MIX_ABLATE_MEM)  // timing only (wrong output): the launch without its global loads and stores
+            d0.v[0] = d0.v[1] = d1.v[1] = make_uint4((uint32_t)i, m, 3, 4); d1.v[0] = make_uint4(m, 2, (uint32_t)i, 5);
+#else
+            mix_load16(d0, in0, i);
+            mix_load16(d1, fw1, i);
+#endif
+        };
+        if (ipl) fetch(0, c0, c1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (uint32_t m = 0; m < ipl; m++) {
+            fetch(m + 1 < ipl ? m + 1 : m, n0, n1);  // (the last step fetches itself again: a fixed count, see above)
+            const uint64_t i = chunk0 + (uint64_t)m * 32 + p;
+            const bool valid = i <= last;
+            {
+                FrVec t;
+                t.f = acc;
+#if !defined(PG_MIX_ABLATE_MEM)
+                store16(valid ? park + i : sink, t.v[0]);
+                store16(valid ? park + 2 * O.batch + i : sink, t.v[1]);
+#endif
+            }
+            const Fr x = bside ? fr_sub(c0.f, c1.f) : c0.f;  // scalar.rs:121 / :73
+            const bool nz = valid && !fr_is_zero(x);
+            if constexpr (PLAN) errs += (uint32_t)__popcll(__ballot(!bside && valid && !nz));  // scalar.rs:73-80
+            const Fr t = fr_mul(acc, x);
+            acc = fr_select(nz, t, acc);
+            c0 = n0;
+            c1 = n1;
+        }
+    }
+
+    // ---- PLAN: failing items in the waves before this one (decoupled look-back, 64 predecessors per round) -----------
+    uint64_t errs_before = 0;
+    if (PLAN && ipl) {
+        if (lane == 0 && gw > 0) __hip_atomic_exchange(&P.agg[gw], kAggA | errs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool gave_up = false;
+        int64_t back = (int64_t)gw - 1;
+        for (bool more = gw > 0; more; back -= 64) {
+            const int64_t j = back - (int64_t)lane;
+            unsigned long long w = kAggP;  // before wave 0: the empty prefix
+            if (j >= 0) {
+                w = plan_rmw_read(&P.agg[j]);
+                for (uint32_t polls = 0; !(w >> 62); w = plan_rmw_read(&P.agg[j])) {
+                    if (++polls > kPlanSpinLimit) { gave_up = true; w = kAggP; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            const uint64_t has_prefix = __ballot((w & kAggP) != 0);
+            const uint32_t first = has_prefix ? (uint32_t)__ffsll((unsigned long long)has_prefix) - 1 : 64u;  // the nearest one
+            errs_before += wave_sum(lane <= first ? w & 0xffffffffull : 0);
+            more = has_prefix == 0;
+        }
+        if (lane == 0) {
+            if (gave_up) P.host->pad = 1;
+            __hip_atomic_exchange(&P.agg[gw], kAggP | (errs_before + errs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gw + 1 == P.nwaves) {  // the wave of the last item: the totals
+                const uint64_t e_all = errs_before + errs;
+                P.row_off[O.batch] = 10 * O.batch - 2 * e_all;
+                P.var_off[O.batch] = 15 * O.batch - 2 * e_all;
+                P.host->n_gates = 10 * O.batch - 2 * e_all;
+                P.host->n_vars = 15 * O.batch - 2 * e_all;
+                P.host->errs = (uint32_t)e_all;
+            }
+        }
+    }
+
+    // ---- ONE inversion per workgroup ------------------------------------------------------------------------------
+    // The inversion is 20 k vector instructions against the 25 k of everything else a wave does here; a wave pays it
+    // whether one lane wants an inverse or sixty-four.  So the waves of a workgroup hand lane l's products to the first wave
+    // (through the LDS that will hold the images), which multiplies them up -- Montgomery's trick once more, across waves:
+    // running products from the left and from the right, 14 multiplications -- and inverts the product of all; every wave
+    // then takes its own inverse out with two multiplications.  While the first wave inverts the others wait at a
+    // barrier: seven idle waves cost nothing, eight inversions side by side cost eight times the energy.
+    Fr accinv;
+    {
+        uint4 *xch = &s_img[0][0];  // [kind][wave][half][lane]: 0 the waves' products, 1 products from the left, 2 from the right; then 1 / all
+        auto slot = [&](uint32_t kind, uint32_t w) { return xch + ((kind * kMixWaves + w) * 2) * 64 + lane; };
+        auto get = [&](uint32_t kind, uint32_t w) {
+            FrVec t;
+            t.v[0] = slot(kind, w)[0];
+            t.v[1] = slot(kind, w)[64];
+            return t.f;
+        };
+        auto set = [&](uint32_t kind, uint32_t w, const Fr &x) {
+            FrVec t;
+            t.f = x;
+            slot(kind, w)[0] = t.v[0];
+            slot(kind, w)[64] = t.v[1];
+        };
+        set(0, wave, acc);
+        __syncthreads();
+        if (wave == 0) {
+            Fr run = fr_one();
+#pragma unroll 1
+            for (uint32_t w = 0; w < kMixWaves; w++) {  // left[w] = product of the waves before w
+                set(1, w, run);
+                run = fr_mul(run, get(0, w));
+            }
+            const Fr all = run;
+            run = fr_one();
+#pragma unroll 1
+            for (uint32_t w = kMixWaves; w-- > 0;) {  // right[w] = product of the waves after w
+                set(2, w, run);
+                if (w) run = fr_mul(run, get(0, w));
+            }
+            set(3, 0, fr_invert_or_zero(all));  // (a product of non-zero elements, or mont(1))
+        }
+        __syncthreads();
+        accinv = fr_mul(fr_mul(get(3, 0), get(1, wave)), get(2, wave));
+        __syncthreads();  // the exchange area is the images' from here on
+    }
+
+    // ---- backward: inverses, the item's variables, the image ------------------------------------------------------
+    struct In {
+        FrVec f0, f1, f2, pk;  // v y s | a b -, the parked product
+        uint64_t base;
+    };
+    In c, n;
+    auto fetch = [&](uint32_t m, In &d) {
+        const uint64_t i0 = chunk0 + (uint64_t)m * 32;
+        uint64_t i = i0 + p;
+        i = i < last ? i : last;
+#if defined(PG_MIX_ABLATE_MEM)
+        d.f0.v[0] = d.f0.v[1] = d.f2.v[1] = make_uint4((uint32_t)i, m, 3, 4); d.f1.v[0] = d.f1.v[1] = d.f2.v[0] = make_uint4(m, 2, (uint32_t)i, 5);
+        d.pk.v[0] = d.pk.v[1] = make_uint4(7, m, (uint32_t)i, 4);
+        d.base = i0 * 15;
+#else
+        mix_load16(d.f0, in0, i);
+        mix_load16(d.f1, in1, i);
+        mix_load16(d.f2, in2, i);
+        d.pk.v[0] = park[i];
+        d.pk.v[1] = park[2 * O.batch + i];
+        if constexpr (!PLAN) d.base = O.var_off[i0 < O.batch ? i0 : O.batch];  // first variable of the step's 32 items, relative to the call
+#endif
+    };
+    if (ipl) fetch(ipl - 1, c);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (uint32_t mm = ipl; mm-- > 0;) {
+        fetch(mm > 0 ? mm - 1 : 0, n);  // (the last step fetches itself again)
+        const uint64_t i = chunk0 + (uint64_t)mm * 32 + p;
+        const bool valid = i <= last;
+        const Fr x = bside ? fr_sub(c.f0.f, c.f1.f) : c.f0.f;  // a - b (scalar.rs:111-117, :121) | v
+        const bool nz = valid && !fr_is_zero(x);
+        // which items stopped at is_non_zero's error (scalar.rs:79): the v sides know, the a - b sides need it for their slots
+        const uint32_t vmask = (uint32_t)__ballot(valid), emask = (uint32_t)__ballot(!bside && valid && !nz);
+        const uint32_t below = (1u << p) - 1;
+        const uint32_t off = 15u * (uint32_t)__popc(vmask & below) - 2u * (uint32_t)__popc(emask & below);
+        const uint32_t total = 15u * (uint32_t)__popc(vmask) - 2u * (uint32_t)__popc(emask);
+        const bool err = (emask >> p) & 1;
+        if constexpr (PLAN) {  // failing items before this step's = before the wave + in the wave's earlier steps
+            errs -= (uint32_t)__popc(emask);
+            const uint64_t eb = errs_before + errs, i0 = chunk0 + (uint64_t)mm * 32;
+            c.base = 15 * i0 - 2 * eb;
+            const uint64_t e_i = eb + (uint64_t)__popc(emask & below);  // ... and before this item
+            uint64_t *po = reinterpret_cast<uint64_t *>(sink);
+            if (valid) po = bside ? P.var_off + i : P.row_off + i;
+            *po = (bside ? 15 : 10) * i - 2 * e_i;
+            if (P.err_mask) {
+                uint8_t *pm = reinterpret_cast<uint8_t *>(sink);
+                if (valid && !bside) pm = P.err_mask + i;
+                *pm = err ? 1 : 0;
+            }
+        }
+        const uint32_t tail = err ? 6 : 8;  // item variables: [v y s a b | va inv one | one' sy oms out | u z yeq]
+        uint4 *it = img + 2 * off;
+        // the copies of the inputs go first: their registers are free before the multiplications begin
+        if (valid) {
+            if (!bside) {
+                mix_put(it, 0, c.f0.f);  // 5 x add_input
+                mix_put(it, 1, c.f1.f);
+                mix_put(it, 2, c.f2.f);
+                mix_put(it, 5, c.f0.f);  // var_assigned, scalar.rs:69
+            } else {
+                mix_put(it, 3, c.f0.f);
+                mix_put(it, 4, c.f1.f);
+                if (!err) mix_put(it, 7, fr_one());  // scalar.rs:83
+                mix_put(it, tail, fr_one());         // scalar.rs:41
+                mix_put(it, tail + 4, x);            // u
+                mix_put(it, tail + 6, nz ? fr_zero() : fr_one());  // y = 1 - u z, scalar.rs:126
+            }
+        }
+        const Fr inv = fr_select(nz, fr_mul(accinv, c.pk.f), fr_zero());  // scalar.rs:77 | :122-123
+        accinv = fr_select(nz, fr_mul(accinv, x), accinv);
+        if (valid) {
+            if (!bside) {
+                if (!err) mix_put(it, 6, inv);
+            } else {
+                mix_put(it, tail + 5, inv);
+            }
+        }
+        const Fr sy = fr_mul(c.f1.f, c.f2.f);  // scalar.rs:43 (the v sides')
+        if (valid && !bside) {
+            const Fr oms = fr_sub(fr_one(), c.f2.f);  // scalar.rs:45-50
+            mix_put(it, tail + 1, sy);
+            mix_put(it, tail + 2, oms);
+            mix_put(it, tail + 3, fr_add(sy, oms));   // scalar.rs:53-58
+        }
+        {   // the results' Variables: select_one's output (the v side stores it), maybe_equal's (the a - b side)
+            uint64_t *rv = reinterpret_cast<uint64_t *>(sink);
+            if (valid && A.result_vars) rv = A.result_vars + 2 * i + (bside ? 1 : 0);
+#if !defined(PG_MIX_ABLATE_MEM)
+            *rv = O.var_base + c.base + off + tail + (bside ? 6 : 3);
+#endif
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image is the wave's own: its LDS writes done is all it takes
+        uint4 *dst = O.vars + c.base * 2;
+#pragma unroll
+        for (uint32_t k = 0; k < 15; k++) {  // (15 stores whatever the items' shapes)
+            const uint32_t o = lane + 64 * k;
+#if defined(PG_MIX_ABLATE_MEM)
+            if (img[o].x == 0x12345678u && img[o].y == 0x9abcdef1u) store16(sink, img[o]);
+#else
+            store16(o < total * 2 ? dst + o : sink, img[o]);
+#endif
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // read out before the next image is laid over it
+        c = n;
+    }
+    if (PLAN && ipl) {  // the last wave to get here has every wave's look-back behind it: the words go back to zero
+        unsigned long long done = 0;
+        if (lane == 0) done = __hip_atomic_fetch_add(&P.agg[P.cap], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        done = __shfl(done, 0, 64);
+        if (done == P.nwaves - 1) {
+            for (uint32_t j = lane; j < P.nwaves; j += 64) __hip_atomic_exchange(&P.agg[j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_exchange(&P.agg[P.cap], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 
 __global__ __launch_bounds__(kThreads) void scalar_mix_plan_kernel(const uint4 *v_in, uint64_t batch, uint32_t *rows, uint32_t *vars,
                                                                   uint8_t *err_mask, uint32_t *err_count, const PlanScan P) {

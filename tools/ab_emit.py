@@ -15,68 +15,27 @@ VDIR = os.path.join(ROOT, "tools", "variants")
 
 # the build options that exist in the tree today (every one of them was measured; DESIGN.md section 3 has the numbers)
 VARIANTS = {
-    "r1": None,  # round 1's library, built by hand from `git archive 937331d` (not rebuilt by `build`)
+    "r2": None,  # round 2's library, built by hand from `git archive 74bdd0d` (not rebuilt by `build`)
     "base": [],
-    "no_vars_image": ["-DPG_NO_VARS_IMAGE"],  # the split gadget's variable table through emit_kernel<GD, EMIT_VARS>
+    # the fused mix (C3)
+    "mix_waves4": ["-DPG_MIX_WAVES=4"],  # workgroups of 4 waves (two per CU, an inversion each) instead of 8
+    "mix_waves2": ["-DPG_MIX_WAVES=2"],
+    "rows_wps4": ["-DPG_ROWS_WAVES_PER_SIMD=4"],  # the periodic rows launch allowed 128 registers
+    "rows_prio3": ["-DPG_ROWS_SETPRIO=3"],      # the rows launch's waves at the highest issue priority
+    "rows_prio1": ["-DPG_ROWS_SETPRIO=1"],
+    # every emitter
     "sequential_prepass": ["-DPG_SEQUENTIAL_PREPASS"],
     "invert_fermat": ["-DPG_INVERT_FERMAT"],
-    "sequential_fermat": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_INVERT_FERMAT"],
-    "no_periodic": ["-DPG_NO_PERIODIC"],
     "full_barriers": ["-DPG_FULL_BARRIERS"],
-    "img_w64": ["-DPG_IMAGE_W=64"],
-    "split_sequential": ["-DPG_SPLIT_SEQUENTIAL"],  # split gadget: pre-pass, rows, variables one after the other
-    "rows_stream_low": ["-DPG_ROWS_STREAM_LOW"],  # split gadget: the rows stream at the lowest instead of normal priority
-    "vars_after_rows": ["-DPG_VARS_AFTER_ROWS"],  # split gadget: the variable table waits for the rows launch as well
-    "vars_after_rows5": ["-DPG_VARS_AFTER_ROWS", "-DPG_ROWS_WGS_PER_CU=5"],
-    "beside_rows4": ["-DPG_ROWS_WGS_PER_CU=4"],
-    "beside_rows5": ["-DPG_ROWS_WGS_PER_CU=5"],
-    "beside_rows6": ["-DPG_ROWS_WGS_PER_CU=6"],
-    "beside_l512": ["-DPG_INV_LANES_PER_CU=512"],
-    "beside_grp8": ["-DPG_INV_GRP=8"],
-    "image_waves5": ["-DPG_IMAGE_WAVES_PER_SIMD=5"],  # variable-image kernel held to 80 registers (5 workgroups per CU, what its LDS allows)
-    "vars_blocks_128": ["-DPG_VARS_BLOCKS_PER_CU=128"],  # variable-image kernel: one workgroup per tile (prefetch never engages)
-    "vars_b5": ["-DPG_VARS_BLOCKS_PER_CU=5"],
-    "columns_in_step": ["-DPG_COLUMNS_IN_STEP"],  # periodic selector sweep: all five columns at the same row in every pass
     "unaligned_sweeps": ["-DPG_UNALIGNED_SWEEPS"],  # generic sweeps start at the tile's first unit wherever it falls in a 128-byte line
-    "abl_var_stores": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_ABLATE_VAR_STORES"],   # timing only
-    "abl_item_phase": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_ABLATE_ITEM_PHASE"],   # timing only
-    "abl_both": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_ABLATE_ITEM_PHASE", "-DPG_ABLATE_VAR_STORES"],
-    "seq_l512_g4": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_INV_LANES_PER_CU=512", "-DPG_INV_GRP=4"],
-    "seq_g4": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_INV_GRP=4"],
-    "seq_l512": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_INV_LANES_PER_CU=512"],
-    "vars_blocks_64": ["-DPG_VARS_BLOCKS_PER_CU=64"],
-    "vars_blocks_16": ["-DPG_VARS_BLOCKS_PER_CU=16"],
-    "vars_blocks_6": ["-DPG_VARS_BLOCKS_PER_CU=6"],
-    "rows_wgs_0": ["-DPG_ROWS_WGS_PER_CU=0"],
-    "rows_wgs_2": ["-DPG_ROWS_WGS_PER_CU=2"],
-    "rows_wgs_4": ["-DPG_ROWS_WGS_PER_CU=4"],
-    "inv_grp4": ["-DPG_INV_GRP=4"],
-    "inv_grp2": ["-DPG_INV_GRP=2"],
-    "inv_grp16": ["-DPG_INV_GRP=16"],
-    "inv_lanes512": ["-DPG_INV_LANES_PER_CU=512"],
-    "inv_lanes512_grp4": ["-DPG_INV_LANES_PER_CU=512", "-DPG_INV_GRP=4"],
-    "inv_lanes512_grp2": ["-DPG_INV_LANES_PER_CU=512", "-DPG_INV_GRP=2"],
-    "inv_lanes1024_grp2": ["-DPG_INV_LANES_PER_CU=1024", "-DPG_INV_GRP=2"],
-    "inv_lanes1024": ["-DPG_INV_LANES_PER_CU=1024"],
-    "inv_lanes1024_grp4": ["-DPG_INV_LANES_PER_CU=1024", "-DPG_INV_GRP=4"],
-    "inv_lanes128_cap64": ["-DPG_INV_LANES_PER_CU=128", "-DPG_INV_MAX_PER_LANE=64"],
-    "inv_cap16": ["-DPG_INV_MAX_PER_LANE=16"],
-    "inv_cap8": ["-DPG_INV_MAX_PER_LANE=8"],
-    "side_stream_normal_priority": ["-DPG_SIDE_STREAM_NORMAL_PRIORITY"],
     "xcd_remap": ["-DPG_XCD_REMAP"],
-    "ablate_amul": ["-DPG_ABLATE_AMUL"],  # timing only (wrong values): the emit kernel without its per-accumulator multiplication
     "nt_stores": ["-DPG_NT_STORES"],
-    "rc_w16": ["-DPG_RC_W=16"],
-    "mix_w32": ["-DPG_MIX_W=32"],
-    "mix_w16": ["-DPG_MIX_W=16"],
-    "seq_mix_w32": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_MIX_W=32"],
-    "seq_mix_w128": ["-DPG_SEQUENTIAL_PREPASS", "-DPG_MIX_W=128"],
-    "mb_w32": ["-DPG_MB_W=32"],
-    "mb_w24": ["-DPG_MB_W=24"],
-    "mb_w8": ["-DPG_MB_W=8"],
-    "rc_w64": ["-DPG_RC_W=64"],
-    "rc_w128": ["-DPG_RC_W=128"],
     "grid8": ["-DPG_GRID_BLOCKS_PER_CU=8"],
+    "inv_grp8": ["-DPG_INV_GRP=8"],
+    "inv_lanes512": ["-DPG_INV_LANES_PER_CU=512"],
+    "rc_w16": ["-DPG_RC_W=16"],
+    "mb_w32": ["-DPG_MB_W=32"],
+    "mb_w8": ["-DPG_MB_W=8"],
 }
 
 
@@ -92,7 +51,7 @@ def build(only=None):
 
 
 def run_c3(log2_chunk=20, rounds=4):
-    """fused scalar mix (BASELINE config C3): plan once, time invert pre-pass + emit"""
+    """fused scalar mix (BASELINE config C3): the planned call (plan + rows + variables), what bench.py times"""
     import numpy as np
     import torch
     from plonk_gadgets_amd import _lib
@@ -132,8 +91,8 @@ def run_c3(log2_chunk=20, rounds=4):
         for name, (lib, h) in order:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-            st = lib.pg_scalar_mix_batch(h, *[t.data_ptr() for t in ins], chunk, roff.data_ptr(), voff.data_ptr(), 3, 5, 0,
-                                         C.byref(cc), res.data_ptr(), sp)
+            st = lib.pg_scalar_mix_planned_batch(h, *[t.data_ptr() for t in ins], chunk, roff.data_ptr(), voff.data_ptr(), None,
+                                                 3, 5, 0, C.byref(cc), res.data_ptr(), sp)
             assert st == 0
             e1.record(stream)
             torch.cuda.synchronize()

@@ -9,9 +9,9 @@ rocprofv3 --kernel-trace --output-format csv -d $D -o t -- python3 bench.py --wo
 python3 - "$(find $D -name '*kernel_trace.csv' | head -1)" <<'PY'
 import csv, sys
 ks = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
-ks = [r for r in ks if any(k in r["Kernel_Name"] for k in ("emit_kernel", "vars_image", "batch_invert", "plan_kernel", "scan_"))]
-first = [i for i, r in enumerate(ks) if "batch_invert" in r["Kernel_Name"]][-1]
-first = min(first, [i for i, r in enumerate(ks) if "plan_kernel" in r["Kernel_Name"]][-1])
+ks = [r for r in ks if "pg::" in r["Kernel_Name"]]
+first = [i for i, r in enumerate(ks) if "plan_kernel" in r["Kernel_Name"]]
+first = first[-1] if first else [i for i, r in enumerate(ks) if "emit_kernel" in r["Kernel_Name"]][-1]
 t0 = int(ks[first]["Start_Timestamp"])
 for r in ks[first:]:
     print(f"{(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} .. {(int(r['End_Timestamp']) - t0) / 1e3:9.1f}  {r['Kernel_Name'].split('(')[0][-60:]}")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""tools/c3_pieces.py LIB -- one C3 call (plan + pre-pass + emit) through library LIB, a few times; run under
-`rocprofv3 --kernel-trace --stats` with a PG_SEQUENTIAL_PREPASS build to read every kernel's duration when it has the
+"""tools/c3_pieces.py LIB -- the C3 step (pg_scalar_mix_planned_batch) through library LIB, a few times; run under
+`rocprofv3 --kernel-trace --stats` with a PG_MIX_SEQUENTIAL build to read every kernel's duration when it has the
 chip to itself."""
 import ctypes as C
 import os
@@ -31,8 +31,7 @@ sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 h = C.c_void_p()
 assert lib.pg_engine_create(0, C.byref(h)) == 0
 for _ in range(5):
-    assert lib.pg_scalar_mix_plan_async(h, ins[0].data_ptr(), chunk, roff.data_ptr(), voff.data_ptr(), None, sp) == 0
-    assert lib.pg_scalar_mix_batch(h, *[t.data_ptr() for t in ins], chunk, roff.data_ptr(), voff.data_ptr(), 3, 5, 0, C.byref(cc),
-                                   res.data_ptr(), sp) == 0
+    assert lib.pg_scalar_mix_planned_batch(h, *[t.data_ptr() for t in ins], chunk, roff.data_ptr(), voff.data_ptr(), None, 3, 5, 0,
+                                           C.byref(cc), res.data_ptr(), sp) == 0
     torch.cuda.synchronize()
 print("done")
