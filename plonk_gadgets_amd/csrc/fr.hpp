@@ -129,8 +129,51 @@ PG_HD Fr fr_mul64(const Fr &a, const Fr &b) {
 // column k is m_k = -lo because q = 1 (mod 2^32) (so -q^-1 mod 2^32 = 0xffffffff and m_k * q_0 = m_k needs no
 // multiply).  120 multiply-adds per product (measured 1.2e11 products/s per MI355X, 1.85x the generic code, whose
 // 64-bit products are re-assembled from 32-bit pieces and whose reduction loop stays rolled: tools/fr_mul_bench.hip).
-__device__ __forceinline__ void mac96(uint32_t a, uint32_t b, uint64_t &acc, uint32_t &ex) {
-    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(ex) : "v"(a), "v"(b) : "vcc");
+// One asm statement per run of products of a column (at most eight): between two asm statements the compiler has to assume
+// that the second reads the VCC the first wrote and pads with an s_nop; per product that was 360 of them in a loop body
+// with three multiplications, a quarter of its instructions.
+#define PG_MAC(p, q) "v_mad_u64_u32 %0, vcc, %" #p ", %" #q ", %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+#define PG_MAC_FN(N, BODY, ...)                                                                               \
+    __device__ __forceinline__ void mac96_##N(uint64_t &acc, uint32_t &ex, __VA_ARGS__) {                      \
+        asm(BODY : "+v"(acc), "+v"(ex) : PG_MAC_IN_##N : "vcc");                                               \
+    }
+#define PG_MAC_IN_1 "v"(p0), "v"(q0)
+#define PG_MAC_IN_2 PG_MAC_IN_1, "v"(p1), "v"(q1)
+#define PG_MAC_IN_3 PG_MAC_IN_2, "v"(p2), "v"(q2)
+#define PG_MAC_IN_4 PG_MAC_IN_3, "v"(p3), "v"(q3)
+#define PG_MAC_IN_5 PG_MAC_IN_4, "v"(p4), "v"(q4)
+#define PG_MAC_IN_6 PG_MAC_IN_5, "v"(p5), "v"(q5)
+#define PG_MAC_IN_7 PG_MAC_IN_6, "v"(p6), "v"(q6)
+#define PG_MAC_IN_8 PG_MAC_IN_7, "v"(p7), "v"(q7)
+#define PG_U2(i) uint32_t p##i, uint32_t q##i
+PG_MAC_FN(1, PG_MAC(2, 3), PG_U2(0))
+PG_MAC_FN(2, PG_MAC(2, 3) PG_MAC(4, 5), PG_U2(0), PG_U2(1))
+PG_MAC_FN(3, PG_MAC(2, 3) PG_MAC(4, 5) PG_MAC(6, 7), PG_U2(0), PG_U2(1), PG_U2(2))
+PG_MAC_FN(4, PG_MAC(2, 3) PG_MAC(4, 5) PG_MAC(6, 7) PG_MAC(8, 9), PG_U2(0), PG_U2(1), PG_U2(2), PG_U2(3))
+PG_MAC_FN(5, PG_MAC(2, 3) PG_MAC(4, 5) PG_MAC(6, 7) PG_MAC(8, 9) PG_MAC(10, 11), PG_U2(0), PG_U2(1), PG_U2(2), PG_U2(3), PG_U2(4))
+PG_MAC_FN(6, PG_MAC(2, 3) PG_MAC(4, 5) PG_MAC(6, 7) PG_MAC(8, 9) PG_MAC(10, 11) PG_MAC(12, 13), PG_U2(0), PG_U2(1), PG_U2(2), PG_U2(3),
+          PG_U2(4), PG_U2(5))
+PG_MAC_FN(7, PG_MAC(2, 3) PG_MAC(4, 5) PG_MAC(6, 7) PG_MAC(8, 9) PG_MAC(10, 11) PG_MAC(12, 13) PG_MAC(14, 15), PG_U2(0), PG_U2(1),
+          PG_U2(2), PG_U2(3), PG_U2(4), PG_U2(5), PG_U2(6))
+PG_MAC_FN(8, PG_MAC(2, 3) PG_MAC(4, 5) PG_MAC(6, 7) PG_MAC(8, 9) PG_MAC(10, 11) PG_MAC(12, 13) PG_MAC(14, 15) PG_MAC(16, 17), PG_U2(0),
+          PG_U2(1), PG_U2(2), PG_U2(3), PG_U2(4), PG_U2(5), PG_U2(6), PG_U2(7))
+#undef PG_U2
+
+// acc:ex += sum over i in [lo, hi] of x[i] * y[k - i]   (hi - lo < 8)
+__device__ __forceinline__ void mac_run(const uint32_t (&x)[8], const uint32_t (&y)[8], int k, int lo, int hi, uint64_t &acc, uint32_t &ex) {
+#define PG_XY(j) x[lo + j], y[k - lo - j]
+    switch (hi - lo + 1) {
+        case 1: mac96_1(acc, ex, PG_XY(0)); break;
+        case 2: mac96_2(acc, ex, PG_XY(0), PG_XY(1)); break;
+        case 3: mac96_3(acc, ex, PG_XY(0), PG_XY(1), PG_XY(2)); break;
+        case 4: mac96_4(acc, ex, PG_XY(0), PG_XY(1), PG_XY(2), PG_XY(3)); break;
+        case 5: mac96_5(acc, ex, PG_XY(0), PG_XY(1), PG_XY(2), PG_XY(3), PG_XY(4)); break;
+        case 6: mac96_6(acc, ex, PG_XY(0), PG_XY(1), PG_XY(2), PG_XY(3), PG_XY(4), PG_XY(5)); break;
+        case 7: mac96_7(acc, ex, PG_XY(0), PG_XY(1), PG_XY(2), PG_XY(3), PG_XY(4), PG_XY(5), PG_XY(6)); break;
+        case 8: mac96_8(acc, ex, PG_XY(0), PG_XY(1), PG_XY(2), PG_XY(3), PG_XY(4), PG_XY(5), PG_XY(6), PG_XY(7)); break;
+        default: break;
+    }
+#undef PG_XY
 }
 
 // (Two interleaved accumulator chains per column were measured 16 % SLOWER at every occupancy: tools/fr_mul_bench.hip.)
@@ -147,10 +190,8 @@ __device__ __forceinline__ Fr fr_mul(const Fr &x, const Fr &y) {
     // columns 0..7 produce the quotient digits
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-#pragma unroll
-        for (int i = 0; i <= k; i++) mac96(a[i], b[k - i], acc, ex);
-#pragma unroll
-        for (int i = 0; i < k; i++) mac96(m[i], Q[k - i], acc, ex);
+        mac_run(a, b, k, 0, k, acc, ex);
+        if (k > 0) mac_run(m, Q, k, 0, k - 1, acc, ex);
         m[k] = 0u - (uint32_t)acc;
         // + m_k * q_0 = m_k zeroes the low word; then shift the accumulator down one word
         const uint64_t s = acc + m[k];
@@ -160,15 +201,15 @@ __device__ __forceinline__ Fr fr_mul(const Fr &x, const Fr &y) {
     }
     // columns 8..15 are the result words
 #pragma unroll
-    for (int k = 8; k < 16; k++) {
-#pragma unroll
-        for (int i = k - 7; i < 8; i++) mac96(a[i], b[k - i], acc, ex);
-#pragma unroll
-        for (int i = k - 7; i < 8; i++) mac96(m[i], Q[k - i], acc, ex);
+    for (int k = 8; k < 15; k++) {
+        mac_run(a, b, k, k - 7, 7, acc, ex);
+        mac_run(m, Q, k, k - 7, 7, acc, ex);
         r[k - 8] = (uint32_t)acc;
         acc = (acc >> 32) | ((uint64_t)ex << 32);
         ex = 0;
     }
+    r[7] = (uint32_t)acc;  // (column 15 has no products)
+    acc >>= 32;
     // value = r + acc * 2^256 < 2q: one conditional subtraction
     uint64_t t[4];
 #pragma unroll
