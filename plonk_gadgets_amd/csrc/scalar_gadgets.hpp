@@ -534,6 +534,24 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
     };
     if (ipl) fetch(ipl - 1, c);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The image of a step is copied out DURING THE NEXT STEP, five stores after each of its three multiplications: all
+    // waves of the chip run in step, and 15 KB per wave at once is 31 MB that the memory system takes 5 us to absorb --
+    // with the copy at the end of its own step the waves stood at their stores for a third of the step (issue-stalled 24 %
+    // of their cycles, profiles/NOTES_r03.md).  A step therefore keeps what it computes in registers and lays its image
+    // down at its end, when the previous one has been read out.
+    uint32_t ptotal = 0;            // scalars of the image that waits to be copied out (0: none yet)
+    uint4 *pdst = sink;
+    auto flush = [&](uint32_t k0, uint32_t k1) {
+#pragma unroll
+        for (uint32_t k = k0; k < k1; k++) {  // (a fixed number of stores whatever the items' shapes)
+            const uint32_t o = lane + 64 * k;
+#if defined(PG_MIX_ABLATE_MEM)
+            if (img[o].x == 0x12345678u && img[o].y == 0x9abcdef1u) store16(sink, img[o]);
+#else
+            store16(o < ptotal * 2 ? pdst + o : sink, img[o]);
+#endif
+        }
+    };
     for (uint32_t mm = ipl; mm-- > 0;) {
         fetch(mm > 0 ? mm - 1 : 0, n);  // (the last step fetches itself again)
         const uint64_t i = chunk0 + (uint64_t)mm * 32 + p;
@@ -561,38 +579,34 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
             }
         }
         const uint32_t tail = err ? 6 : 8;  // item variables: [v y s a b | va inv one | one' sy oms out | u z yeq]
+        const Fr inv = fr_select(nz, fr_mul(accinv, c.pk.f), fr_zero());  // scalar.rs:77 | :122-123
+        flush(0, 5);
+        accinv = fr_select(nz, fr_mul(accinv, x), accinv);
+        flush(5, 10);
+        const Fr sy = fr_mul(c.f1.f, c.f2.f);  // scalar.rs:43 (the v sides')
+        flush(10, 15);
+        asm volatile("" ::: "memory");  // (LDS executes a wave's instructions in order: the reads above are ahead of the writes below)
         uint4 *it = img + 2 * off;
-        // the copies of the inputs go first: their registers are free before the multiplications begin
         if (valid) {
             if (!bside) {
                 mix_put(it, 0, c.f0.f);  // 5 x add_input
                 mix_put(it, 1, c.f1.f);
                 mix_put(it, 2, c.f2.f);
                 mix_put(it, 5, c.f0.f);  // var_assigned, scalar.rs:69
+                if (!err) mix_put(it, 6, inv);
+                const Fr oms = fr_sub(fr_one(), c.f2.f);  // scalar.rs:45-50
+                mix_put(it, tail + 1, sy);
+                mix_put(it, tail + 2, oms);
+                mix_put(it, tail + 3, fr_add(sy, oms));   // scalar.rs:53-58
             } else {
                 mix_put(it, 3, c.f0.f);
                 mix_put(it, 4, c.f1.f);
                 if (!err) mix_put(it, 7, fr_one());  // scalar.rs:83
                 mix_put(it, tail, fr_one());         // scalar.rs:41
                 mix_put(it, tail + 4, x);            // u
+                mix_put(it, tail + 5, inv);
                 mix_put(it, tail + 6, nz ? fr_zero() : fr_one());  // y = 1 - u z, scalar.rs:126
             }
-        }
-        const Fr inv = fr_select(nz, fr_mul(accinv, c.pk.f), fr_zero());  // scalar.rs:77 | :122-123
-        accinv = fr_select(nz, fr_mul(accinv, x), accinv);
-        if (valid) {
-            if (!bside) {
-                if (!err) mix_put(it, 6, inv);
-            } else {
-                mix_put(it, tail + 5, inv);
-            }
-        }
-        const Fr sy = fr_mul(c.f1.f, c.f2.f);  // scalar.rs:43 (the v sides')
-        if (valid && !bside) {
-            const Fr oms = fr_sub(fr_one(), c.f2.f);  // scalar.rs:45-50
-            mix_put(it, tail + 1, sy);
-            mix_put(it, tail + 2, oms);
-            mix_put(it, tail + 3, fr_add(sy, oms));   // scalar.rs:53-58
         }
         {   // the results' Variables: select_one's output (the v side stores it), maybe_equal's (the a - b side)
             uint64_t *rv = reinterpret_cast<uint64_t *>(sink);
@@ -601,20 +615,12 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
             *rv = O.var_base + c.base + off + tail + (bside ? 6 : 3);
 #endif
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image is the wave's own: its LDS writes done is all it takes
-        uint4 *dst = O.vars + c.base * 2;
-#pragma unroll
-        for (uint32_t k = 0; k < 15; k++) {  // (15 stores whatever the items' shapes)
-            const uint32_t o = lane + 64 * k;
-#if defined(PG_MIX_ABLATE_MEM)
-            if (img[o].x == 0x12345678u && img[o].y == 0x9abcdef1u) store16(sink, img[o]);
-#else
-            store16(o < total * 2 ? dst + o : sink, img[o]);
-#endif
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // read out before the next image is laid over it
+        ptotal = total;
+        pdst = O.vars + c.base * 2;
+        asm volatile("" ::: "memory");
         c = n;
     }
+    if (ipl) flush(0, 15);  // the wave's last image
     if (PLAN && ipl) {  // the last wave to get here has every wave's look-back behind it: the words go back to zero
         unsigned long long done = 0;
         if (lane == 0) done = __hip_atomic_fetch_add(&P.agg[P.cap], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

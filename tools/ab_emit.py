@@ -17,6 +17,7 @@ VDIR = os.path.join(ROOT, "tools", "variants")
 VARIANTS = {
     "r2": None,  # round 2's library, built by hand from `git archive 74bdd0d` (not rebuilt by `build`)
     "base": [],
+    "prev": None,  # the commit before, built by hand (git stash; build(out=...); git stash pop)
     # the fused mix (C3)
     "mix_waves4": ["-DPG_MIX_WAVES=4"],  # workgroups of 4 waves (two per CU, an inversion each) instead of 8
     "mix_waves2": ["-DPG_MIX_WAVES=2"],
