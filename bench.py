@@ -21,6 +21,11 @@ thread) on a bounded sample of the same workload on this box's host cores.  At N
 process with the same steps/warmup, each with its own roofline object.
 
 --workload c3 / c4 make one of those the line's headline instead (profiling aid); the default (c2) is the judged one.
+
+Exit codes: 0 = the line was printed; 2 = refused (fewer GPUs than asked for); 3 = N > 1 only: the headline was measured and
+printed, but the gather-inclusive sample hung past --allgather-timeout and was abandoned (its "allgather" object says so).
+`roofline.launch_ms` = {min, median, max} of the timed launches (frac is computed from the median); `roofline.traffic` is
+null, with the reason in `traffic_source`, when profiles/pmc_summary.json was collected for other kernel sources.
 """
 from __future__ import annotations
 
@@ -186,14 +191,21 @@ def cpu_baseline(workload: str, sample: int):
         d1 = time.perf_counter() - t1
         base["config_c1"] = {"value": o1["n_gates"] / d1, "unit": "constraints/s", "cores": 1, "kind": "port",
                              "sample": f"1000 witnesses x range_check(min=0,max=2^64) (n=65), {o1['n_gates']} rows, {d1:.1f} s"}
-        # best-case CPU beside the faithful port: oracle/fast.c (mont(2^i) table, flat arrays, closed-form offsets)
-        threads = min(os.cpu_count() or 1, 16)
-        fast = po.range_check_fast(synth.mont(0), synth.mont(2**254), synth.random_scalars(16384, seed=synth.SEED),
-                                   threads=threads)
-        base["fast_variant"] = {"value": fast["n_gates"] / fast["seconds"], "unit": "constraints/s", "cores": threads,
-                                "kind": "port (table-driven, threaded: oracle/fast.c)",
-                                "sample": f"16384 witnesses, {fast['n_gates']} rows, {fast['seconds']:.3f} s "
-                                          "(3.65 GB written to host memory)"}
+        # best-case CPU beside the faithful port: oracle/fast.c (mont(2^i) table, flat arrays, closed-form offsets) on
+        # the host's cores -- 16, 64 and all of them (nproc printed), the best reported with its thread count
+        ncpu = os.cpu_count() or 1
+        nwit = 32768  # 7.3 GB of columns in host memory: enough work per thread for the timing to mean something
+        wit = synth.random_scalars(nwit, seed=synth.SEED)
+        sweep = []
+        for threads in sorted({min(16, ncpu), min(64, ncpu), ncpu}):
+            best_of = min((po.range_check_fast(synth.mont(0), synth.mont(2**254), wit, threads=threads) for _ in range(2)),
+                          key=lambda r: r["seconds"])
+            sweep.append({"cores": threads, "value": best_of["n_gates"] / best_of["seconds"], "seconds": round(best_of["seconds"], 4)})
+        best = max(sweep, key=lambda r: r["value"])
+        base["fast_variant"] = {"value": best["value"], "unit": "constraints/s", "cores": best["cores"],
+                                "kind": "port (table-driven, threaded: oracle/fast.c)", "nproc": ncpu, "thread_sweep": sweep,
+                                "sample": f"{nwit} witnesses, {best_of['n_gates']} rows, {best['seconds']:.3f} s with {best['cores']} "
+                                          "threads (7.3 GB written to host memory; best of two runs per thread count)"}
     return base
 
 
@@ -317,28 +329,47 @@ def measure(wl: Workload, steps: int, warmup: int, sync_all):
     return elapsed, kernel_ms
 
 
+def kernel_sources_sha256() -> str:
+    """what the library is built from (plonk_gadgets_amd.build.kernel_sources_sha256): the PMC passes under profiles/ say
+    which sources they were collected for"""
+    from plonk_gadgets_amd import build as pg_build
+    return pg_build.kernel_sources_sha256()
+
+
 def pmc_traffic(workload: str, chunk: int):
-    """HBM bytes per launch of this workload from the tracked PMC passes (offline: rocprofv3 cannot run inside bench.py)"""
+    """HBM bytes per launch of this workload from the tracked PMC passes (offline: rocprofv3 cannot run inside bench.py).
+    Only if they were collected for the kernel sources this run's library is built from: a summary that has gone stale
+    yields null and says why."""
     if not os.path.exists(PMC_SUMMARY):
-        return None, None
+        return None, "no profiles/pmc_summary.json"
     try:
-        ent = json.load(open(PMC_SUMMARY)).get(workload, {}).get(str(chunk))
-        if ent:
-            return ent["hbm_bytes_per_launch"], ("profiles/pmc_summary.json (%s, offline rocprofv3 --pmc WRITE_SIZE / "
-                                                 "FETCH_SIZE passes of this command; not measured by this run)" % ent.get("round", "?"))
-    except Exception:
-        pass
-    return None, None
+        summ = json.load(open(PMC_SUMMARY))
+        ent = summ.get(workload, {}).get(str(chunk))
+        if not ent:
+            return None, "profiles/pmc_summary.json has no entry for this workload and launch size"
+        have, want = ent.get("kernel_sources_sha256"), kernel_sources_sha256()
+        if have != want:
+            return None, ("profiles/pmc_summary.json (%s) was collected for other kernel sources (%s..., this run: %s...): "
+                          "stale, not reported" % (ent.get("round", "?"), str(have)[:12], want[:12]))
+        return ent["hbm_bytes_per_launch"], ("profiles/pmc_summary.json (%s, offline rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE "
+                                             "passes of this command at these kernel sources, %s...; not measured by this run)"
+                                             % (ent.get("round", "?"), want[:12]))
+    except Exception as exc:  # a summary that cannot be read is no reason to lose the run
+        return None, "profiles/pmc_summary.json unreadable: %r" % (exc,)
 
 
 def roofline_of(wl: Workload, kernel_ms):
-    avg_launch_s = sum(kernel_ms) / len(kernel_ms) / 1e3
-    achieved = wl.algo_bytes_per_launch / avg_launch_s / 1e9
+    """achieved = algorithmic bytes per launch / the MEDIAN launch duration (HIP events on the launch stream around every
+    timed launch); min / median / max are in the line so that a slow box can be told from a slow build"""
+    ms = sorted(kernel_ms)
+    med = ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2])
+    achieved = wl.algo_bytes_per_launch / (med / 1e3) / 1e9
     traffic, src = pmc_traffic(wl.name, wl.chunk)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src, "kernel": wl.kernel,
             "algorithmic_bytes_per_launch": wl.algo_bytes_per_launch, "input_bytes_per_launch": wl.read_bytes,
-            "avg_launch_ms": avg_launch_s * 1e3, "launches_timed": len(kernel_ms)}
+            "launch_ms": {"min": ms[0], "median": med, "max": ms[-1]},
+            "avg_launch_ms": sum(ms) / len(ms), "launches_timed": len(ms)}
 
 
 def main():
@@ -359,6 +390,15 @@ def main():
 
     def emit(obj):
         os.write(out_fd, (json.dumps(obj) + "\n").encode())
+
+    emit_lock = threading.Lock()
+    emitted = []
+
+    def emit_once(obj):
+        with emit_lock:
+            if not emitted:
+                emitted.append(True)
+                emit(obj)
 
     import numpy as np  # noqa: F401
     import torch
@@ -473,10 +513,12 @@ def main():
         # the headline is measured; a collective that hangs (a link, a rank that died) must not cost it: after the limit
         # rank 0 prints the line it has, and every rank leaves
         def bail():
+            # exactly one line is ever written (emit_once), and a run whose collective hung does not exit 0: code 3 = "the
+            # headline was measured and printed, the gather-inclusive sample was abandoned"
             if rank == 0:
-                line["allgather"] = {"error": f"the gather-inclusive sample did not finish within {args.allgather_timeout} s; abandoned"}
-                emit(line)
-            os._exit(0)
+                emit_once(dict(line, allgather={"error": f"the gather-inclusive sample did not finish within "
+                                                         f"{args.allgather_timeout} s; abandoned"}))
+            os._exit(3)
         watchdog = threading.Timer(args.allgather_timeout, bail)
         watchdog.daemon = True
         watchdog.start()
@@ -519,13 +561,14 @@ def main():
             allgather["variables_only"] = {"error": repr(ex)}
 
     if watchdog is not None:
-        watchdog.cancel()
+        watchdog.cancel()  # (before the final line is built; a timer that has already fired wins the lock below and exits)
     if rank == 0:
+        final = dict(line)
         if allgather:
-            line["allgather"] = allgather
+            final["allgather"] = allgather
         if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample)
-        emit(line)
+            final["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample)
+        emit_once(final)
     if distributed:
         dist.destroy_process_group()
     eng.close()

@@ -25,6 +25,10 @@
  *     table and grow-only scratch (inverses of the current call, prefix-sum
  *     temporaries).  Because that scratch is per engine, calls on one engine
  *     must be issued on ONE stream at a time (one engine per stream/thread).
+ *     A call on another stream than the previous one is ordered behind it by
+ *     an event recorded on the previous stream: keep a stream alive until the
+ *     next call on the engine has been issued (a stream that has been
+ *     destroyed costs that call a device synchronisation instead).
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *     Batch calls enqueue and return; synchronise the stream (or call
  *     pg_engine_sync) before reading results.

@@ -29,11 +29,27 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def kernel_sources_sha256() -> str:
+    """one hash over everything the library is compiled from (csrc/ and the C header), in a fixed order: what
+    profiles/pmc_summary.json is stamped with and bench.py compares against"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(os.path.dirname(HERE), "include", "plonk_gadgets_hip.h"), "rb").read())
+    return h.hexdigest()
+
+
 def build(force: bool = False, extra_flags: list[str] | None = None, out: str | None = None) -> str:
     out = out or LIB
     if not force and out == LIB and not is_stale():
         return out
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-I/opt/rocm/include",
+    cc = hipcc()
+    # ROCm's include directory (only for <rccl/rccl.h>, which capi_dist.inc can do without): beside the compiler, or $ROCM_PATH
+    rocm = os.environ.get("ROCM_PATH") or os.path.dirname(os.path.dirname(os.path.realpath(cc)))
+    inc = ["-I" + os.path.join(rocm, "include")] if os.path.isdir(os.path.join(rocm, "include")) else []
+    cmd = [cc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"] + inc + [
            "-o", out] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"] + (extra_flags or [])
     subprocess.check_call(cmd)
     return out

@@ -241,8 +241,15 @@ pg_status ensure_inv_scratch(pg_engine *e, uint64_t elems) {
 pg_status enter_stream(pg_engine *e, hipStream_t st) {
     PG_HIP_TRY(hipSetDevice(e->device));
     if (e->have_last && e->last_stream != st) {
-        PG_HIP_TRY(hipEventRecord(e->ev_switch, e->last_stream));
-        PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_switch, 0));
+        // (the previous stream may be gone -- a caller may destroy a stream it has synchronised: then nothing of the engine
+        // is in flight on it, but to be safe against handles that merely look dead the device is synchronised once)
+        if (hipEventRecord(e->ev_switch, e->last_stream) == hipSuccess) {
+            PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_switch, 0));
+        } else {
+            (void)hipGetLastError();
+            e->have_last = false;
+            PG_HIP_TRY(hipDeviceSynchronize());
+        }
     }
     e->last_stream = st;
     e->have_last = true;

@@ -675,13 +675,14 @@ __device__ __forceinline__ uint64_t wave_sum(uint64_t x) {
     return x;
 }
 
-__device__ __forceinline__ void plan_finish(const PlanScan &P, const uint32_t r[4], const uint32_t v[4], uint64_t batch) {
+__device__ __forceinline__ void plan_finish(const PlanScan &P, const uint32_t r[4], const uint32_t v[4], uint64_t batch, uint32_t my_errs) {
     __shared__ uint64_t s_w[4], s_pref[2];
     __shared__ uint32_t s_last;
     const uint32_t tid = threadIdx.x, b = blockIdx.x, nblk = gridDim.x;
-    uint64_t tr, tv;
+    uint64_t tr, tv, te;
     const uint64_t er = block_exclusive_scan((uint64_t)r[0] + r[1] + r[2] + r[3], s_w, tr);
     const uint64_t ev = block_exclusive_scan((uint64_t)v[0] + v[1] + v[2] + v[3], s_w, tv);
+    (void)block_exclusive_scan((uint64_t)my_errs, s_w, te);  // the block's failing items: ONE atomic per block, below
     if (tid == 0 && b > 0) plan_publish(&P.agg[b], kAggA, tr, tv);
     if (tid < 64) {  // wave 0 looks back, 64 predecessors at a time, nearest first, until one of them holds a prefix
         uint64_t pr = 0, pv = 0;
@@ -726,12 +727,17 @@ __device__ __forceinline__ void plan_finish(const PlanScan &P, const uint32_t r[
             P.host->n_vars = vo;
         }
     }
-    // the last block to get here has every block's error count behind it: a block's own atomics have been performed
-    // (workgroup-scope fence = the waves wait for their outstanding memory operations) before it counts itself
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (tid == 0)
+    // The last block to get here must have every block's error count behind it.  A block adds its count with ONE atomic
+    // whose RESULT it consumes before it counts itself done: a returning atomic has been performed at the coherence point
+    // when its value arrives, so the two are ordered by a data dependency (a non-returning add could still be in flight
+    // when the done counter is bumped; a workgroup-scope fence does not wait for it).
+    if (tid == 0) {
+        if (P.err_count && te) {
+            uint32_t before = __hip_atomic_fetch_add(P.err_count, (uint32_t)te, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"(before));  // the value is needed here: the wave waits for the atomic to return
+        }
         s_last = __hip_atomic_fetch_add(&P.agg[P.blocks_cap], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1 ? 1u : 0u;
+    }
     __syncthreads();
     if (!s_last) return;
     for (uint32_t j = tid; j < nblk; j += kThreads) __hip_atomic_exchange(&P.agg[j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -743,7 +749,7 @@ __device__ __forceinline__ void plan_finish(const PlanScan &P, const uint32_t r[
 
 // what every plan kernel ends with: its threads' four row / variable counts -> offsets (fused) or counts + block sums
 __device__ __forceinline__ void plan_store(const PlanScan &P, const uint32_t r[4], const uint32_t v[4], uint64_t batch, uint32_t *rows,
-                                           uint32_t *vars);
+                                           uint32_t *vars, uint32_t my_errs = 0);
 
 // block sums straight from a plan kernel: thread t of plan block b owns items b * kScanBlock + 4 t .. + 3 (the
 // indexing of scan_final_kernel) and hands in the sums of its four counts -- the separate block-sums launch is gone
@@ -755,12 +761,14 @@ __device__ __forceinline__ void plan_block_sums(uint64_t r, uint64_t v, uint64_t
     if (threadIdx.x == 0) { blk_rows[blockIdx.x] = tr; blk_vars[blockIdx.x] = tv; }
 }
 
+// my_errs: this thread's failing items (counted into P.err_count: by one atomic per block on the fused path, per thread on the other)
 __device__ __forceinline__ void plan_store(const PlanScan &P, const uint32_t r[4], const uint32_t v[4], uint64_t batch, uint32_t *rows,
-                                           uint32_t *vars) {
+                                           uint32_t *vars, uint32_t my_errs) {
     if (P.fused) {
-        plan_finish(P, r, v, batch);
+        plan_finish(P, r, v, batch, my_errs);
         return;
     }
+    if (my_errs && P.err_count) atomicAdd(P.err_count, my_errs);  // (read by scan_final_kernel, a later launch)
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x * 4 + k;

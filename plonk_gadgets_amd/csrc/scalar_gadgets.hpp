@@ -236,7 +236,7 @@ struct IsNonZeroGD {
 __global__ __launch_bounds__(kThreads) void is_non_zero_plan_kernel(const uint4 *value, uint64_t batch, uint32_t *rows,
                                                                    uint32_t *vars, uint8_t *err_mask, uint32_t *err_count,
                                                                    const PlanScan P) {
-    uint32_t r[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
+    uint32_t r[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0}, errs = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x * 4 + k;
@@ -244,10 +244,10 @@ __global__ __launch_bounds__(kThreads) void is_non_zero_plan_kernel(const uint4 
             const bool err = fr_is_zero(load_fr(value, i));
             r[k] = v[k] = err ? 1 : 3;
             if (err_mask) err_mask[i] = err ? 1 : 0;
-            if (err) atomicAdd(err_count, 1u);
+            errs += err ? 1 : 0;
         }
     }
-    plan_store(P, r, v, batch, rows, vars);
+    plan_store(P, r, v, batch, rows, vars, errs);
 }
 
 // ---- the fused mix (BASELINE config C3) ---------------------------------------------
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
 
 __global__ __launch_bounds__(kThreads) void scalar_mix_plan_kernel(const uint4 *v_in, uint64_t batch, uint32_t *rows, uint32_t *vars,
                                                                   uint8_t *err_mask, uint32_t *err_count, const PlanScan P) {
-    uint32_t r[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
+    uint32_t r[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0}, errs = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x * 4 + k;
@@ -643,10 +643,10 @@ __global__ __launch_bounds__(kThreads) void scalar_mix_plan_kernel(const uint4 *
             r[k] = err ? 8 : 10;
             v[k] = err ? 13 : 15;
             if (err_mask) err_mask[i] = err ? 1 : 0;
-            if (err) atomicAdd(err_count, 1u);
+            errs += err ? 1 : 0;
         }
     }
-    plan_store(P, r, v, batch, rows, vars);
+    plan_store(P, r, v, batch, rows, vars, errs);
 }
 
 }  // namespace pg

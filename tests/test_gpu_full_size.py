@@ -55,10 +55,12 @@ def compare_items(cols, roff, voff, idx, ora, o_rows, o_vars, var_base=5):
             assert np.array_equal(got[~zero] - (var_base + v0), exp[~zero] - (5 + ovar[s])), (name, i)
 
 
-def test_config_c3_full_size_properties(engine):
+@pytest.mark.parametrize("form", ["planned", "two_step"])
+def test_config_c3_full_size_properties(engine, form):
     """BASELINE config 3 at full size: 2^20 fused items in one launch, with items whose v is 0 sprinkled in (alone, and
     a run of 70 in a row) so that tiles of every kind occur: all items complete (the uniform fast path), some stopped
-    early, all stopped early"""
+    early, all stopped early.  `planned` is the call bench.py times (pg_scalar_mix_planned_batch: worst-case buffers, the
+    totals read afterwards with pg_plan_result); `two_step` is pg_scalar_mix_plan followed by pg_scalar_mix_batch."""
     import bench
     import plonk_gadgets_amd as pg
     from oracle import pyoracle as po
@@ -67,22 +69,37 @@ def test_config_c3_full_size_properties(engine):
     v[zeros] = 0
     ins = [dev(x) for x in (v, y, s, a, b)]
     _, roff, voff = engine.ragged_buffers(BATCH)
-    err = torch.zeros((BATCH,), dtype=torch.uint8, device="cuda:0")
-    lay, nerr = engine.scalar_mix_plan(ins[0], roff, voff, err)
+    roff.fill_(-1)
+    voff.fill_(-1)
+    err = torch.full((BATCH,), 7, dtype=torch.uint8, device="cuda:0")
+    res = torch.empty((BATCH, 2), dtype=torch.int64, device="cuda:0")
+    if form == "planned":
+        cols = pg.Columns.allocate(10 * BATCH, 15 * BATCH, "cuda:0", 3, 5)  # the worst case: the layout is not known yet
+        for name in SEL + WIRES + ("var_values",):
+            getattr(cols, name).fill_(-1)  # a slot nobody writes would fail the row check / the comparison
+        engine.scalar_mix_planned(*ins, roff, voff, cols, res, err, 3, 5, 0)
+        torch.cuda.synchronize()
+        lay, nerr = engine.plan_result()
+        # what lies beyond the totals was not touched
+        assert bool((cols.q_m[lay.n_gates:] == -1).all()) and bool((cols.var_values[lay.n_vars:] == -1).all())
+        cols = pg.Columns(**{n: getattr(cols, n)[:lay.n_gates] for n in SEL + WIRES}, var_values=cols.var_values[:lay.n_vars],
+                          gate_base=3, var_base=5)
+    else:
+        lay, nerr = engine.scalar_mix_plan(ins[0], roff, voff, err)
     assert nerr == len(zeros)
     assert (lay.n_gates, lay.n_vars) == (10 * BATCH - 2 * nerr, 15 * BATCH - 2 * nerr)
     is_zero = torch.zeros((BATCH,), dtype=torch.bool, device="cuda:0")
     is_zero[torch.tensor(zeros, device="cuda:0")] = True
-    assert bool((err.bool() == is_zero).all())
+    assert bool((err.bool() == is_zero).all()) and int(err.max()) == 1
     # the prefix sums, item by item
     assert bool((roff[1:] - roff[:-1] == torch.where(is_zero, 8, 10)).all()) and int(roff[0]) == 0 and int(roff[-1]) == lay.n_gates
     assert bool((voff[1:] - voff[:-1] == torch.where(is_zero, 13, 15)).all()) and int(voff[0]) == 0 and int(voff[-1]) == lay.n_vars
-    cols = pg.Columns.allocate(lay.n_gates, lay.n_vars, "cuda:0", 3, 5)
-    for name in SEL + WIRES + ("var_values",):
-        getattr(cols, name).fill_(-1)  # a slot nobody writes would fail the row check / the comparison
-    res = torch.empty((BATCH, 2), dtype=torch.int64, device="cuda:0")
-    engine.scalar_mix_emit(*ins, roff, voff, cols, res, 3, 5, 0)
-    torch.cuda.synchronize()
+    if form == "two_step":
+        cols = pg.Columns.allocate(lay.n_gates, lay.n_vars, "cuda:0", 3, 5)
+        for name in SEL + WIRES + ("var_values",):
+            getattr(cols, name).fill_(-1)
+        engine.scalar_mix_emit(*ins, roff, voff, cols, res, 3, 5, 0)
+        torch.cuda.synchronize()
     # every one of the 10.5 M rows satisfies its gate equation over the emitted variable table
     assert engine.check_rows(cols, var_base=5, zero_var=0) == -1
     # the five inputs are each item's first five variables
@@ -109,9 +126,12 @@ def test_config_c3_full_size_properties(engine):
     torch.cuda.empty_cache()
 
 
-def test_config_c4_full_size_properties(engine):
+@pytest.mark.parametrize("form", ["async_plan", "sync_plan"])
+def test_config_c4_full_size_properties(engine, form):
     """BASELINE config 4 at full size: 2^20 x max_bound with random 253-bit bounds (ladder length from the bound, ragged
-    rows), 115.8 GB of columns in one launch"""
+    rows), 115.8 GB of columns in one launch.  `async_plan` is what bench.py times: pg_max_bound_ragged_plan_async and
+    pg_max_bound_ragged_batch back to back without a host round trip (buffers sized from an earlier plan, as the bench
+    does); `sync_plan` the plan that returns its totals."""
     import bench
     import plonk_gadgets_amd as pg
     from oracle import pyoracle as po
@@ -129,8 +149,19 @@ def test_config_c4_full_size_properties(engine):
     assert bool((voff[1:] - voff[:-1] == n64 + 262).all()) and int(voff[0]) == 0 and int(voff[-1]) == lay.n_vars
     cols = pg.Columns.allocate(lay.n_gates, lay.n_vars, "cuda:0", 3, 5)
     res = torch.empty((BATCH,), dtype=torch.int64, device="cuda:0")
+    if form == "async_plan":  # plan again, this time without the round trip, straight into the emit call
+        nb.fill_(0)
+        roff.fill_(-1)
+        voff.fill_(-1)
+        engine.max_bound_ragged_plan_async(mr, nb, roff, voff)
     engine.max_bound_ragged_emit(mr, wt, nb, roff, voff, cols, res, 3, 5)
     torch.cuda.synchronize()
+    if form == "async_plan":
+        lay2, nerr2 = engine.plan_result()
+        assert (lay2.n_gates, lay2.n_vars, nerr2) == (lay.n_gates, lay.n_vars, 0)
+        assert bool((nb.to(torch.int64) == n64).all())
+        assert bool((roff[1:] - roff[:-1] == 2 * n64 + 5).all()) and int(roff[0]) == 0 and int(roff[-1]) == lay.n_gates
+        assert bool((voff[1:] - voff[:-1] == n64 + 262).all()) and int(voff[0]) == 0 and int(voff[-1]) == lay.n_vars
     # every one of the 5.3e8 rows satisfies its gate equation over the emitted variable table
     assert engine.check_rows(cols, var_base=5) == -1
     # witness = the item's first variable, result = its last

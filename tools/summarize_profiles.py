@@ -8,10 +8,16 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+sys.path.insert(0, ROOT)
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
 DST = os.path.join(ROOT, "profiles")
 summary = {}
+# the kernel sources the passes were collected for: written on the GPU box by collect_profiles.sh, checked against this tree
+SOURCES = open(os.path.join(SRC, "kernel_sources.sha256")).read().split()[0]
+from plonk_gadgets_amd import build as pg_build
+if SOURCES != pg_build.kernel_sources_sha256():
+    print("WARNING: the passes under", SRC, "were collected for other kernel sources than this tree's")
 
 
 def newest(pattern):
@@ -31,7 +37,7 @@ for w in ("c2", "c3", "c4"):
         f = newest(os.path.join(SRC, f"{kind}_{w}", "*", "*counter_collection.csv"))
         # every kernel of the one step the PMC pass runs (steps = 1, warmup = 0): the emit launch(es), the inversion
         # pre-pass, the plan and its prefix-sum launch
-        keep = [r for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in ("emit_kernel", "vars_image", "batch_invert", "plan_kernel", "scan_"))]
+        keep = [r for r in csv.DictReader(open(f)) if "pg::" in r["Kernel_Name"]]
         with open(os.path.join(DST, f"{R}_{w}_pmc_{cn.lower()}.csv"), "w") as o:
             wr = csv.DictWriter(o, fieldnames=list(keep[0].keys()))
             wr.writeheader()
@@ -39,22 +45,24 @@ for w in ("c2", "c3", "c4"):
         vals[cn] = sum(float(r["Counter_Value"]) for r in keep)
     # MI355X_MICROARCH.md: WRITE_SIZE exact (KB) for 16-B-per-lane streaming stores; FETCH_SIZE counts half the bytes
     # of wide streaming reads on gfx950 -> doubled
-    summary[w] = {str(chunk): {"kernel": "every kernel of one step (emit launches + pre-pass + plan)", "write_size_kb": vals["WRITE_SIZE"],
+    summary[w] = {str(chunk): {"kernel": "every kernel of one step", "write_size_kb": vals["WRITE_SIZE"],
                                "fetch_size_kb_raw": vals["FETCH_SIZE"],
                                "hbm_bytes_per_launch": (vals["WRITE_SIZE"] + 2 * vals["FETCH_SIZE"]) * 1024,
-                               "round": R,
+                               "round": R, "kernel_sources_sha256": SOURCES,
                                "note": "rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate passes; FETCH_SIZE doubled "
                                        "(gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md section HBM)"}}
-    # launches of one step overlap (the fused mix's rows run beside its pre-pass, its variable table beside the rows): the
-    # step's duration is the SPAN of its kernels, not the sum of their durations -- from the kernel trace, last step
+    # launches of one step may overlap (a big-item gadget's pre-pass runs beside its emit launch): the step's duration is
+    # the SPAN of its kernels, not the sum of their durations -- from the kernel trace, last step
     tr = newest(os.path.join(SRC, f"stats_{w}", "*", "*kernel_trace.csv"))
     ks = sorted(csv.DictReader(open(tr)), key=lambda r: int(r["Start_Timestamp"]))
-    ks = [r for r in ks if any(k in r["Kernel_Name"] for k in ("emit_kernel", "vars_image", "batch_invert", "plan_kernel", "scan_"))]
-    firsts = [i for i, r in enumerate(ks) if "plan_kernel" in r["Kernel_Name"]] or [i for i, r in enumerate(ks) if "emit_kernel" in r["Kernel_Name"]]
+    ks = [r for r in ks if "pg::" in r["Kernel_Name"]]
+    # the last step: from the last kernel that begins a step (c2: the pre-pass or the emit launch; c3: the launch that plans,
+    # inverts and writes the variable table; c4: the plan kernel)
+    first_of = {"c2": ("batch_invert", "emit_kernel"), "c3": ("scalar_mix_vars",), "c4": ("plan_kernel",)}[w]
+    firsts = [i for i, r in enumerate(ks) if any(k in r["Kernel_Name"] for k in first_of)]
     start = firsts[-1]
-    inv = [i for i, r in enumerate(ks) if "batch_invert" in r["Kernel_Name"]]
-    if inv and inv[-1] < start and start - inv[-1] <= 2:  # a planned call launches its pre-pass ahead of its plan
-        start = inv[-1]
+    if w == "c2" and len(firsts) > 1 and firsts[-2] == start - 1:  # pre-pass and emit launch of the same step
+        start = firsts[-2]
     step = ks[start:]
     t0 = int(step[0]["Start_Timestamp"])
     with open(os.path.join(DST, f"{R}_{w}_step_timeline.txt"), "w") as o:
