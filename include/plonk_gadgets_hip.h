@@ -511,6 +511,50 @@ pg_status pg_allgather_bytes(pg_comm *c, const void *d_send, void *d_recv, uint6
 pg_status pg_allgather_columns(pg_comm *c, const pg_columns *local, uint64_t n_gates, uint64_t n_vars,
                                const pg_columns *gathered, void *stream);
 
+/* BASELINE config 5 as ONE object: the chunked gather pipeline.  2^23 x 223 KB = 1.87 TB fits no GPU, so a sharded batch is
+ * streamed in chunks of `chunk` witnesses per rank: chunk k + 1 is emitted on the caller's stream while chunk k is in
+ * ncclAllGather on the pipeline's communication stream (two slots, events between the streams).  Numbering: rank r's
+ * item i is item r * total_per_rank + i of the whole batch (contiguous witness shards).
+ *   variables_only = 0  every rank's packed chunk travels (all nine arrays back to back, pg_packed_layout): one collective
+ *                       of 223 KB per witness;
+ *   variables_only = 1  only the variable tables travel (33 KB per witness); the other ranks' selectors and wire indices --
+ *                       a function of the public bounds and the numbering -- are regenerated locally
+ *                       (pg_range_check_structure_batch).
+ * `consume` is called on the host, once per chunk and in order, when the chunk is complete for `stream`: parts[r] are the
+ * nine arrays of rank r's chunk (device pointers owned by the pipeline, n_gates rows / n_vars variables each); whatever
+ * the callback enqueues on `stream` reads them safely, and they are overwritten two chunks later.  The communicator must
+ * outlive every run of the pipeline (not its destruction).  The reference has no
+ * counterpart (one composer, one thread: src/range.rs:27-32); the shape is BASELINE.json config 5's. */
+typedef struct pg_gather_pipeline pg_gather_pipeline;
+typedef void (*pg_chunk_consumer)(void *user, uint64_t chunk_index, uint32_t world, const pg_columns *parts, uint64_t n_gates,
+                                  uint64_t n_vars, void *stream);
+pg_status pg_range_check_gather_pipeline_create(pg_comm *c, const pg_scalar *min_range, const pg_scalar *max_range,
+                                                uint64_t chunk, uint32_t variables_only, pg_gather_pipeline **out);
+/* bytes one rank puts on the links per chunk */
+uint64_t pg_range_check_gather_pipeline_bytes_per_chunk(const pg_gather_pipeline *p);
+pg_status pg_range_check_gather_pipeline_run(pg_gather_pipeline *p, const pg_scalar *d_witness_local,
+                                             uint64_t total_per_rank /* a multiple of chunk */, uint64_t gate_base,
+                                             uint64_t var_base, pg_chunk_consumer consume /* may be NULL */, void *user,
+                                             void *stream);
+void pg_range_check_gather_pipeline_destroy(pg_gather_pipeline *p);
+
+/* Ragged sharded batches (one public bound per item: rows per item differ) have ONE real exchange step: every rank plans
+ * its contiguous shard, the 16 bytes of (rows, variables) totals are all-gathered, and an exclusive prefix sum over the
+ * ranks gives each rank the global numbering of its first row and variable.
+ *   pg_max_bound_ragged_sharded_plan   plan + exchange; `shard` receives this rank's placement (gate_base / var_base
+ *                                      already global, n_gates / n_vars its totals); gates_per_rank / vars_per_rank
+ *                                      ([world] each, may be NULL) every rank's totals.  Synchronises `stream`.
+ *   pg_max_bound_ragged_sharded_batch  the same followed by the emission (pg_max_bound_ragged_batch) at that numbering, for
+ *                                      callers whose `out` holds the worst case (515 rows, 517 variables per item). */
+pg_status pg_max_bound_ragged_sharded_plan(pg_comm *c, const pg_scalar *d_max_range_local, uint64_t batch_local,
+                                           uint32_t *d_num_bits, uint64_t *d_row_off, uint64_t *d_var_off, uint64_t gate_base,
+                                           uint64_t var_base, pg_shard *shard, uint64_t *gates_per_rank, uint64_t *vars_per_rank,
+                                           void *stream);
+pg_status pg_max_bound_ragged_sharded_batch(pg_comm *c, const pg_scalar *d_max_range_local, const pg_scalar *d_witness_local,
+                                            uint64_t batch_local, uint32_t *d_num_bits, uint64_t *d_row_off, uint64_t *d_var_off,
+                                            uint64_t gate_base, uint64_t var_base, const pg_columns *out,
+                                            pg_variable *d_result_vars /* may be NULL */, pg_shard *shard, void *stream);
+
 /* ---- diagnostics ----------------------------------------------------------
  * pg_fill_bytes: a bare streaming fill (16 B per lane, same store form as the emitters) that bench.py times on the same
  * box as a comparison point.  streams = 1..16: the buffer is written as that many equal parts

@@ -194,6 +194,20 @@ SIGNATURES = {
                                                                   C.c_uint64, C.c_uint64, _P(ColumnsC), C.c_void_p, C.c_void_p]),
 }
 
+# the gather pipeline's consumer callback (pg_chunk_consumer)
+CHUNK_CONSUMER = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint32, _P(ColumnsC), C.c_uint64, C.c_uint64, C.c_void_p)
+SIGNATURES.update({
+    "pg_range_check_gather_pipeline_create": (C.c_int, [C.c_void_p, _P(Scalar), _P(Scalar), C.c_uint64, C.c_uint32, _P(C.c_void_p)]),
+    "pg_range_check_gather_pipeline_bytes_per_chunk": (C.c_uint64, [C.c_void_p]),
+    "pg_range_check_gather_pipeline_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, CHUNK_CONSUMER,
+                                                     C.c_void_p, C.c_void_p]),
+    "pg_range_check_gather_pipeline_destroy": (None, [C.c_void_p]),
+    "pg_max_bound_ragged_sharded_plan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                                   C.c_uint64, _P(ShardC), _P(C.c_uint64), _P(C.c_uint64), C.c_void_p]),
+    "pg_max_bound_ragged_sharded_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_uint64, C.c_uint64, _P(ColumnsC), C.c_void_p, _P(ShardC), C.c_void_p]),
+})
+
 _lib = None
 
 

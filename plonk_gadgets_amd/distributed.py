@@ -211,13 +211,24 @@ def exchange_totals(n_gates: int, n_vars: int, device, group=None):
 
 
 def max_bound_ragged_sharded(engine, max_range_local: torch.Tensor, witness_local: torch.Tensor, gate_base: int = 0,
-                             var_base: int = 0, group=None):
+                             var_base: int = 0, group=None, collective=None):
     """Ragged max_bound (one public bound per item) over ranks: every rank plans its contiguous shard, the shard
     totals are all-gathered (exchange_totals), and each rank emits at the global numbering its prefix gives it.
     Returns (Columns, result_vars, ShardInfo, gates_per_rank, vars_per_rank)."""
     rank, world = _rank_world(group)
     batch = witness_local.shape[0]
     nb, roff, voff = engine.ragged_buffers(batch)
+    if isinstance(collective, NativeCollective):  # plan + exchange inside the library (pg_max_bound_ragged_sharded_plan)
+        lib, s = _lib.load(), _lib.ShardC()
+        gates, vars_ = (C.c_uint64 * world)(), (C.c_uint64 * world)()
+        st = lib.pg_max_bound_ragged_sharded_plan(collective._h, max_range_local.data_ptr(), batch, nb.data_ptr(), roff.data_ptr(),
+                                                  voff.data_ptr(), gate_base, var_base, C.byref(s), gates, vars_, engine._stream())
+        if st != 0:
+            raise PgError(st, "pg_max_bound_ragged_sharded_plan")
+        cols = Columns.allocate(s.n_gates, s.n_vars, witness_local.device, s.gate_base, s.var_base)
+        res = torch.empty((batch,), dtype=torch.int64, device=witness_local.device)
+        engine.max_bound_ragged_emit(max_range_local, witness_local, nb, roff, voff, cols, res, s.gate_base, s.var_base)
+        return cols, res, ShardInfo(rank, world, -1, -1, s.gate_base, s.var_base, s.n_gates, s.n_vars), list(gates), list(vars_)
     lay = engine.max_bound_ragged_plan(max_range_local, nb, roff, voff)
     gates, vars_ = exchange_totals(lay.n_gates, lay.n_vars, witness_local.device, group)
     g0, v0 = gate_base + sum(gates[:rank]), var_base + sum(vars_[:rank])
@@ -299,6 +310,74 @@ def columns_in(flat: torch.Tensor, n_gates: int, n_vars: int) -> Columns:
                    v["var_values"].view(n_vars, 4))
 
 
+class _DevMem:
+    """device memory owned by the library, seen by torch through __cuda_array_interface__"""
+
+    def __init__(self, ptr: int, nwords: int):
+        self.__cuda_array_interface__ = {"shape": (nwords,), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+
+
+def _dev_words(ptr: int, nwords: int, device) -> torch.Tensor:
+    return torch.as_tensor(_DevMem(ptr, nwords), device=device)
+
+
+class _NativePipeline:
+    """pg_range_check_gather_pipeline_*: the whole double-buffered emit-while-gather loop runs inside the library (the path
+    a host without torch takes -- examples/c5_rank.c); this class only hands it the witnesses and turns the chunks it
+    delivers (device pointers) into tensors for a Python consumer."""
+
+    def __init__(self, engine, coll: "NativeCollective", min_range, max_range, chunk: int, variables_only: bool):
+        self.engine, self.coll, self.chunk = engine, coll, chunk
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        st = self._lib.pg_range_check_gather_pipeline_create(coll._h, C.byref(min_range.c), C.byref(max_range.c), chunk,
+                                                             1 if variables_only else 0, C.byref(h))
+        if st != 0:
+            raise PgError(st, "pg_range_check_gather_pipeline_create")
+        self._h = h
+
+    def bytes_per_chunk(self) -> int:
+        return int(self._lib.pg_range_check_gather_pipeline_bytes_per_chunk(self._h))
+
+    def run(self, witness_local: torch.Tensor, total_per_rank: int, gate_base: int, var_base: int, on_chunk):
+        """on_chunk(parts: list of (ColumnsC, n_gates, n_vars) per rank, chunk_index) is called from inside the run"""
+        failure = []
+
+        def cb(_user, k, world, parts, n_gates, n_vars, _stream):
+            if failure or on_chunk is None:
+                return
+            try:
+                on_chunk([parts[r] for r in range(world)], int(n_gates), int(n_vars), int(k))
+            except BaseException as ex:  # an exception must not unwind through the C frames
+                failure.append(ex)
+
+        fn = _lib.CHUNK_CONSUMER(cb)
+        st = self._lib.pg_range_check_gather_pipeline_run(self._h, witness_local.data_ptr(), total_per_rank, gate_base, var_base,
+                                                          fn, None, self.engine._stream())
+        if failure:
+            raise failure[0]
+        if st != 0:
+            raise PgError(st, "pg_range_check_gather_pipeline_run")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize(self.engine.device)
+            self._lib.pg_range_check_gather_pipeline_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _columns_from_c(pc, n_gates: int, n_vars: int, device) -> Columns:
+    sc = [_dev_words(getattr(pc, n), n_gates * 4, device).view(n_gates, 4) for n in Columns.SCALAR_COLS]
+    wc = [_dev_words(getattr(pc, n), n_gates, device) for n in Columns.WIRE_COLS]
+    return Columns(*sc, *wc, _dev_words(pc.var_values, n_vars * 4, device).view(n_vars, 4))
+
+
 class GatherPipeline:
     """Streaming sharded range_check with a single all-gather per chunk (packed buffer), double-buffered:
     while chunk k is on the links, chunk k+1 is being emitted.  `consume(gathered, chunk_index)` sees
@@ -311,6 +390,10 @@ class GatherPipeline:
         self.lay = engine.range_check_layout(min_range, max_range, chunk)
         _, _, self.words = packed_layout(self.lay.n_gates, self.lay.n_vars)
         dev = engine.device
+        self.native = None
+        if isinstance(self.coll, NativeCollective):  # the loop itself is the library's (pg_range_check_gather_pipeline_run)
+            self.native = _NativePipeline(engine, self.coll, min_range, max_range, chunk, variables_only=False)
+            return
         self.local = [torch.empty(self.words, dtype=torch.int64, device=dev) for _ in range(2)]
         self._gflat = [torch.empty(self.world * self.words, dtype=torch.int64, device=dev) for _ in range(2)]
         self.gathered = [g.view(self.world, self.words) for g in self._gflat]
@@ -327,6 +410,13 @@ class GatherPipeline:
         """witness_local: this rank's total_per_rank witnesses (a multiple of chunk).  Global numbering: rank r's
         item i is item r*total_per_rank + i of the whole batch."""
         assert total_per_rank % self.chunk == 0
+        if self.native is not None:
+            def on_chunk(parts, n_gates, n_vars, k):
+                # rank r's packed chunk starts at its q_m (the first section of the packed layout)
+                flat = _dev_words(parts[0].q_m, self.world * self.words, self.engine.device)
+                consume(flat.view(self.world, self.words), k)
+            self.native.run(witness_local, total_per_rank, gate_base, var_base, on_chunk if consume is not None else None)
+            return
         G, V = self.lay.gates_per_item, self.lay.vars_per_item
         pending = None
         for k in range(total_per_rank // self.chunk):
@@ -368,6 +458,10 @@ class VariablesOnlyPipeline:
         self.lay = engine.range_check_layout(min_range, max_range, chunk)
         G, V = self.lay.n_gates, self.lay.n_vars
         dev = engine.device
+        self.native = None
+        if isinstance(self.coll, NativeCollective):  # the loop itself is the library's (pg_range_check_gather_pipeline_run)
+            self.native = _NativePipeline(engine, self.coll, min_range, max_range, chunk, variables_only=True)
+            return
         # per double-buffer slot: rows of every rank's chunk, one gathered variable table, this rank's own table
         self.rows = [[Columns.allocate(G, 0, dev) for _ in range(self.world)] for _ in range(2)]
         self._vflat = [torch.empty(self.world * V * 4, dtype=torch.int64, device=dev) for _ in range(2)]
@@ -391,6 +485,11 @@ class VariablesOnlyPipeline:
     def run(self, witness_local: torch.Tensor, total_per_rank: int, gate_base: int = 0, var_base: int = 0, consume=None):
         """numbering as in GatherPipeline.run: rank r's item i is item r * total_per_rank + i of the whole batch"""
         assert total_per_rank % self.chunk == 0
+        if self.native is not None:
+            def on_chunk(parts, n_gates, n_vars, k):
+                consume([_columns_from_c(pc, n_gates, n_vars, self.engine.device) for pc in parts], k)
+            self.native.run(witness_local, total_per_rank, gate_base, var_base, on_chunk if consume is not None else None)
+            return
         G, V = self.lay.gates_per_item, self.lay.vars_per_item
         pending = None
         for k in range(total_per_rank // self.chunk):

@@ -184,6 +184,45 @@ def test_native_communicator_of_size_one(engine):
     lib.pg_comm_destroy(comm)
 
 
+def test_ragged_sharded_batch_through_the_c_abi(engine):
+    """pg_max_bound_ragged_sharded_plan / _batch with a communicator of one rank: plan, exchange of the totals, emission at
+    the numbering the exchange gives -- the same columns as the oracle's; and the Python layer's max_bound_ragged_sharded
+    through the same entry point"""
+    import bench
+    import plonk_gadgets_amd as pg
+    from oracle import pyoracle as po
+    from plonk_gadgets_amd import _lib, distributed as pd
+    lib = _lib.load()
+    batch = 300
+    mr_np, wt_np = bench.c4_inputs(batch, seed=0xC4)
+    mr, wt = (torch.from_numpy(np.ascontiguousarray(x).view(np.int64)).to("cuda:0") for x in (mr_np, wt_np))
+    ora = po.max_bound_batch(mr_np, wt_np)
+    coll = pd.NativeCollective(engine)
+    nb, roff, voff = engine.ragged_buffers(batch)
+    cols = pg.Columns.allocate(515 * batch, 517 * batch, "cuda:0", 3, 5)  # the worst case
+    res = torch.empty((batch,), dtype=torch.int64, device="cuda:0")
+    cc, s = cols.as_c(), _lib.ShardC()
+    st = lib.pg_max_bound_ragged_sharded_batch(coll._h, mr.data_ptr(), wt.data_ptr(), batch, nb.data_ptr(), roff.data_ptr(),
+                                               voff.data_ptr(), 3, 5, C.byref(cc), res.data_ptr(), C.byref(s), engine._stream())
+    assert st == 0, lib.pg_last_error()
+    torch.cuda.synchronize()
+    assert (s.rank, s.world, s.gate_base, s.var_base, s.n_gates, s.n_vars) == (0, 1, 3, 5, ora["n_gates"], ora["n_vars"])
+    got = cols.to_numpy()
+    for name in COLS:
+        n = ora["n_vars"] if name == "var_values" else ora["n_gates"]
+        assert np.array_equal(got[name][:n], ora[name]), name
+    assert np.array_equal(res.cpu().numpy().view(np.uint64), ora["result_vars"])
+    c2, r2, info, gates, vars_ = pd.max_bound_ragged_sharded(engine, mr, wt, 3, 5, collective=coll)
+    torch.cuda.synchronize()
+    assert (gates, vars_, info.gate_base, info.var_base) == ([ora["n_gates"]], [ora["n_vars"]], 3, 5)
+    got2 = c2.to_numpy()
+    for name in COLS:
+        assert np.array_equal(got2[name], ora[name]), name
+    assert lib.pg_max_bound_ragged_sharded_plan(None, mr.data_ptr(), batch, nb.data_ptr(), roff.data_ptr(), voff.data_ptr(), 3, 5,
+                                                C.byref(s), None, None, engine._stream()) == 2
+    coll.close()
+
+
 def _bench(args, env_extra=None, timeout=900):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(env_extra or {})
