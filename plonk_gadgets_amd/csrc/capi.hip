@@ -331,7 +331,11 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
             const uint64_t lanes = (elems + groups * GRP - 1) / (groups * GRP);
             const uint32_t blocks = (uint32_t)((lanes + pg::kThreads - 1) / pg::kThreads);
             // a handful of elements (the single-gadget calls of pg_composer): two event hops cost more than the overlap buys
+#if defined(PG_PREPASS_ON_CALLER_STREAM)  // A/B build: the pre-pass ahead of the emit launch on the caller's stream
+            side = false;
+#else
             side = elems >= 2048;
+#endif
             hipStream_t inv_st = st;
             if (side) {
                 PG_HIP_TRY(hipEventRecord(e->ev_fork, st));  // the pre-pass reads the call's inputs: order it after the stream

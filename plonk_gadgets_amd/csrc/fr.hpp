@@ -279,6 +279,15 @@ PG_HD Fr fr_invert_fermat(const Fr &a) {
 }
 
 // ---- inversion by division steps (Bernstein-Yang "safegcd", the 32-bit formulation with 30 steps per batch) ------
+// Algorithm: D. J. Bernstein, B.-Y. Yang, "Fast constant-time gcd computation and modular inversion" (TCHES 2019).  The
+// formulation used here -- numbers as nine signed 30-bit limbs, 30 division steps per batch summarised by a 2x2 matrix
+// (divsteps_30), the matrix applied to (f, g) exactly and to (d, e) modulo the prime (update_fg_30 / update_de_30), the
+// final normalize_30 -- is the one Pieter Wuille wrote for libsecp256k1 (src/modinv32.h / modinv32_impl.h, "modinv32",
+// MIT licence; explained in that project's doc/safegcd_implementation.md): same decomposition, same function roles and
+// names.  It is re-expressed here for the BLS12-381 scalar modulus (other limb constants; q^-1 mod 2^30 = 1 removes the
+// multiplication by the modular inverse), for Montgomery-form inputs, and for a GPU wave (the early exit when every lane
+// has reached g = 0, v_mad_i64_i32 spelt out).  Nothing of it comes from the reference, whose dependency inverts by a
+// Fermat power.
 // 20 batches of 30 branch-free division steps on (f, g) = (q, a) reduce g to 0 and f to +-1; every batch is
 // summarised by a 2x2 integer matrix that is then applied to the full-width (f, g) and, modulo q, to (d, e) with
 // d a = f, e a = g (mod q), so that at the end a^-1 = +-d.  600 steps cover any 256-bit input (590 suffice); the

@@ -25,7 +25,7 @@ VARIANTS = {
     "rows_prio3": ["-DPG_ROWS_SETPRIO=3"],      # the rows launch's waves at the highest issue priority
     "rows_prio1": ["-DPG_ROWS_SETPRIO=1"],
     # every emitter
-    "sequential_prepass": ["-DPG_SEQUENTIAL_PREPASS"],
+    "sequential_prepass": ["-DPG_PREPASS_ON_CALLER_STREAM"],  # big-item gadgets: pre-pass, then the emit launch, on one stream
     "invert_fermat": ["-DPG_INVERT_FERMAT"],
     "full_barriers": ["-DPG_FULL_BARRIERS"],
     "unaligned_sweeps": ["-DPG_UNALIGNED_SWEEPS"],  # generic sweeps start at the tile's first unit wherever it falls in a 128-byte line
