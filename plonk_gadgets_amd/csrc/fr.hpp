@@ -71,6 +71,99 @@ PG_HD Fr fr_final_sub(const uint64_t r[4], uint64_t top) {
     return Fr{{keep ? r[0] : d0, keep ? r[1] : d1, keep ? r[2] : d2, keep ? r[3] : d3}};
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950 forms of the carry chains: eight 32-bit words, ONE asm statement each (seen by the device pass only; host code
+// that names them in a .hip file is compiled from the generic forms below in the host pass).  Written through 128-bit integers (the host
+// forms below) the compiler emulates every 64-bit carry step with three or four 32-bit instructions and pads every
+// carry-in with an s_nop: 75 instructions for a subtraction that is 25.
+#define PG_W(x, i) ((uint32_t)((x).l[(i) >> 1] >> (32 * ((i) & 1))))
+PG_HD Fr fr_from_words(const uint32_t (&w)[8]) {
+    Fr o;
+#pragma unroll
+    for (int i = 0; i < 4; i++) o.l[i] = ((uint64_t)w[2 * i + 1] << 32) | w[2 * i];
+    return o;
+}
+
+// a - b mod q: subtract, then add q back under the mask of the final borrow
+PG_HD Fr fr_sub(const Fr &a, const Fr &b) {
+    uint32_t d[8], m;
+    asm("v_sub_co_u32 %0, vcc, %9, %17\n\t"
+        "v_subb_co_u32 %1, vcc, %10, %18, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %11, %19, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %12, %20, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %13, %21, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %14, %22, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %15, %23, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %16, %24, vcc\n\t"
+        "v_cndmask_b32 %8, 0, -1, vcc\n\t"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]), "=&v"(m)
+        : "v"(PG_W(a, 0)), "v"(PG_W(a, 1)), "v"(PG_W(a, 2)), "v"(PG_W(a, 3)), "v"(PG_W(a, 4)), "v"(PG_W(a, 5)), "v"(PG_W(a, 6)),
+          "v"(PG_W(a, 7)), "v"(PG_W(b, 0)), "v"(PG_W(b, 1)), "v"(PG_W(b, 2)), "v"(PG_W(b, 3)), "v"(PG_W(b, 4)), "v"(PG_W(b, 5)),
+          "v"(PG_W(b, 6)), "v"(PG_W(b, 7))
+        : "vcc");
+    // q = {0x00000001, 0xffffffff, 0xfffe5bfe, 0x53bda402, 0x09a1d805, 0x3339d808, 0x299d7d48, 0x73eda753}
+    uint32_t t[7];
+    t[0] = m & 1u;
+    t[1] = m & 0xfffe5bfeu; t[2] = m & 0x53bda402u; t[3] = m & 0x09a1d805u; t[4] = m & 0x3339d808u; t[5] = m & 0x299d7d48u;
+    t[6] = m & 0x73eda753u;
+    asm("v_add_co_u32 %0, vcc, %0, %8\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %2, %10, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %3, %11, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %4, %12, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, %5, %13, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %6, %14, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %7, %15, vcc\n\t"
+        : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7])
+        : "v"(t[0]), "v"(m), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6])
+        : "vcc");
+    return fr_from_words(d);
+}
+
+// r (eight words) + top * 2^256 < 2q  ->  r mod q: subtract q, keep r if that borrowed past the top
+PG_HD Fr fr_final_sub_words(const uint32_t (&r)[8], uint32_t top) {
+    uint32_t d[8], keep;
+    const uint32_t q2 = 0xfffe5bfeu, q3 = 0x53bda402u, q4 = 0x09a1d805u, q5 = 0x3339d808u, q6 = 0x299d7d48u, q7 = 0x73eda753u;
+    asm("v_sub_co_u32 %0, vcc, %9, 1\n\t"
+        "v_subb_co_u32 %1, vcc, %10, -1, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %11, %17, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %12, %18, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %13, %19, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %14, %20, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %15, %21, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %16, %22, vcc\n\t"
+        "v_cndmask_b32 %8, 0, -1, vcc\n\t"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]), "=&v"(keep)
+        : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "v"(q2), "v"(q3), "v"(q4),
+          "v"(q5), "v"(q6), "v"(q7)
+        : "vcc");
+    const bool below = keep != 0 && top == 0;  // borrowed past the top: r + top * 2^256 < q
+    uint32_t o[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[i] = below ? r[i] : d[i];
+    return fr_from_words(o);
+}
+
+PG_HD Fr fr_add(const Fr &a, const Fr &b) {
+    uint32_t r[8], top;
+    asm("v_add_co_u32 %0, vcc, %9, %17\n\t"
+        "v_addc_co_u32 %1, vcc, %10, %18, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %11, %19, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %12, %20, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %13, %21, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, %14, %22, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %15, %23, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %16, %24, vcc\n\t"
+        "v_cndmask_b32 %8, 0, 1, vcc\n\t"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(top)
+        : "v"(PG_W(a, 0)), "v"(PG_W(a, 1)), "v"(PG_W(a, 2)), "v"(PG_W(a, 3)), "v"(PG_W(a, 4)), "v"(PG_W(a, 5)), "v"(PG_W(a, 6)),
+          "v"(PG_W(a, 7)), "v"(PG_W(b, 0)), "v"(PG_W(b, 1)), "v"(PG_W(b, 2)), "v"(PG_W(b, 3)), "v"(PG_W(b, 4)), "v"(PG_W(b, 5)),
+          "v"(PG_W(b, 6)), "v"(PG_W(b, 7))
+        : "vcc");
+    return fr_final_sub_words(r, top);
+}
+#undef PG_W
+#else
 PG_HD Fr fr_add(const Fr &a, const Fr &b) {
     uint64_t c = 0, r[4];
     for (int i = 0; i < 4; i++) r[i] = adc64(a.l[i], b.l[i], c);
@@ -88,6 +181,7 @@ PG_HD Fr fr_sub(const Fr &a, const Fr &b) {
     o.l[3] = adc64(d[3], PG_Q3 & m, c);
     return o;
 }
+#endif
 
 PG_HD Fr fr_neg(const Fr &a) {
     uint64_t bw = 0;
@@ -209,12 +303,8 @@ __device__ __forceinline__ Fr fr_mul(const Fr &x, const Fr &y) {
         ex = 0;
     }
     r[7] = (uint32_t)acc;  // (column 15 has no products)
-    acc >>= 32;
-    // value = r + acc * 2^256 < 2q: one conditional subtraction
-    uint64_t t[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) t[i] = ((uint64_t)r[2 * i + 1] << 32) | r[2 * i];
-    return fr_final_sub(t, (uint64_t)(uint32_t)acc);
+    // value = r + top * 2^256 < 2q: one conditional subtraction
+    return fr_final_sub_words(r, (uint32_t)(acc >> 32));
 }
 #else
 PG_HD Fr fr_mul(const Fr &a, const Fr &b) { return fr_mul64(a, b); }
