@@ -227,9 +227,15 @@ PG_HD Fr fr_mul64(const Fr &a, const Fr &b) {
 // that the second reads the VCC the first wrote and pads with an s_nop; per product that was 360 of them in a loop body
 // with three multiplications, a quarter of its instructions.
 #define PG_MAC(p, q) "v_mad_u64_u32 %0, vcc, %" #p ", %" #q ", %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+// (the first product of a COLUMN starts the third word afresh: 0 + 0 + carry, so that nothing has to zero it)
+#define PG_MAC0(p, q) "v_mad_u64_u32 %0, vcc, %" #p ", %" #q ", %0\n\tv_addc_co_u32 %1, vcc, 0, 0, vcc\n\t"
 #define PG_MAC_FN(N, BODY, ...)                                                                               \
     __device__ __forceinline__ void mac96_##N(uint64_t &acc, uint32_t &ex, __VA_ARGS__) {                      \
         asm(BODY : "+v"(acc), "+v"(ex) : PG_MAC_IN_##N : "vcc");                                               \
+    }
+#define PG_MAC_FN0(N, BODY, ...)                                                                              \
+    __device__ __forceinline__ void mac96f_##N(uint64_t &acc, uint32_t &ex, __VA_ARGS__) {                     \
+        asm(BODY : "+v"(acc), "=&v"(ex) : PG_MAC_IN_##N : "vcc");                                              \
     }
 #define PG_MAC_IN_1 "v"(p0), "v"(q0)
 #define PG_MAC_IN_2 PG_MAC_IN_1, "v"(p1), "v"(q1)
@@ -251,11 +257,37 @@ PG_MAC_FN(7, PG_MAC(2, 3) PG_MAC(4, 5) PG_MAC(6, 7) PG_MAC(8, 9) PG_MAC(10, 11) 
           PG_U2(2), PG_U2(3), PG_U2(4), PG_U2(5), PG_U2(6))
 PG_MAC_FN(8, PG_MAC(2, 3) PG_MAC(4, 5) PG_MAC(6, 7) PG_MAC(8, 9) PG_MAC(10, 11) PG_MAC(12, 13) PG_MAC(14, 15) PG_MAC(16, 17), PG_U2(0),
           PG_U2(1), PG_U2(2), PG_U2(3), PG_U2(4), PG_U2(5), PG_U2(6), PG_U2(7))
+PG_MAC_FN0(1, PG_MAC0(2, 3), PG_U2(0))
+PG_MAC_FN0(2, PG_MAC0(2, 3) PG_MAC(4, 5), PG_U2(0), PG_U2(1))
+PG_MAC_FN0(3, PG_MAC0(2, 3) PG_MAC(4, 5) PG_MAC(6, 7), PG_U2(0), PG_U2(1), PG_U2(2))
+PG_MAC_FN0(4, PG_MAC0(2, 3) PG_MAC(4, 5) PG_MAC(6, 7) PG_MAC(8, 9), PG_U2(0), PG_U2(1), PG_U2(2), PG_U2(3))
+PG_MAC_FN0(5, PG_MAC0(2, 3) PG_MAC(4, 5) PG_MAC(6, 7) PG_MAC(8, 9) PG_MAC(10, 11), PG_U2(0), PG_U2(1), PG_U2(2), PG_U2(3), PG_U2(4))
+PG_MAC_FN0(6, PG_MAC0(2, 3) PG_MAC(4, 5) PG_MAC(6, 7) PG_MAC(8, 9) PG_MAC(10, 11) PG_MAC(12, 13), PG_U2(0), PG_U2(1), PG_U2(2), PG_U2(3),
+           PG_U2(4), PG_U2(5))
+PG_MAC_FN0(7, PG_MAC0(2, 3) PG_MAC(4, 5) PG_MAC(6, 7) PG_MAC(8, 9) PG_MAC(10, 11) PG_MAC(12, 13) PG_MAC(14, 15), PG_U2(0), PG_U2(1),
+           PG_U2(2), PG_U2(3), PG_U2(4), PG_U2(5), PG_U2(6))
+PG_MAC_FN0(8, PG_MAC0(2, 3) PG_MAC(4, 5) PG_MAC(6, 7) PG_MAC(8, 9) PG_MAC(10, 11) PG_MAC(12, 13) PG_MAC(14, 15) PG_MAC(16, 17), PG_U2(0),
+           PG_U2(1), PG_U2(2), PG_U2(3), PG_U2(4), PG_U2(5), PG_U2(6), PG_U2(7))
 #undef PG_U2
 
-// acc:ex += sum over i in [lo, hi] of x[i] * y[k - i]   (hi - lo < 8)
+// acc:ex += sum over i in [lo, hi] of x[i] * y[k - i]   (hi - lo < 8); FIRST: the column's first run (ex comes in as 0)
+template <bool FIRST = false>
 __device__ __forceinline__ void mac_run(const uint32_t (&x)[8], const uint32_t (&y)[8], int k, int lo, int hi, uint64_t &acc, uint32_t &ex) {
 #define PG_XY(j) x[lo + j], y[k - lo - j]
+    if constexpr (FIRST) {
+        switch (hi - lo + 1) {
+            case 1: mac96f_1(acc, ex, PG_XY(0)); break;
+            case 2: mac96f_2(acc, ex, PG_XY(0), PG_XY(1)); break;
+            case 3: mac96f_3(acc, ex, PG_XY(0), PG_XY(1), PG_XY(2)); break;
+            case 4: mac96f_4(acc, ex, PG_XY(0), PG_XY(1), PG_XY(2), PG_XY(3)); break;
+            case 5: mac96f_5(acc, ex, PG_XY(0), PG_XY(1), PG_XY(2), PG_XY(3), PG_XY(4)); break;
+            case 6: mac96f_6(acc, ex, PG_XY(0), PG_XY(1), PG_XY(2), PG_XY(3), PG_XY(4), PG_XY(5)); break;
+            case 7: mac96f_7(acc, ex, PG_XY(0), PG_XY(1), PG_XY(2), PG_XY(3), PG_XY(4), PG_XY(5), PG_XY(6)); break;
+            case 8: mac96f_8(acc, ex, PG_XY(0), PG_XY(1), PG_XY(2), PG_XY(3), PG_XY(4), PG_XY(5), PG_XY(6), PG_XY(7)); break;
+            default: break;
+        }
+        return;
+    }
     switch (hi - lo + 1) {
         case 1: mac96_1(acc, ex, PG_XY(0)); break;
         case 2: mac96_2(acc, ex, PG_XY(0), PG_XY(1)); break;
@@ -280,27 +312,30 @@ __device__ __forceinline__ Fr fr_mul(const Fr &x, const Fr &y) {
         b[2 * i] = (uint32_t)y.l[i]; b[2 * i + 1] = (uint32_t)(y.l[i] >> 32);
     }
     uint64_t acc = 0;
-    uint32_t ex = 0;
+    uint32_t ex;
     // columns 0..7 produce the quotient digits
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        mac_run(a, b, k, 0, k, acc, ex);
+        mac_run<true>(a, b, k, 0, k, acc, ex);
         if (k > 0) mac_run(m, Q, k, 0, k - 1, acc, ex);
-        m[k] = 0u - (uint32_t)acc;
-        // + m_k * q_0 = m_k zeroes the low word; then shift the accumulator down one word
-        const uint64_t s = acc + m[k];
-        const uint32_t c = (s < acc) ? 1u : 0u;
-        acc = (s >> 32) | ((uint64_t)(ex + c) << 32);
-        ex = 0;
+        // m_k = -lo; adding m_k * q_0 = m_k zeroes the low word (a carry iff lo != 0); then the accumulator moves down one word
+        uint32_t nlo, nhi;
+        asm("v_sub_u32 %0, 0, %3\n\t"
+            "v_cmp_ne_u32 vcc, 0, %3\n\t"
+            "v_addc_co_u32 %1, vcc, %4, 0, vcc\n\t"
+            "v_addc_co_u32 %2, vcc, %5, 0, vcc\n\t"
+            : "=&v"(m[k]), "=&v"(nlo), "=&v"(nhi)
+            : "v"((uint32_t)acc), "v"((uint32_t)(acc >> 32)), "v"(ex)
+            : "vcc");
+        acc = (uint64_t)nlo | ((uint64_t)nhi << 32);
     }
     // columns 8..15 are the result words
 #pragma unroll
     for (int k = 8; k < 15; k++) {
-        mac_run(a, b, k, k - 7, 7, acc, ex);
+        mac_run<true>(a, b, k, k - 7, 7, acc, ex);
         mac_run(m, Q, k, k - 7, 7, acc, ex);
         r[k - 8] = (uint32_t)acc;
         acc = (acc >> 32) | ((uint64_t)ex << 32);
-        ex = 0;
     }
     r[7] = (uint32_t)acc;  // (column 15 has no products)
     // value = r + top * 2^256 < 2q: one conditional subtraction
