@@ -485,10 +485,19 @@ def test_fuzz_very_ragged_max_bound(engine):
         assert engine.check_rows(cols) == -1
 
 
-@pytest.mark.parametrize("batch,zeros", [(1, (0,)), (700, (3, 77, 699)), (6000, (0, 64, 255, 256, 4096, 5999))])
+@pytest.mark.parametrize("batch,zeros", [
+    (1, (0,)), (31, ()), (33, (32,)), (700, (3, 77, 699)), (6000, (0, 64, 255, 256, 4096, 5999)),
+    # every step count of the launch that plans and inverts (a wave owns 32 x steps items): 65 536 items is the last batch with
+    # one step per wave, 70 000 the first with two and a ragged last wave
+    (65536, (0, 31, 32, 65535)), (70000, tuple(range(1000, 1040)) + (69999,)),
+    # beyond 2 M items the step count is capped and the launch has more workgroups than the chip holds at once: the look-back
+    # then crosses workgroups that start later
+    (2 * 1024 * 1024 + 12345, (0, 1, 1048576, 2097152, 2 * 1024 * 1024 + 12344) + tuple(range(5, 2 * 1024 * 1024, 65537))),
+])
 def test_planned_mix_call_matches_plan_then_emit(engine, batch, zeros):
-    """pg_scalar_mix_planned_batch (the plan launched by the call itself, beside the pre-pass for big batches) == the
-    synchronous plan followed by the emit call: offsets, totals, error mask, result Variables, every column"""
+    """pg_scalar_mix_planned_batch (the call plans itself: the launch that inverts makes the prefix sums by a look-back over
+    its waves) == the synchronous plan (the plan kernel) followed by the emit call: offsets, totals, error mask, result
+    Variables, every column"""
     import plonk_gadgets_amd as pg
     v, y, s, a, b = mix_inputs(batch, 13, zeros)
     ins = [dev(x) for x in (v, y, s, a, b)]
