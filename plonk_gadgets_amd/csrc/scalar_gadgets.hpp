@@ -463,49 +463,42 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
         }
     }
 
-    // ---- ONE inversion per workgroup ------------------------------------------------------------------------------
-    // The inversion is 20 k vector instructions against the 25 k of everything else a wave does here; a wave pays it
-    // whether one lane wants an inverse or sixty-four.  So the waves of a workgroup hand lane l's products to the first wave
-    // (through the LDS that will hold the images), which multiplies them up -- Montgomery's trick once more, across waves:
-    // running products from the left and from the right, 14 multiplications -- and inverts the product of all; every wave
-    // then takes its own inverse out with two multiplications.  While the first wave inverts the others wait at a
-    // barrier: seven idle waves cost nothing, eight inversions side by side cost eight times the energy.
+    // ---- one inversion per PAIR of waves --------------------------------------------------------------------------
+    // The inversion is 20 k vector instructions against the 25 k of everything else a wave does here, and a wave pays it
+    // whether one lane wants an inverse or sixty-four.  Waves w and w + 4 of the workgroup -- the two that share a SIMD --
+    // therefore share one: the upper wave hands its lanes' products to the lower one (through the LDS that will hold the
+    // images), which multiplies them to its own, inverts the product and takes the two inverses apart again (three
+    // multiplications); the upper wave waits at a barrier meanwhile.  Every SIMD then runs exactly one inversion, alone --
+    // the chain of dependent instructions that it is gains nothing from a second wave beside it, and one inversion for all
+    // eight waves (14 multiplications by a single wave first) measured 15 us slower.
     Fr accinv;
     {
-        uint4 *xch = &s_img[0][0];  // [kind][wave][half][lane]: 0 the waves' products, 1 products from the left, 2 from the right; then 1 / all
-        auto slot = [&](uint32_t kind, uint32_t w) { return xch + ((kind * kMixWaves + w) * 2) * 64 + lane; };
-        auto get = [&](uint32_t kind, uint32_t w) {
+        static_assert(kMixWaves == 8, "waves w and w + 4 pair up");
+        uint4 *xch = &s_img[0][0];  // [pair][half][lane]
+        const uint32_t pair = wave & 3;
+        uint4 *slot = xch + (pair * 2) * 64 + lane;
+        auto get = [&]() {
             FrVec t;
-            t.v[0] = slot(kind, w)[0];
-            t.v[1] = slot(kind, w)[64];
+            t.v[0] = slot[0];
+            t.v[1] = slot[64];
             return t.f;
         };
-        auto set = [&](uint32_t kind, uint32_t w, const Fr &x) {
+        auto set = [&](const Fr &x) {
             FrVec t;
             t.f = x;
-            slot(kind, w)[0] = t.v[0];
-            slot(kind, w)[64] = t.v[1];
+            slot[0] = t.v[0];
+            slot[64] = t.v[1];
         };
-        set(0, wave, acc);
+        if (wave >= 4) set(acc);
         __syncthreads();
-        if (wave == 0) {
-            Fr run = fr_one();
-#pragma unroll 1
-            for (uint32_t w = 0; w < kMixWaves; w++) {  // left[w] = product of the waves before w
-                set(1, w, run);
-                run = fr_mul(run, get(0, w));
-            }
-            const Fr all = run;
-            run = fr_one();
-#pragma unroll 1
-            for (uint32_t w = kMixWaves; w-- > 0;) {  // right[w] = product of the waves after w
-                set(2, w, run);
-                if (w) run = fr_mul(run, get(0, w));
-            }
-            set(3, 0, fr_invert_or_zero(all));  // (a product of non-zero elements, or mont(1))
+        if (wave < 4) {
+            const Fr other = get();
+            const Fr t = fr_invert_or_zero(fr_mul(acc, other));  // (a product of non-zero elements, or mont(1))
+            accinv = fr_mul(t, other);
+            set(fr_mul(t, acc));
         }
         __syncthreads();
-        accinv = fr_mul(fr_mul(get(3, 0), get(1, wave)), get(2, wave));
+        if (wave >= 4) accinv = get();
         __syncthreads();  // the exchange area is the images' from here on
     }
 
