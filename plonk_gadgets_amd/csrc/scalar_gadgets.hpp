@@ -367,10 +367,8 @@ struct MixPlan {
     uint32_t cap, nwaves;
 };
 
-#ifndef PG_MIX_WAVES
-#define PG_MIX_WAVES 8  // waves per workgroup = chains per inversion (8 x 15 KB of images: one workgroup per CU, two waves per SIMD)
-#endif
-constexpr int kMixWaves = PG_MIX_WAVES;
+// waves per workgroup: one workgroup per CU (8 x 15 KB of images), two waves per SIMD; waves w and w + 4 share an inversion
+constexpr int kMixWaves = 8;
 
 template <bool PLAN>
 __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_MIX_VARS_VGPRS))) void scalar_mix_vars_kernel(

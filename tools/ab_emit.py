@@ -19,8 +19,7 @@ VARIANTS = {
     "base": [],
     "prev": None,  # the commit before, built by hand (git stash; build(out=...); git stash pop)
     # the fused mix (C3)
-    "mix_waves4": ["-DPG_MIX_WAVES=4"],  # workgroups of 4 waves (two per CU, an inversion each) instead of 8
-    "mix_waves2": ["-DPG_MIX_WAVES=2"],
+    "mix_nomem": ["-DPG_MIX_ABLATE_MEM"],  # timing only (wrong output): the arithmetic launch without its global loads and stores
     "rows_wps4": ["-DPG_ROWS_WAVES_PER_SIMD=4"],  # the periodic rows launch allowed 128 registers
     "rows_prio3": ["-DPG_ROWS_SETPRIO=3"],      # the rows launch's waves at the highest issue priority
     "rows_prio1": ["-DPG_ROWS_SETPRIO=1"],
