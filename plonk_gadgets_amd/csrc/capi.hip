@@ -294,7 +294,7 @@ pg_status launch_mix(pg_engine *e, const pg::ScalarMixArgs &A, const pg_columns 
     uint4 *sink = e->d_prefix + e->inv_elems * 4;
     if (planned) {
         pg::MixPlan P = *planned;
-        P.nwaves = (uint32_t)waves;
+        P.nwaves = vgrid.x;  // (the look-back is over workgroups)
         hipLaunchKernelGGL(pg::scalar_mix_vars_kernel<true>, vgrid, vblock, 0, st, A, V, (uint32_t)ipl, e->d_prefix, sink, P);
     } else
         hipLaunchKernelGGL(pg::scalar_mix_vars_kernel<false>, vgrid, vblock, 0, st, A, V, (uint32_t)ipl, e->d_prefix, sink,
@@ -919,6 +919,14 @@ pg_status pg_scalar_mix_planned_batch(pg_engine *e, const pg_scalar *d_v, const 
     P.host = e->h_plan;
     return launch<pg::ScalarMixGD>(e, A, out, batch, gate_base, var_base, zero_var, d_row_off, d_var_off, stream, &P);
 }
+
+#if defined(PG_MIX_STAMPS)  // timing build only: ticks (100 MHz) the fused mix's waves spent per phase since the last call; not in the header
+extern "C" int pg_debug_mix_phases(unsigned long long out[8]) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pg::g_mix_phase_ticks), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(pg::g_mix_phase_ticks), zero, sizeof zero) == hipSuccess ? 0 : 1;
+}
+#endif
 
 pg_status pg_fill_bytes(pg_engine *e, void *d_dst, uint64_t bytes, uint32_t streams, uint64_t pattern, void *stream) {
     if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");

@@ -354,26 +354,39 @@ __device__ __forceinline__ void mix_put(uint4 *img, uint32_t slot, const Fr &x) 
 //
 // PLAN: the launch also makes the call's prefix sums (pg_scalar_mix_planned_batch), which are nothing but the count of
 // items with v = 0 before each item: rows before item i = 10 i - 2 e_i, variables 15 i - 2 e_i.  A wave counts its own in
-// the forward pass, publishes the count and adds up its predecessors' -- the single-pass scan of the plan kernels
-// (emit.hpp, plan_finish: one 64-bit word per wave that carries the count and two flag bits, touched by relaxed atomics
-// only; a wave waits for waves of lower index, which were dispatched before it; every wait is bounded; the last wave to
-// finish zeroes the words) -- while nothing else needs the result: it is first used in the backward pass, an inversion
-// later.  The offsets are written beside the variables, the totals by the wave that owns the last item.
+// the forward pass; the workgroup's last wave publishes the workgroup's count and adds up its predecessors' -- the
+// single-pass scan of the plan kernels (emit.hpp, plan_finish: one 64-bit word per workgroup that carries the count and two
+// flag bits, touched by relaxed atomics only; a workgroup waits for workgroups of lower index, which were dispatched
+// before it; every wait is bounded; the last one to finish zeroes the words) -- while the inversions run and it would
+// only wait.  The offsets are written beside the variables, the totals by the workgroup that owns the last item.
 struct MixPlan {
-    unsigned long long *agg;      // per wave: flags | count of failing items (zero between launches); [cap] = waves done
+    unsigned long long *agg;      // per workgroup: flags | count of failing items (zero between launches); [cap] = workgroups done
     uint64_t *row_off, *var_off;  // the call's outputs, batch + 1 entries each
     uint8_t *err_mask;            // per item: it stopped at is_non_zero's error (optional)
     PlanTotals *host;
-    uint32_t cap, nwaves;
+    uint32_t cap, nwaves;         // index of the done counter; workgroups of the launch
 };
 
 // waves per workgroup: one workgroup per CU (8 x 15 KB of images), two waves per SIMD; waves w and w + 4 share an inversion
 constexpr int kMixWaves = 8;
 
+#if defined(PG_MIX_STAMPS)  // timing build (tools/mix_phases.py): time the waves spend in each phase, summed over the launch
+__device__ unsigned long long g_mix_phase_ticks[8];
+#define PG_STAMP(k)                                                                                              \
+    do {                                                                                                         \
+        const unsigned long long now_ = wall_clock64();                                                          \
+        if (lane == 0) atomicAdd(&g_mix_phase_ticks[k], now_ - stamp_);                                          \
+        stamp_ = now_;                                                                                           \
+    } while (0)
+#else
+#define PG_STAMP(k) do {} while (0)
+#endif
+
 template <bool PLAN>
 __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_MIX_VARS_VGPRS))) void scalar_mix_vars_kernel(
     const ScalarMixArgs A, const EmitOut O, uint32_t ipl, uint4 *scratch, uint4 *sink, const MixPlan P) {
     __shared__ uint4 s_img[kMixWaves][32 * 15 * 2];
+    __shared__ uint64_t s_errs[kMixWaves], s_before;  // PLAN: failing items of the workgroup's waves, and before the workgroup
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 31;
     const bool bside = lane >= 32;  // the a - b side of item p
     const uint64_t gw = (uint64_t)blockIdx.x * kMixWaves + wave;  // the wave's index in the launch
@@ -387,6 +400,9 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
     uint4 *park = scratch + (bside ? O.batch : 0);  // [2][2][batch] 16-byte halves: a half-wave's store is 512 contiguous bytes
     sink += lane;
 
+#if defined(PG_MIX_STAMPS)
+    unsigned long long stamp_ = wall_clock64();
+#endif
     // ---- forward: running products ------------------------------------------------------------------------------
     Fr acc = fr_one();
     uint32_t errs = 0;  // PLAN: the wave's items with v = 0
@@ -426,41 +442,11 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
         }
     }
 
-    // ---- PLAN: failing items in the waves before this one (decoupled look-back, 64 predecessors per round) -----------
+    PG_STAMP(0);  // forward
+    // (PLAN: the failing items before this wave are counted while the inversions run, below)
     uint64_t errs_before = 0;
-    if (PLAN && ipl) {
-        if (lane == 0 && gw > 0) __hip_atomic_exchange(&P.agg[gw], kAggA | errs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bool gave_up = false;
-        int64_t back = (int64_t)gw - 1;
-        for (bool more = gw > 0; more; back -= 64) {
-            const int64_t j = back - (int64_t)lane;
-            unsigned long long w = kAggP;  // before wave 0: the empty prefix
-            if (j >= 0) {
-                w = plan_rmw_read(&P.agg[j]);
-                for (uint32_t polls = 0; !(w >> 62); w = plan_rmw_read(&P.agg[j])) {
-                    if (++polls > kPlanSpinLimit) { gave_up = true; w = kAggP; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            const uint64_t has_prefix = __ballot((w & kAggP) != 0);
-            const uint32_t first = has_prefix ? (uint32_t)__ffsll((unsigned long long)has_prefix) - 1 : 64u;  // the nearest one
-            errs_before += wave_sum(lane <= first ? w & 0xffffffffull : 0);
-            more = has_prefix == 0;
-        }
-        if (lane == 0) {
-            if (gave_up) P.host->pad = 1;
-            __hip_atomic_exchange(&P.agg[gw], kAggP | (errs_before + errs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (gw + 1 == P.nwaves) {  // the wave of the last item: the totals
-                const uint64_t e_all = errs_before + errs;
-                P.row_off[O.batch] = 10 * O.batch - 2 * e_all;
-                P.var_off[O.batch] = 15 * O.batch - 2 * e_all;
-                P.host->n_gates = 10 * O.batch - 2 * e_all;
-                P.host->n_vars = 15 * O.batch - 2 * e_all;
-                P.host->errs = (uint32_t)e_all;
-            }
-        }
-    }
 
+    PG_STAMP(1);  // look-back
     // ---- one inversion per PAIR of waves --------------------------------------------------------------------------
     // The inversion is 20 k vector instructions against the 25 k of everything else a wave does here, and a wave pays it
     // whether one lane wants an inverse or sixty-four.  Waves w and w + 4 of the workgroup -- the two that share a SIMD --
@@ -488,18 +474,73 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
             slot[64] = t.v[1];
         };
         if (wave >= 4) set(acc);
+        if (PLAN && lane == 0) s_errs[wave] = errs;  // (a wave without items counted none)
         __syncthreads();
         if (wave < 4) {
             const Fr other = get();
             const Fr t = fr_invert_or_zero(fr_mul(acc, other));  // (a product of non-zero elements, or mont(1))
             accinv = fr_mul(t, other);
             set(fr_mul(t, acc));
+        } else if (PLAN && wave == kMixWaves - 1) {
+            // PLAN: failing items in the WORKGROUPS before this one, by the last wave while it would only wait for its
+            // inverse: the decoupled look-back of the plan kernels, one word per workgroup, 64 predecessors per round.
+            // (Per wave instead -- 2048 words, every wave adding up its own predecessors ahead of the inversion -- it took
+            // every wave 21 us: thirty-two rounds of agent-scope atomics, all waves of the chip at once.)
+            const uint32_t b = blockIdx.x;
+            uint64_t mine = 0;
+#pragma unroll
+            for (int w = 0; w < kMixWaves; w++) mine += s_errs[w];
+            if (lane == 0 && b > 0) __hip_atomic_exchange(&P.agg[b], kAggA | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint64_t before = 0;
+            bool gave_up = false;
+            int64_t back = (int64_t)b - 1;
+            for (bool more = b > 0; more; back -= 64) {
+                const int64_t j = back - (int64_t)lane;
+                unsigned long long w = kAggP;  // before workgroup 0: the empty prefix
+                if (j >= 0) {
+                    w = plan_rmw_read(&P.agg[j]);
+                    for (uint32_t polls = 0; !(w >> 62); w = plan_rmw_read(&P.agg[j])) {
+                        if (++polls > kPlanSpinLimit) { gave_up = true; w = kAggP; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                const uint64_t has_prefix = __ballot((w & kAggP) != 0);
+                const uint32_t first = has_prefix ? (uint32_t)__ffsll((unsigned long long)has_prefix) - 1 : 64u;  // the nearest one
+                before += wave_sum(lane <= first ? w & 0xffffffffull : 0);
+                more = has_prefix == 0;
+            }
+            if (lane == 0) {
+                if (gave_up) P.host->pad = 1;
+                __hip_atomic_exchange(&P.agg[b], kAggP | (before + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_before = before;
+                if (b + 1 == P.nwaves) {  // the workgroup of the last item: the totals
+                    const uint64_t e_all = before + mine;
+                    P.row_off[O.batch] = 10 * O.batch - 2 * e_all;
+                    P.var_off[O.batch] = 15 * O.batch - 2 * e_all;
+                    P.host->n_gates = 10 * O.batch - 2 * e_all;
+                    P.host->n_vars = 15 * O.batch - 2 * e_all;
+                    P.host->errs = (uint32_t)e_all;
+                }
+            }
+            // the last workgroup to get here has every look-back behind it: the words go back to zero
+            unsigned long long done = 0;
+            if (lane == 0) done = __hip_atomic_fetch_add(&P.agg[P.cap], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            done = __shfl(done, 0, 64);
+            if (done == P.nwaves - 1) {
+                for (uint32_t j = lane; j < P.nwaves; j += 64) __hip_atomic_exchange(&P.agg[j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_exchange(&P.agg[P.cap], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         __syncthreads();
         if (wave >= 4) accinv = get();
+        if constexpr (PLAN) {  // before this wave = before the workgroup + in its earlier waves
+            errs_before = s_before;
+            for (uint32_t w = 0; w < wave; w++) errs_before += s_errs[w];
+        }
         __syncthreads();  // the exchange area is the images' from here on
     }
 
+    PG_STAMP(2);  // inversion (and waiting for it)
     // ---- backward: inverses, the item's variables, the image ------------------------------------------------------
     struct In {
         FrVec f0, f1, f2, pk;  // v y s | a b -, the parked product
@@ -612,15 +653,7 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
         c = n;
     }
     if (ipl) flush(0, 15);  // the wave's last image
-    if (PLAN && ipl) {  // the last wave to get here has every wave's look-back behind it: the words go back to zero
-        unsigned long long done = 0;
-        if (lane == 0) done = __hip_atomic_fetch_add(&P.agg[P.cap], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        done = __shfl(done, 0, 64);
-        if (done == P.nwaves - 1) {
-            for (uint32_t j = lane; j < P.nwaves; j += 64) __hip_atomic_exchange(&P.agg[j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lane == 0) __hip_atomic_exchange(&P.agg[P.cap], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    PG_STAMP(3);  // backward
 }
 
 __global__ __launch_bounds__(kThreads) void scalar_mix_plan_kernel(const uint4 *v_in, uint64_t batch, uint32_t *rows, uint32_t *vars,

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""tools/mix_phases.py -- on the GPU box, with tools/variants/lib_mix_stamps.so (python tools/ab_emit.py build mix_stamps):
+how long the waves of the fused mix's arithmetic launch spend in each phase (forward, look-back, inversion incl. waiting
+for it, backward), averaged over the waves of a 2^20-item launch."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from plonk_gadgets_amd import _lib
+import plonk_gadgets_amd as pg
+import bench
+
+lib = C.CDLL(os.path.join(ROOT, "tools", "variants", "lib_mix_stamps.so"))
+for fn, (r, a) in _lib.SIGNATURES.items():
+    if hasattr(lib, fn):
+        f = getattr(lib, fn)
+        f.restype, f.argtypes = r, a
+dev = torch.device("cuda", 0)
+n = 1 << 20
+ins = [torch.from_numpy(np.ascontiguousarray(x).view(np.int64)).to(dev) for x in bench.mix_inputs(n)]
+roff = torch.empty((n + 1,), dtype=torch.int64, device=dev)
+voff = torch.empty((n + 1,), dtype=torch.int64, device=dev)
+res = torch.empty((n, 2), dtype=torch.int64, device=dev)
+cols = pg.Columns.allocate(10 * n, 15 * n, dev)
+cc = cols.as_c()
+h = C.c_void_p()
+assert lib.pg_engine_create(0, C.byref(h)) == 0
+out = (C.c_ulonglong * 8)()
+for rep in range(6):
+    assert lib.pg_scalar_mix_planned_batch(h, *[t.data_ptr() for t in ins], n, roff.data_ptr(), voff.data_ptr(), None, 3, 5, 0,
+                                           C.byref(cc), res.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert lib.pg_debug_mix_phases(out) == 0
+    if rep:
+        waves = 2048
+        print("us per wave: forward %.1f  look-back %.1f  inversion %.1f  backward %.1f" % tuple(out[k] / waves / 100.0 for k in range(4)))
