@@ -407,38 +407,54 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
     Fr acc = fr_one();
     uint32_t errs = 0;  // PLAN: the wave's items with v = 0
     {
-        FrVec c0, c1, n0, n1;
+        // A forward step is short -- one multiplication, ~1.2 us with two waves per SIMD -- and a load from HBM is not: the
+        // elements are fetched THREE steps ahead into four sets of registers that take turns (the loop is unrolled by four so
+        // that no set is ever copied into another: a copy would make its step wait for the load it has just issued).  Steps
+        // past the wave's last one (ipl is rounded up to a multiple of four) fetch the last step again and change nothing.
+        FrVec b0[4], b1[4];
         auto fetch = [&](uint32_t m, FrVec &d0, FrVec &d1) {
+            m = m < ipl ? m : ipl - 1;
             uint64_t i = chunk0 + (uint64_t)m * 32 + p;
             i = i < last ? i : last;  // lanes past the end re-read the last item (masked below)
-#if defined(PG_MIX_ABLATE_MEM)  // timing only (wrong output): the launch without its global loads and stores
+#if defined(PG_MIX_ABLATE_MEM) || defined(PG_MIX_ABLATE_FWD_LOADS)  // timing only (wrong output): the launch without its global loads and stores
             d0.v[0] = d0.v[1] = d1.v[1] = make_uint4((uint32_t)i, m, 3, 4); d1.v[0] = make_uint4(m, 2, (uint32_t)i, 5);
 #else
             mix_load16(d0, in0, i);
             mix_load16(d1, fw1, i);
 #endif
         };
-        if (ipl) fetch(0, c0, c1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (uint32_t m = 0; m < ipl; m++) {
-            fetch(m + 1 < ipl ? m + 1 : m, n0, n1);  // (the last step fetches itself again: a fixed count, see above)
+        auto step = [&](uint32_t m, const FrVec &e0, const FrVec &e1) {
             const uint64_t i = chunk0 + (uint64_t)m * 32 + p;
-            const bool valid = i <= last;
+            const bool valid = m < ipl && i <= last;
             {
                 FrVec t;
                 t.f = acc;
-#if !defined(PG_MIX_ABLATE_MEM)
+#if !defined(PG_MIX_ABLATE_MEM) && !defined(PG_MIX_ABLATE_FWD_STORES)
                 store16(valid ? park + i : sink, t.v[0]);
                 store16(valid ? park + 2 * O.batch + i : sink, t.v[1]);
 #endif
             }
-            const Fr x = bside ? fr_sub(c0.f, c1.f) : c0.f;  // scalar.rs:121 / :73
+            const Fr x = bside ? fr_sub(e0.f, e1.f) : e0.f;  // scalar.rs:121 / :73
             const bool nz = valid && !fr_is_zero(x);
             if constexpr (PLAN) errs += (uint32_t)__popcll(__ballot(!bside && valid && !nz));  // scalar.rs:73-80
             const Fr t = fr_mul(acc, x);
             acc = fr_select(nz, t, acc);
-            c0 = n0;
-            c1 = n1;
+        };
+        if (ipl) {
+            fetch(0, b0[0], b1[0]);
+            fetch(1, b0[1], b1[1]);
+            fetch(2, b0[2], b1[2]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (uint32_t m = 0; m < ipl; m += 4) {
+            fetch(m + 3, b0[3], b1[3]);
+            step(m, b0[0], b1[0]);
+            fetch(m + 4, b0[0], b1[0]);
+            step(m + 1, b0[1], b1[1]);
+            fetch(m + 5, b0[1], b1[1]);
+            step(m + 2, b0[2], b1[2]);
+            fetch(m + 6, b0[2], b1[2]);
+            step(m + 3, b0[3], b1[3]);
         }
     }
 

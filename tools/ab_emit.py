@@ -20,6 +20,9 @@ VARIANTS = {
     "prev": None,  # the commit before, built by hand (git stash; build(out=...); git stash pop)
     # the fused mix (C3)
     "mix_stamps": ["-DPG_MIX_STAMPS"],  # timing build for tools/mix_phases.py
+    "mix_stamps_nomem": ["-DPG_MIX_STAMPS", "-DPG_MIX_ABLATE_MEM"],
+    "mix_stamps_nofwdld": ["-DPG_MIX_STAMPS", "-DPG_MIX_ABLATE_FWD_LOADS"],
+    "mix_stamps_nofwdst": ["-DPG_MIX_STAMPS", "-DPG_MIX_ABLATE_FWD_STORES"],
     "mix_nomem": ["-DPG_MIX_ABLATE_MEM"],  # timing only (wrong output): the arithmetic launch without its global loads and stores
     "rows_wps4": ["-DPG_ROWS_WAVES_PER_SIMD=4"],  # the periodic rows launch allowed 128 registers
     "rows_prio3": ["-DPG_ROWS_SETPRIO=3"],      # the rows launch's waves at the highest issue priority

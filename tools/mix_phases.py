@@ -14,7 +14,7 @@ from plonk_gadgets_amd import _lib
 import plonk_gadgets_amd as pg
 import bench
 
-lib = C.CDLL(os.path.join(ROOT, "tools", "variants", "lib_mix_stamps.so"))
+lib = C.CDLL(os.path.join(ROOT, "tools", "variants", "lib_%s.so" % (sys.argv[1] if len(sys.argv) > 1 else "mix_stamps")))
 for fn, (r, a) in _lib.SIGNATURES.items():
     if hasattr(lib, fn):
         f = getattr(lib, fn)
