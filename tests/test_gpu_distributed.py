@@ -220,6 +220,19 @@ def test_ragged_sharded_batch_through_the_c_abi(engine):
         assert np.array_equal(got2[name], ora[name]), name
     assert lib.pg_max_bound_ragged_sharded_plan(None, mr.data_ptr(), batch, nb.data_ptr(), roff.data_ptr(), voff.data_ptr(), 3, 5,
                                                 C.byref(s), None, None, engine._stream()) == 2
+    # the gather pipeline's argument checks: nothing aborts, nothing is launched
+    mn, mx = pg.BlsScalar.from_int(MN), pg.BlsScalar.from_int(MX)
+    h = C.c_void_p()
+    assert lib.pg_range_check_gather_pipeline_create(coll._h, C.byref(mn.c), C.byref(mx.c), 0, 0, C.byref(h)) == 2  # chunk 0
+    assert lib.pg_range_check_gather_pipeline_create(None, C.byref(mn.c), C.byref(mx.c), 8, 0, C.byref(h)) == 2
+    assert lib.pg_range_check_gather_pipeline_create(coll._h, C.byref(mn.c), C.byref(mx.c), 8, 1, C.byref(h)) == 0, lib.pg_last_error()
+    assert lib.pg_range_check_gather_pipeline_bytes_per_chunk(h) == 8 * engine.range_check_layout(mn, mx, 1).vars_per_item * 32
+    nothing = _lib.CHUNK_CONSUMER(lambda *a: None)
+    assert lib.pg_range_check_gather_pipeline_run(h, wt.data_ptr(), 12, 3, 5, nothing, None, engine._stream()) == 2  # not a multiple of the chunk
+    assert lib.pg_range_check_gather_pipeline_run(h, None, 8, 3, 5, nothing, None, engine._stream()) == 2
+    assert lib.pg_range_check_gather_pipeline_run(h, wt.data_ptr(), 0, 3, 5, nothing, None, engine._stream()) == 0  # an empty batch
+    lib.pg_range_check_gather_pipeline_destroy(h)
+    lib.pg_range_check_gather_pipeline_destroy(None)
     coll.close()
 
 
