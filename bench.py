@@ -50,8 +50,8 @@ PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_summary.json")
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2")
     ap.add_argument("--log2-batch", type=int, default=20, help="items per GPU per step = 2^this")
     ap.add_argument("--log2-chunk", type=int, default=-1, help="items per launch = 2^this (-1: largest that fits)")
