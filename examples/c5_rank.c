@@ -14,7 +14,8 @@
  * digest, in (chunk, rank, array) order, and prints it: all ranks print the same digest, which the test compares with the
  * CPU oracle's for the same witnesses (tests/test_c_example.py).
  *
- * Witness g of the whole batch is the integer splitmix64(g + 1) mod 2^(MAX_BITS + 1): about half are in range.
+ * Witness g of the whole batch is the integer splitmix64(g + 1) mod 2^(MAX_BITS + 1): about half are in range.  MAX_BITS
+ * defaults to 252 and may be at most 253 (a witness of 255 bits need not be below q).
  */
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
@@ -88,7 +89,11 @@ int main(int argc, char **argv) {
     const char *id_file = argv[3];
     const uint64_t total = strtoull(argv[4], NULL, 10), chunk = strtoull(argv[5], NULL, 10);
     const uint32_t variables_only = (uint32_t)atoi(argv[6]);
-    const unsigned max_bits = argc > 7 ? (unsigned)atoi(argv[7]) : 254;
+    const unsigned max_bits = argc > 7 ? (unsigned)atoi(argv[7]) : 252;  /* (witnesses have MAX_BITS + 1 bits and must stay below q, a 255-bit number) */
+    if (max_bits > 253) {
+        fprintf(stderr, "MAX_BITS must be at most 253: witnesses of MAX_BITS + 1 bits have to be canonical (below q)\n");
+        return 2;
+    }
     g_rank = (int)rank;
 
     int ndev = 0;

@@ -18,8 +18,24 @@ def build(force: bool = False) -> str:
            "-lamdhip64", f"-Wl,-rpath,{lib_dir}", f"-Wl,-rpath,{ora_dir}", "-Wl,-rpath,/opt/rocm/lib",
            "-Wl,-rpath,$ORIGIN/../../plonk_gadgets_amd", "-Wl,-rpath,$ORIGIN/../../oracle"]
     subprocess.check_call(cmd)
+    build_fake_rccl(force)
     return BIN
 
 
+FAKE_RCCL = os.path.join(HERE, "libfake_rccl.so")
+
+
+def build_fake_rccl(force: bool = False) -> str:
+    """tests/cpp/fake_rccl.c: the test-only collective the world-2-on-one-GPU tests load through PG_RCCL_LIB"""
+    src = os.path.join(HERE, "fake_rccl.c")
+    if not force and os.path.exists(FAKE_RCCL) and os.path.getmtime(src) < os.path.getmtime(FAKE_RCCL):
+        return FAKE_RCCL
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-shared", "-fPIC", "-D_DEFAULT_SOURCE", "-D__HIP_PLATFORM_AMD__",
+                           "-I", "/opt/rocm/include", src, "-L", "/opt/rocm/lib", "-lamdhip64", "-lrt", "-Wl,-rpath,/opt/rocm/lib",
+                           "-o", FAKE_RCCL])
+    return FAKE_RCCL
+
+
 if __name__ == "__main__":
+    print(build_fake_rccl(force=True))
     print(build(force=True))

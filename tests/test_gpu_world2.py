@@ -1,0 +1,94 @@
+"""GPU: the C-ABI multi-GPU slice with a world of TWO ranks on the box's ONE GPU.
+
+No box of the pool has two GPUs, and with a communicator of one rank the interesting branches of csrc/capi_dist.inc are
+dead code.  Here two fresh processes share device 0 and talk through tests/cpp/fake_rccl.c, a test-only collective the
+library loads through PG_RCCL_LIB (stream-ordered bounce through POSIX shared memory): a rehearsal of ordering and
+arithmetic -- other ranks' parts of a chunk, their regenerated rows, the totals exchange, bases of rank > 0 -- never a
+measurement.  BASELINE.json config 5's shape: contiguous witness shards, one all-gather per chunk, bit-exact vs the CPU
+oracle at the global numbering."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+import test_c_example as ce
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def fake_rccl():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "cpp"))
+    import build as cpp_build
+    return cpp_build.build_fake_rccl()
+
+
+def rank_env(extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(PG_RCCL_LIB=fake_rccl(), LOCAL_RANK="0", FAKE_RCCL_TIMEOUT_S="90", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra or {})
+    return env
+
+
+def run_ranks(cmds, env, timeout=420):
+    """starts one fresh child process per rank (nothing is re-exec'd), waits for all, kills the others when one fails"""
+    procs = [subprocess.Popen(c, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT) for c in cmds]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.communicate()
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        print(f"--- rank {r}: exit {p.returncode}\n{so}\n{se[-3000:]}")
+    return [(p.returncode, so, se) for p, (so, se) in zip(procs, outs)]
+
+
+@pytest.mark.parametrize("variables_only", [0, 1])
+@pytest.mark.parametrize("delay_us", [0, 20000])
+def test_c5_two_ranks_from_plain_c(tmp_path, variables_only, delay_us):
+    """examples/c5_rank.c twice (`0 2 ...` and `1 2 ...`), packed and variables-only: BOTH ranks print the digest the CPU
+    oracle gives for the two shards' chunks in (chunk, rank, array) order.  With a delay inside the collective (the data is
+    published 20 ms late) a consumer that did not wait for its chunk would fold stale bytes."""
+    binary = ce.C5_BIN if os.path.exists(ce.C5_BIN) else (ce.build() and ce.C5_BIN)
+    world, total, chunk, bits = 2, 192, 64, 18
+    ident = str(tmp_path / "comm.id")
+    res = run_ranks([[binary, str(r), str(world), ident, str(total), str(chunk), str(variables_only), str(bits)] for r in range(world)],
+                    rank_env({"FAKE_RCCL_DELAY_US": str(delay_us), "FAKE_RCCL_PIECE_BYTES": str(1 << 20)}))
+    want, words = ce.c5_oracle_digest(world, total, chunk, bits)
+    for r, (code, so, se) in enumerate(res):
+        assert code == 0, (r, se[-2000:])
+        line = so.strip().splitlines()[-1]
+        assert line.startswith(f"rank {r} of {world}: {total // chunk} chunks, {words} words"), line
+        assert line.endswith("digest %016x" % want), (r, line, "%016x" % want)
+
+
+def test_c5_rank_default_bits(tmp_path):
+    """the example's default MAX_BITS (advisor finding: 254 made ~9 % of the witnesses non-canonical and the program exit 1)"""
+    binary = ce.C5_BIN if os.path.exists(ce.C5_BIN) else (ce.build() and ce.C5_BIN)
+    p = subprocess.run([binary, "0", "1", str(tmp_path / "comm.id"), "64", "32", "1"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    want, words = ce.c5_oracle_digest(1, 64, 32, 252)
+    assert p.stdout.strip().endswith("digest %016x" % want), p.stdout
+    p = subprocess.run([binary, "0", "1", str(tmp_path / "comm2.id"), "64", "32", "1", "254"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "at most 253" in p.stderr
+
+
+def test_two_ranks_through_the_python_layer():
+    """tests/world2_rank.py twice: pg_allgather_bytes in several pieces, pg_allgather_columns with two parts, ragged shards
+    (uneven: 170 + 131 items; rank 1's bases = rank 0's totals; a failing plan on one rank fails both), and both forms of
+    config 5's pipeline with a consumer that compares every rank's part of every chunk with the oracle"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    res = run_ranks([[sys.executable, os.path.join(ROOT, "tests", "world2_rank.py"), str(r), "2", str(port)] for r in range(2)],
+                    rank_env({"FAKE_RCCL_PIECE_BYTES": str(1 << 20), "FAKE_RCCL_DELAY_US": "2000"}), timeout=900)
+    for r, (code, so, se) in enumerate(res):
+        assert code == 0 and f"rank {r} OK" in so, (r, se[-3000:])
