@@ -148,6 +148,31 @@ pg_status pg_range_check_batch(pg_engine *e, const pg_scalar *min_range, const p
 pg_status pg_range_check_structure_batch(pg_engine *e, const pg_scalar *min_range, const pg_scalar *max_range, uint64_t batch,
                                          uint64_t gate_base, uint64_t var_base, const pg_columns *out, void *stream);
 
+/* ---- witness refresh: the variable assignments of a batched call, and nothing else ---------------------------------
+ * The reference's prover flow builds a circuit once, preprocesses it, and then rebuilds the SAME circuit with other witnesses
+ * (prover.clear_witness(); gadget calls again; prove -- tests/scalar_gadgets_tests.rs:108-119, 168-177): selectors, wire
+ * indices and numbering are a function of the public inputs (the verifier builds them from other witnesses altogether, :36 vs
+ * :43), only the assignments change.  A *_values_batch call writes exactly what the full call writes into out->var_values --
+ * d_var_values[k] = the assignment of the call's k-th variable, limb for limb -- and touches no row: 32 B per variable instead
+ * of 184 B per row on top (33 of the 223 KB a 256-bit range_check item weighs).  Numbering does not enter (no gate_base /
+ * var_base: an assignment does not depend on its Variable's index). */
+pg_status pg_range_check_values_batch(pg_engine *e, const pg_scalar *min_range, const pg_scalar *max_range,
+                                      const pg_scalar *d_witness, uint64_t batch, pg_scalar *d_var_values, void *stream);
+pg_status pg_max_bound_values_batch(pg_engine *e, const pg_scalar *max_range, const pg_scalar *d_witness, uint64_t batch,
+                                    pg_scalar *d_var_values, void *stream);
+/* ragged: the plan of the bounds (pg_max_bound_ragged_plan) is public structure and is reused as it is */
+pg_status pg_max_bound_ragged_values_batch(pg_engine *e, const pg_scalar *d_max_range, const pg_scalar *d_witness, uint64_t batch,
+                                           const uint32_t *d_num_bits, const uint64_t *d_row_off, const uint64_t *d_var_off,
+                                           pg_scalar *d_var_values, void *stream);
+/* the fused mix: an item's SHAPE depends on its witness (is_non_zero stops at v = 0, src/scalar.rs:79), so the refresh plans
+ * again -- d_row_off / d_var_off / d_err_mask (may be NULL) are OUTPUTS as in pg_scalar_mix_planned_batch, the totals come
+ * from pg_plan_result -- and the caller compares them with the circuit it preprocessed: other totals or another error mask
+ * mean another circuit. */
+pg_status pg_scalar_mix_values_batch(pg_engine *e, const pg_scalar *d_v, const pg_scalar *d_y, const pg_scalar *d_s,
+                                     const pg_scalar *d_a, const pg_scalar *d_b, uint64_t batch, uint64_t *d_row_off,
+                                     uint64_t *d_var_off, uint8_t *d_err_mask /* may be NULL */, pg_scalar *d_var_values,
+                                     void *stream);
+
 /* pg_range_check_allocated_batch: the gadget alone, on witnesses that are ALREADY allocated --
  *     result[i] = range_check(composer, min, max, AllocatedScalar { var: d_witness_var[i], scalar: d_witness[i] });
  * 4n+11 rows and 2n+523 variables per item (no allocate). */

@@ -78,6 +78,11 @@ SIGNATURES = {
     "pg_scalars_to_canonical_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "pg_range_check_structure_batch": (C.c_int, [C.c_void_p, _P(Scalar), _P(Scalar), C.c_uint64, C.c_uint64, C.c_uint64, _P(ColumnsC),
                                                  C.c_void_p]),
+    "pg_range_check_values_batch": (C.c_int, [C.c_void_p, _P(Scalar), _P(Scalar), C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "pg_max_bound_values_batch": (C.c_int, [C.c_void_p, _P(Scalar), C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "pg_max_bound_ragged_values_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p]),
+    "pg_scalar_mix_values_batch": (C.c_int, [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pg_range_check_allocated_batch": (C.c_int, [C.c_void_p, _P(Scalar), _P(Scalar), C.c_void_p, C.c_void_p, C.c_uint64,
                                                  C.c_uint64, C.c_uint64, _P(ColumnsC), C.c_void_p, C.c_void_p]),
     "pg_max_bound_allocated_batch": (C.c_int, [C.c_void_p, _P(Scalar), C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,

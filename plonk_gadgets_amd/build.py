@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libplonk_gadgets_hip.so")
 SOURCES = ["capi.hip"]
-HEADERS = ["fr.hpp", "emit.hpp", "invert.hpp", "range_gadgets.hpp", "scalar_gadgets.hpp", "composer.hpp", "permutation.hpp",
+HEADERS = ["experiment.hpp", "fr.hpp", "emit.hpp", "invert.hpp", "range_gadgets.hpp", "scalar_gadgets.hpp", "composer.hpp", "permutation.hpp",
            "capi_composer.inc", "capi_dist.inc"]
 
 
@@ -41,17 +41,22 @@ def kernel_sources_sha256() -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, extra_flags: list[str] | None = None, out: str | None = None) -> str:
-    out = out or LIB
-    if not force and out == LIB and not is_stale():
-        return out
+def command(out: str, csrc: str = CSRC, extra_flags: list[str] | None = None) -> list[str]:
+    """the compiler command line of the library: NO -DPG_... option (csrc/experiment.hpp: those are tools/ab_emit.py's A/B
+    builds, which pass them -- and -DPG_EXPERIMENT -- as extra_flags)"""
     cc = hipcc()
     # ROCm's include directory (only for <rccl/rccl.h>, which capi_dist.inc can do without): beside the compiler, or $ROCM_PATH
     rocm = os.environ.get("ROCM_PATH") or os.path.dirname(os.path.dirname(os.path.realpath(cc)))
     inc = ["-I" + os.path.join(rocm, "include")] if os.path.isdir(os.path.join(rocm, "include")) else []
-    cmd = [cc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"] + inc + [
-           "-o", out] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"] + (extra_flags or [])
-    subprocess.check_call(cmd)
+    return [cc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"] + inc + [
+            "-o", out] + [os.path.join(csrc, s) for s in SOURCES] + ["-ldl"] + (extra_flags or [])
+
+
+def build(force: bool = False, extra_flags: list[str] | None = None, out: str | None = None, csrc: str = CSRC) -> str:
+    out = out or LIB
+    if not force and out == LIB and not is_stale():
+        return out
+    subprocess.check_call(command(out, csrc, extra_flags))
     return out
 
 

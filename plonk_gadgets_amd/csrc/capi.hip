@@ -230,7 +230,7 @@ pg_status ensure_inv_scratch(pg_engine *e, uint64_t elems) {
     if (e->d_prefix) { (void)hipFree(e->d_prefix); e->d_prefix = nullptr; }
     e->inv_elems = 0;
     // per element: the element and its running product; + 64 x 16 bytes that the fused mix's masked lanes store to
-    PG_HIP_TRY(hipMalloc(&e->d_prefix, (elems * 4 + 64) * sizeof(uint4)));
+    PG_HIP_TRY(hipMalloc(&e->d_prefix, (elems * 4 + 64 + 4 * 32 * 32 * 8) * sizeof(uint4)));  // (+ the fused mix's last workgroup: whole steps of whole waves)
     e->inv_elems = elems;
     return PG_OK;
 }
@@ -277,7 +277,7 @@ pg_status enter_stream(pg_engine *e, hipStream_t st) {
 // engine's plan totals); otherwise it reads them.
 pg_status launch_mix(pg_engine *e, const pg::ScalarMixArgs &A, const pg_columns *c, uint64_t batch, uint64_t gate_base,
                      uint64_t var_base, uint64_t zero_var, const uint64_t *row_off, const uint64_t *var_off, hipStream_t st,
-                     const pg::MixPlan *planned) {
+                     const pg::MixPlan *planned, bool values_only = false) {
     using GD = pg::ScalarMixGD;
     PG_TRY(ensure_inv_scratch(e, batch));
     // geometry of the arithmetic launch: a wave owns 32 * ipl consecutive items; two waves per SIMD is what it is built for
@@ -291,7 +291,7 @@ pg_status launch_mix(pg_engine *e, const pg::ScalarMixArgs &A, const pg_columns 
     const uint32_t max_blocks = (uint32_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
     const dim3 grid(R.tiles < max_blocks ? R.tiles : max_blocks), vgrid((uint32_t)((waves + pg::kMixWaves - 1) / pg::kMixWaves));
     const dim3 vblock(pg::kMixWaves * 64);
-    uint4 *sink = e->d_prefix + e->inv_elems * 4;
+    uint4 *sink = e->d_prefix + e->inv_elems * 4 + 4 * 32 * 32 * 8;
     if (planned) {
         pg::MixPlan P = *planned;
         P.nwaves = vgrid.x;  // (the look-back is over workgroups)
@@ -299,6 +299,10 @@ pg_status launch_mix(pg_engine *e, const pg::ScalarMixArgs &A, const pg_columns 
     } else
         hipLaunchKernelGGL(pg::scalar_mix_vars_kernel<false>, vgrid, vblock, 0, st, A, V, (uint32_t)ipl, e->d_prefix, sink,
                            pg::MixPlan{});
+    if (values_only) {  // a witness refresh: the variable table (and, planned, the prefix sums) alone
+        PG_HIP_TRY(hipGetLastError());
+        return PG_OK;
+    }
     hipLaunchKernelGGL(pg::rows_periodic_kernel<GD>, grid, dim3(pg::kThreads), 0, st, A, R);
     // the tiles that hold an item of another shape (none, unless an item stopped at its error): every other workgroup of
     // this launch reads two offsets and leaves
@@ -307,15 +311,21 @@ pg_status launch_mix(pg_engine *e, const pg::ScalarMixArgs &A, const pg_columns 
     return PG_OK;
 }
 
+// gadgets whose witness refresh (EMIT_VALUES: the variable assignments alone) is exported
+template <class GD> struct ValuesMode { static constexpr bool ok = false; };
+template <> struct ValuesMode<pg::RangeCheckGD> { static constexpr bool ok = true; };
+template <> struct ValuesMode<pg::MaxBoundGD<false>> { static constexpr bool ok = true; };
+template <> struct ValuesMode<pg::MaxBoundGD<true>> { static constexpr bool ok = true; };
+
 template <class GD>
 pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, uint64_t batch, uint64_t gate_base,
                  uint64_t var_base, uint64_t zero_var, const uint64_t *row_off, const uint64_t *var_off, void *stream,
-                 const pg::MixPlan *planned = nullptr) {
+                 const pg::MixPlan *planned = nullptr, bool values_only = false) {
     if ((batch + GD::W - 1) / GD::W > 0xffffffffull) return fail(PG_ERR_INVALID_ARGUMENT, "batch too large for one call");
     hipStream_t st = static_cast<hipStream_t>(stream);
     PG_TRY(enter_stream(e, st));
     if constexpr (pg::Split<GD>::ok) {
-        return launch_mix(e, A, c, batch, gate_base, var_base, zero_var, row_off, var_off, st, planned);
+        return launch_mix(e, A, c, batch, gate_base, var_base, zero_var, row_off, var_off, st, planned, values_only);
     } else {
         pg::EmitOut O = make_out(c, batch, GD::W, gate_base, var_base, zero_var, row_off, var_off);
         bool side = false;  // the inversion pre-pass runs on the engine's side stream
@@ -330,12 +340,12 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
             const uint64_t groups = (per_lane + GRP - 1) / GRP;  // a lane owns groups * GRP elements
             const uint64_t lanes = (elems + groups * GRP - 1) / (groups * GRP);
             const uint32_t blocks = (uint32_t)((lanes + pg::kThreads - 1) / pg::kThreads);
-            // a handful of elements (the single-gadget calls of pg_composer): two event hops cost more than the overlap buys
-#if defined(PG_PREPASS_ON_CALLER_STREAM)  // A/B build: the pre-pass ahead of the emit launch on the caller's stream
-            side = false;
-#else
-            side = elems >= 2048;
-#endif
+            // a handful of elements (the single-gadget calls of pg_composer): two event hops cost more than the overlap buys.
+            // A big call (an emit launch of milliseconds): the pre-pass goes FIRST on the caller's stream -- beside the
+            // emitter its round trips crawl through a saturated memory system and it ends with the emitter (17.58 of 17.64 ms
+            // at 2^20 ragged max_bound items), one wave per SIMD taken from the store stream all the while; alone it takes
+            // 0.15 ms and the step is the same within 0.4 % (profiles/NOTES_r04.md, tools/c4_timeline.sh).
+            side = elems >= 2048 && elems < (1ull << 18);
             hipStream_t inv_st = st;
             if (side) {
                 PG_HIP_TRY(hipEventRecord(e->ev_fork, st));  // the pre-pass reads the call's inputs: order it after the stream
@@ -348,7 +358,13 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
             if (side) PG_HIP_TRY(hipEventRecord(e->ev_inv, e->side));
         }
         const uint32_t max_blocks = (uint32_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
-        hipLaunchKernelGGL(pg::emit_kernel<GD>, dim3(O.tiles < max_blocks ? O.tiles : max_blocks), dim3(pg::kThreads), 0, st, A, O);
+        const dim3 egrid(O.tiles < max_blocks ? O.tiles : max_blocks);
+        if (values_only) {
+            if constexpr (ValuesMode<GD>::ok) hipLaunchKernelGGL((pg::emit_kernel<GD, pg::EMIT_VALUES>), egrid, dim3(pg::kThreads), 0, st, A, O);
+            else return fail(PG_ERR_INVALID_ARGUMENT, "this gadget has no values-only emission");
+        } else {
+            hipLaunchKernelGGL(pg::emit_kernel<GD>, egrid, dim3(pg::kThreads), 0, st, A, O);
+        }
         PG_HIP_TRY(hipGetLastError());
         if (side) PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_inv, 0));  // join
         return PG_OK;
@@ -589,7 +605,7 @@ pg_status pg_range_check_layout(const pg_scalar *min_range, const pg_scalar *max
 static pg_status range_check_common(pg_engine *e, const pg_scalar *min_range, const pg_scalar *max_range,
                                     const pg_variable *d_witness_var, const pg_scalar *d_witness, uint64_t batch,
                                     uint64_t gate_base, uint64_t var_base, const pg_columns *out,
-                                    pg_variable *d_result_vars, void *stream) {
+                                    pg_variable *d_result_vars, void *stream, bool values_only = false) {
     if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
     pg_layout lay;
     PG_TRY(pg_range_check_layout(min_range, max_range, batch, &lay));
@@ -606,7 +622,21 @@ static pg_status range_check_common(pg_engine *e, const pg_scalar *min_range, co
     A.witness_vars = d_witness_var;
     A.result_vars = d_result_vars;
     A.pow2 = e->d_pow2;
-    return launch<pg::RangeCheckGD>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream);
+    return launch<pg::RangeCheckGD>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream, nullptr, values_only);
+}
+
+// a witness refresh's `out`: only var_values is written (EMIT_VALUES); the row pointers merely have to pass the checks
+static pg_columns values_columns(pg_scalar *d_var_values) {
+    pg_columns c;
+    c.q_m = c.q_l = c.q_r = c.q_o = c.q_c = c.var_values = d_var_values;
+    c.w_l = c.w_r = c.w_o = reinterpret_cast<uint64_t *>(d_var_values);
+    return c;
+}
+
+pg_status pg_range_check_values_batch(pg_engine *e, const pg_scalar *min_range, const pg_scalar *max_range, const pg_scalar *d_witness,
+                                      uint64_t batch, pg_scalar *d_var_values, void *stream) {
+    const pg_columns c = values_columns(d_var_values);
+    return range_check_common(e, min_range, max_range, nullptr, d_witness, batch, 0, 0, &c, nullptr, stream, true);
 }
 
 pg_status pg_range_check_structure_batch(pg_engine *e, const pg_scalar *min_range, const pg_scalar *max_range, uint64_t batch,
@@ -698,7 +728,7 @@ pg_status pg_max_bound_layout(const pg_scalar *max_range, uint64_t batch, pg_lay
 
 static pg_status max_bound_common(pg_engine *e, const pg_scalar *max_range, const pg_variable *d_witness_var,
                                   const pg_scalar *d_witness, uint64_t batch, uint64_t gate_base, uint64_t var_base,
-                                  const pg_columns *out, pg_variable *d_result_vars, void *stream) {
+                                  const pg_columns *out, pg_variable *d_result_vars, void *stream, bool values_only = false) {
     if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
     pg_layout lay;
     PG_TRY(pg_max_bound_layout(max_range, batch, &lay));
@@ -713,7 +743,13 @@ static pg_status max_bound_common(pg_engine *e, const pg_scalar *max_range, cons
     A.witness_vars = d_witness_var;
     A.result_vars = d_result_vars;
     A.pow2 = e->d_pow2;
-    return launch<pg::MaxBoundGD<false>>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream);
+    return launch<pg::MaxBoundGD<false>>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream, nullptr, values_only);
+}
+
+pg_status pg_max_bound_values_batch(pg_engine *e, const pg_scalar *max_range, const pg_scalar *d_witness, uint64_t batch,
+                                    pg_scalar *d_var_values, void *stream) {
+    const pg_columns c = values_columns(d_var_values);
+    return max_bound_common(e, max_range, nullptr, d_witness, batch, 0, 0, &c, nullptr, stream, true);
 }
 
 pg_status pg_max_bound_batch(pg_engine *e, const pg_scalar *max_range, const pg_scalar *d_witness, uint64_t batch,
@@ -776,10 +812,10 @@ pg_status pg_plan_result(pg_engine *e, pg_layout *out, uint64_t *err_count) {
                            : PG_OK;
 }
 
-pg_status pg_max_bound_ragged_batch(pg_engine *e, const pg_scalar *d_max_range, const pg_scalar *d_witness, uint64_t batch,
-                                    const uint32_t *d_num_bits, const uint64_t *d_row_off, const uint64_t *d_var_off,
-                                    uint64_t gate_base, uint64_t var_base, const pg_columns *out,
-                                    pg_variable *d_result_vars, void *stream) {
+static pg_status max_bound_ragged_common(pg_engine *e, const pg_scalar *d_max_range, const pg_scalar *d_witness, uint64_t batch,
+                                         const uint32_t *d_num_bits, const uint64_t *d_row_off, const uint64_t *d_var_off,
+                                         uint64_t gate_base, uint64_t var_base, const pg_columns *out,
+                                         pg_variable *d_result_vars, void *stream, bool values_only) {
     if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
     if (batch == 0) return PG_OK;
     PG_TRY(check_scalars(d_max_range, "d_max_range"));
@@ -795,7 +831,22 @@ pg_status pg_max_bound_ragged_batch(pg_engine *e, const pg_scalar *d_max_range, 
     A.witness = reinterpret_cast<const uint4 *>(d_witness);
     A.result_vars = d_result_vars;
     A.pow2 = e->d_pow2;
-    return launch<pg::MaxBoundGD<true>>(e, A, out, batch, gate_base, var_base, 0, d_row_off, d_var_off, stream);
+    return launch<pg::MaxBoundGD<true>>(e, A, out, batch, gate_base, var_base, 0, d_row_off, d_var_off, stream, nullptr, values_only);
+}
+
+pg_status pg_max_bound_ragged_batch(pg_engine *e, const pg_scalar *d_max_range, const pg_scalar *d_witness, uint64_t batch,
+                                    const uint32_t *d_num_bits, const uint64_t *d_row_off, const uint64_t *d_var_off,
+                                    uint64_t gate_base, uint64_t var_base, const pg_columns *out,
+                                    pg_variable *d_result_vars, void *stream) {
+    return max_bound_ragged_common(e, d_max_range, d_witness, batch, d_num_bits, d_row_off, d_var_off, gate_base, var_base, out,
+                                   d_result_vars, stream, false);
+}
+
+pg_status pg_max_bound_ragged_values_batch(pg_engine *e, const pg_scalar *d_max_range, const pg_scalar *d_witness, uint64_t batch,
+                                           const uint32_t *d_num_bits, const uint64_t *d_row_off, const uint64_t *d_var_off,
+                                           pg_scalar *d_var_values, void *stream) {
+    const pg_columns c = values_columns(d_var_values);
+    return max_bound_ragged_common(e, d_max_range, d_witness, batch, d_num_bits, d_row_off, d_var_off, 0, 0, &c, nullptr, stream, true);
 }
 
 /* ---- scalar gadgets ------------------------------------------------------- */
@@ -890,10 +941,11 @@ pg_status pg_scalar_mix_batch(pg_engine *e, const pg_scalar *d_v, const pg_scala
     return launch<pg::ScalarMixGD>(e, A, out, batch, gate_base, var_base, zero_var, d_row_off, d_var_off, stream);
 }
 
-pg_status pg_scalar_mix_planned_batch(pg_engine *e, const pg_scalar *d_v, const pg_scalar *d_y, const pg_scalar *d_s,
-                                      const pg_scalar *d_a, const pg_scalar *d_b, uint64_t batch, uint64_t *d_row_off,
-                                      uint64_t *d_var_off, uint8_t *d_err_mask, uint64_t gate_base, uint64_t var_base,
-                                      pg_variable zero_var, const pg_columns *out, pg_variable *d_result_vars, void *stream) {
+static pg_status scalar_mix_planned_common(pg_engine *e, const pg_scalar *d_v, const pg_scalar *d_y, const pg_scalar *d_s,
+                                           const pg_scalar *d_a, const pg_scalar *d_b, uint64_t batch, uint64_t *d_row_off,
+                                           uint64_t *d_var_off, uint8_t *d_err_mask, uint64_t gate_base, uint64_t var_base,
+                                           pg_variable zero_var, const pg_columns *out, pg_variable *d_result_vars, void *stream,
+                                           bool values_only) {
     if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
     if (batch == 0) return pg_scalar_mix_plan_async(e, d_v, 0, d_row_off, d_var_off, d_err_mask, stream);
     const pg_scalar *in[5] = {d_v, d_y, d_s, d_a, d_b};
@@ -917,7 +969,23 @@ pg_status pg_scalar_mix_planned_batch(pg_engine *e, const pg_scalar *d_v, const 
     P.var_off = d_var_off;
     P.err_mask = d_err_mask;
     P.host = e->h_plan;
-    return launch<pg::ScalarMixGD>(e, A, out, batch, gate_base, var_base, zero_var, d_row_off, d_var_off, stream, &P);
+    return launch<pg::ScalarMixGD>(e, A, out, batch, gate_base, var_base, zero_var, d_row_off, d_var_off, stream, &P, values_only);
+}
+
+pg_status pg_scalar_mix_planned_batch(pg_engine *e, const pg_scalar *d_v, const pg_scalar *d_y, const pg_scalar *d_s,
+                                      const pg_scalar *d_a, const pg_scalar *d_b, uint64_t batch, uint64_t *d_row_off,
+                                      uint64_t *d_var_off, uint8_t *d_err_mask, uint64_t gate_base, uint64_t var_base,
+                                      pg_variable zero_var, const pg_columns *out, pg_variable *d_result_vars, void *stream) {
+    return scalar_mix_planned_common(e, d_v, d_y, d_s, d_a, d_b, batch, d_row_off, d_var_off, d_err_mask, gate_base, var_base, zero_var,
+                                     out, d_result_vars, stream, false);
+}
+
+pg_status pg_scalar_mix_values_batch(pg_engine *e, const pg_scalar *d_v, const pg_scalar *d_y, const pg_scalar *d_s,
+                                     const pg_scalar *d_a, const pg_scalar *d_b, uint64_t batch, uint64_t *d_row_off,
+                                     uint64_t *d_var_off, uint8_t *d_err_mask, pg_scalar *d_var_values, void *stream) {
+    const pg_columns c = values_columns(d_var_values);
+    return scalar_mix_planned_common(e, d_v, d_y, d_s, d_a, d_b, batch, d_row_off, d_var_off, d_err_mask, 0, 0, 0, &c, nullptr, stream,
+                                     true);
 }
 
 #if defined(PG_MIX_STAMPS)  // timing build only: ticks (100 MHz) the fused mix's waves spent per phase since the last call; not in the header

@@ -184,12 +184,16 @@ constexpr uint32_t periodic_wire_lanes(uint32_t R) {
 //                   per-item shape (GD::RowRec, GD::item_rows), over tiles of GD::kRowsW items.  For a periodic gadget
 //                   (below) this launch writes only the tiles that hold an item of another shape; the full-shape tiles --
 //                   all of them, unless an item stopped at its error -- are rows_periodic_kernel's
-// A gadget with GD::kSplit (small items: the fused mix) is emitted as rows launches beside ONE launch of its own that
-// inverts and writes the variable table (scalar_gadgets.hpp, scalar_mix_vars_kernel): for small items the all-in-one
+//   EMIT_VALUES     the variable assignments alone (item phase + variable sweep; the pre-pass still writes the inverse slots):
+//                   what changes when the SAME circuit is rebuilt with other witnesses -- the reference's prover flow
+//                   after clear_witness() (tests/scalar_gadgets_tests.rs:108-119); 33 of the 223 KB a 256-bit range_check
+//                   item weighs
+// A gadget with GD::kSplit (small items: the fused mix) is emitted as ONE launch of its own that inverts and writes the
+// variable table (scalar_gadgets.hpp, scalar_mix_vars_kernel), followed on the same stream by rows launches: for small items the all-in-one
 // launch is a poor streaming writer -- its tile is bounded by the LDS the item records take (64 items = 148 KB of output
 // for the fused mix), so a workgroup's global round trips before its first store are never amortised -- while four
 // fifths of its bytes (the rows) need no record at all.
-enum EmitMode : int { EMIT_ALL = 0, EMIT_STRUCTURE = 1, EMIT_ROWS = 2 };
+enum EmitMode : int { EMIT_ALL = 0, EMIT_STRUCTURE = 1, EMIT_ROWS = 2, EMIT_VALUES = 3 };
 
 template <class GD, class = void>
 struct Split {
@@ -216,7 +220,8 @@ struct EmitShape<GD, EMIT_ROWS> {
 template <class GD, int MODE = EMIT_ALL>
 __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(const typename GD::Args A, const EmitOut O) {
     static_assert(MODE != EMIT_STRUCTURE || !(GD::kRagged || GD::kRecInRows), "rows of this gadget depend on its inputs");
-    constexpr bool kVars = MODE == EMIT_ALL;  // item arithmetic and the variable sweep
+    constexpr bool kVars = MODE == EMIT_ALL || MODE == EMIT_VALUES;  // item arithmetic and the variable sweep
+    constexpr bool kRows = MODE != EMIT_VALUES;                      // selector and wire sweeps
     constexpr int W = EmitShape<GD, MODE>::W;
     using Rec = typename EmitShape<GD, MODE>::Rec;
     constexpr uint32_t kTable = GD::kUsePow2 ? kTableEntries : T_POW;  // gadgets without a ladder need the 8 constants only
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
         constexpr uint32_t kUniR = UniformShape<GD>::rows, kUniV = UniformShape<GD>::vars;
         const bool uni_rows = kUniR != 0 && total_rows == Wt * kUniR, uni_vars = kUniV != 0 && total_vars == Wt * kUniV;
 
-        {
+        if constexpr (kRows) {
             // ---- selector sweep: 16 B per lane, 128 rows x 5 columns per pass ---
             {
                 const uint32_t total = total_rows * 2;
@@ -430,8 +435,9 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
 // count that is a multiple of the item size, so that a lane meets the SAME row-within-item on every pass: selector values
 // are computed once per workgroup, wire offsets once per tile, and the loops are bare stores (the generic sweeps spend
 // ~30 vector + ~20 scalar instructions per 16-byte store on finding the item, the row and the constants again).  The
-// launch is a pure store stream: no item phase, no per-item record, 128 bytes of LDS (the constants), and few enough
-// registers to keep its residency beside the fat waves of the gadget's inverting launch, which it shares the chip with.
+// launch is a pure store stream: no item phase, no per-item record, 256 bytes of LDS (the constants) and 62 registers: eight
+// waves per SIMD, which a store stream needs (a wave keeps only a handful of stores in flight).  It runs AFTER the gadget's
+// inverting launch, on the same stream.
 // Tiles that hold an item of another shape (is_non_zero stopped at its error, scalar.rs:79) are left to
 // emit_kernel<GD, EMIT_ROWS>, which skips the ones written here: both read the shape off the call's prefix sums.
 #ifndef PG_ROWS_WAVES_PER_SIMD

@@ -7,6 +7,8 @@
 // 130,146,152,163,174-177,187; src/scalar.rs:47,73,91,113,121-126).
 #pragma once
 
+#include "experiment.hpp"  // (first: it looks at build options before any header gives them a default)
+
 #include <stdint.h>
 
 #if defined(__HIPCC__)

@@ -110,11 +110,7 @@ __device__ __forceinline__ Fr bound_var_value(const BoundRec &B, uint32_t y, uin
     if (kk <= 256) return raw_bit(B.Tc, kk - 1) ? fr_one() : fr_zero();  // range.rs:128-131
     if (kk <= 257 + n) {                                                  // A_i = mont(T mod 2^i), range.rs:152
         const uint32_t i = kk - 257;
-#if defined(PG_ABLATE_AMUL)  // timing-only build (wrong values): what the per-accumulator multiplication costs
-        return raw_low_bits(B.Tc, i);
-#else
         return i ? fr_to_mont(raw_low_bits(B.Tc, i)) : fr_zero();
-#endif
     }
     if (kk == 258 + n) return B.U;
     // kk == 259 + n is z: written by the pre-pass, never asked for here

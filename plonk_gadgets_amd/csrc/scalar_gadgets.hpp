@@ -313,14 +313,17 @@ struct ScalarMixGD {
 //   the wave lays the variables of its 32 items out in a private LDS image exactly as they lie in memory (ragged: an item
 //   that stopped at its error has 13; ballots give every lane its item's offset), and copies the image out linearly -- 16
 //   bytes per lane, every wave store one contiguous KiB.
-// Waves never wait for each other: no barrier, no LDS shared between waves.  Two lanes per item is what keeps the
-// registers down (a lane carries half an item and its prefetch): the launch has to leave room on every SIMD for the rows
-// launch's waves, which run beside it (capi.hip, launch_mix) -- with one lane per item (230 registers, two waves per SIMD)
-// not one rows wave fitted and the two launches simply ran one after the other.  Inputs are read once per pass, the parked
-// products are 64 B per item each way: against the three-launch form this replaces (pre-pass with 128 B per element of
-// scratch traffic, a compact inverse array, a variable-table launch that read all five inputs again) the step's reads fell
-// from 3.5 x the inputs to 2 x and nothing waits for a pre-pass any more.  Geometry: ipl = 16 at 2^20 items = 2048 waves =
-// two per SIMD, which is what the multiplier needs (one wave alone issues every other cycle).
+// Waves meet only around the inversion (one per pair of waves, below).  Two lanes per item halve what a lane carries (half an
+// item and its prefetch: 226 registers with the forward pass's four prefetch sets) and make every load and store of a step
+// a full-width access.  The launch is built for TWO waves per SIMD (amdgpu_num_vgpr(256), 120 KB of LDS = one workgroup per
+// CU): the multiplier needs two (one wave alone issues every other cycle), and the rows launches do NOT run beside it --
+// they follow it on the same stream (capi.hip, launch_mix; side by side they lose in every arrangement measured,
+// profiles/NOTES_r03.md section 2).  Inputs are read once per pass, the parked products are 64 B per item each way: against
+// the three-launch form this replaced (pre-pass with 128 B per element of scratch traffic, a compact inverse array, a
+// variable-table launch that read all five inputs again) the step's reads fell from 3.5 x the inputs to 2 x and nothing
+// waits for a pre-pass any more.  Geometry: ipl = 16 at 2^20 items = 2048 waves = two per SIMD.  What bounds the launch
+// (profiles/NOTES_r04.md): the forward pass is bound by the chip's memory system, not by a CU (half of the workgroups alone
+// run it twice as fast), the inversion by latency with HBM idle, the backward pass by HBM.
 constexpr uint32_t kMixMaxIpl = 32;  // steps per wave at most (beyond: more workgroups than fit at once)
 
 __device__ __forceinline__ void mix_load16(FrVec &d, const uint4 *col, uint64_t i) {
@@ -416,12 +419,8 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
             m = m < ipl ? m : ipl - 1;
             uint64_t i = chunk0 + (uint64_t)m * 32 + p;
             i = i < last ? i : last;  // lanes past the end re-read the last item (masked below)
-#if defined(PG_MIX_ABLATE_MEM) || defined(PG_MIX_ABLATE_FWD_LOADS)  // timing only (wrong output): the launch without its global loads and stores
-            d0.v[0] = d0.v[1] = d1.v[1] = make_uint4((uint32_t)i, m, 3, 4); d1.v[0] = make_uint4(m, 2, (uint32_t)i, 5);
-#else
             mix_load16(d0, in0, i);
             mix_load16(d1, fw1, i);
-#endif
         };
         auto step = [&](uint32_t m, const FrVec &e0, const FrVec &e1) {
             const uint64_t i = chunk0 + (uint64_t)m * 32 + p;
@@ -429,10 +428,8 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
             {
                 FrVec t;
                 t.f = acc;
-#if !defined(PG_MIX_ABLATE_MEM) && !defined(PG_MIX_ABLATE_FWD_STORES)
                 store16(valid ? park + i : sink, t.v[0]);
                 store16(valid ? park + 2 * O.batch + i : sink, t.v[1]);
-#endif
             }
             const Fr x = bside ? fr_sub(e0.f, e1.f) : e0.f;  // scalar.rs:121 / :73
             const bool nz = valid && !fr_is_zero(x);
@@ -459,6 +456,23 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
     }
 
     PG_STAMP(0);  // forward
+    // ---- what the backward pass loads per step (declared here: its first step is fetched while the inversion runs) ------
+    struct In {
+        FrVec f0, f1, f2, pk;  // v y s | a b -, the parked product
+        uint64_t base;
+    };
+    In c, n;
+    auto fetch = [&](uint32_t m, In &d) {
+        const uint64_t i0 = chunk0 + (uint64_t)m * 32;
+        uint64_t i = i0 + p;
+        i = i < last ? i : last;
+        mix_load16(d.f0, in0, i);
+        mix_load16(d.f1, in1, i);
+        mix_load16(d.f2, in2, i);
+        d.pk.v[0] = park[i];
+        d.pk.v[1] = park[2 * O.batch + i];
+        if constexpr (!PLAN) d.base = O.var_off[i0 < O.batch ? i0 : O.batch];  // first variable of the step's 32 items, relative to the call
+    };
     // (PLAN: the failing items before this wave are counted while the inversions run, below)
     uint64_t errs_before = 0;
 
@@ -558,28 +572,6 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
 
     PG_STAMP(2);  // inversion (and waiting for it)
     // ---- backward: inverses, the item's variables, the image ------------------------------------------------------
-    struct In {
-        FrVec f0, f1, f2, pk;  // v y s | a b -, the parked product
-        uint64_t base;
-    };
-    In c, n;
-    auto fetch = [&](uint32_t m, In &d) {
-        const uint64_t i0 = chunk0 + (uint64_t)m * 32;
-        uint64_t i = i0 + p;
-        i = i < last ? i : last;
-#if defined(PG_MIX_ABLATE_MEM)
-        d.f0.v[0] = d.f0.v[1] = d.f2.v[1] = make_uint4((uint32_t)i, m, 3, 4); d.f1.v[0] = d.f1.v[1] = d.f2.v[0] = make_uint4(m, 2, (uint32_t)i, 5);
-        d.pk.v[0] = d.pk.v[1] = make_uint4(7, m, (uint32_t)i, 4);
-        d.base = i0 * 15;
-#else
-        mix_load16(d.f0, in0, i);
-        mix_load16(d.f1, in1, i);
-        mix_load16(d.f2, in2, i);
-        d.pk.v[0] = park[i];
-        d.pk.v[1] = park[2 * O.batch + i];
-        if constexpr (!PLAN) d.base = O.var_off[i0 < O.batch ? i0 : O.batch];  // first variable of the step's 32 items, relative to the call
-#endif
-    };
     if (ipl) fetch(ipl - 1, c);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // The image of a step is copied out DURING THE NEXT STEP, five stores after each of its three multiplications: all
@@ -593,11 +585,7 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
 #pragma unroll
         for (uint32_t k = k0; k < k1; k++) {  // (a fixed number of stores whatever the items' shapes)
             const uint32_t o = lane + 64 * k;
-#if defined(PG_MIX_ABLATE_MEM)
-            if (img[o].x == 0x12345678u && img[o].y == 0x9abcdef1u) store16(sink, img[o]);
-#else
             store16(o < ptotal * 2 ? pdst + o : sink, img[o]);
-#endif
         }
     };
     for (uint32_t mm = ipl; mm-- > 0;) {
@@ -659,9 +647,7 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
         {   // the results' Variables: select_one's output (the v side stores it), maybe_equal's (the a - b side)
             uint64_t *rv = reinterpret_cast<uint64_t *>(sink);
             if (valid && A.result_vars) rv = A.result_vars + 2 * i + (bside ? 1 : 0);
-#if !defined(PG_MIX_ABLATE_MEM)
             *rv = O.var_base + c.base + off + tail + (bside ? 6 : 3);
-#endif
         }
         ptotal = total;
         pdst = O.vars + c.base * 2;

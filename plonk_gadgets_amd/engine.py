@@ -436,6 +436,56 @@ class Engine:
         if st != 0:
             raise PgError(st, "pg_scalar_mix_planned_batch")
 
+    # ---- witness refresh: the variable assignments of a call, no rows (pg_*_values_batch) ----------------------------------
+    def range_check_values_batch(self, min_range: BlsScalar, max_range: BlsScalar, witness: torch.Tensor,
+                                 var_values: torch.Tensor | None = None) -> torch.Tensor:
+        """what range_check_batch writes into Columns.var_values, and nothing else: the same circuit rebuilt with other
+        witnesses (prover.clear_witness() and the calls again, /root/reference/tests/scalar_gadgets_tests.rs:108-119)"""
+        self._check_scalars(witness)
+        batch = witness.shape[0]
+        lay = self.range_check_layout(min_range, max_range, batch)
+        if var_values is None:
+            var_values = torch.empty((lay.n_vars, 4), dtype=torch.int64, device=self.device)
+        assert var_values.is_contiguous() and var_values.shape == (lay.n_vars, 4)
+        st = self._lib.pg_range_check_values_batch(self._h, C.byref(min_range.c), C.byref(max_range.c), witness.data_ptr(), batch,
+                                                   var_values.data_ptr(), self._stream())
+        if st != 0:
+            raise PgError(st, "pg_range_check_values_batch")
+        return var_values
+
+    def max_bound_values_batch(self, max_range: BlsScalar, witness: torch.Tensor, var_values: torch.Tensor | None = None) -> torch.Tensor:
+        self._check_scalars(witness)
+        batch = witness.shape[0]
+        lay = self.max_bound_layout(max_range, batch)
+        if var_values is None:
+            var_values = torch.empty((lay.n_vars, 4), dtype=torch.int64, device=self.device)
+        assert var_values.is_contiguous() and var_values.shape == (lay.n_vars, 4)
+        st = self._lib.pg_max_bound_values_batch(self._h, C.byref(max_range.c), witness.data_ptr(), batch, var_values.data_ptr(),
+                                                 self._stream())
+        if st != 0:
+            raise PgError(st, "pg_max_bound_values_batch")
+        return var_values
+
+    def max_bound_ragged_values(self, max_range, witness, num_bits, row_off, var_off, var_values: torch.Tensor):
+        """the ragged call's assignments under the plan of its (public) bounds"""
+        st = self._lib.pg_max_bound_ragged_values_batch(self._h, max_range.data_ptr(), witness.data_ptr(), witness.shape[0],
+                                                        num_bits.data_ptr(), row_off.data_ptr(), var_off.data_ptr(),
+                                                        var_values.data_ptr(), self._stream())
+        if st != 0:
+            raise PgError(st, "pg_max_bound_ragged_values_batch")
+        return var_values
+
+    def scalar_mix_values(self, v, y, s, a, b, row_off, var_off, var_values: torch.Tensor, err_mask=None):
+        """the fused mix's assignments AND its plan for these witnesses (row_off / var_off / err_mask are outputs; totals:
+        plan_result()): an item's shape depends on its witness, the caller compares the plan with the circuit it has"""
+        st = self._lib.pg_scalar_mix_values_batch(self._h, v.data_ptr(), y.data_ptr(), s.data_ptr(), a.data_ptr(), b.data_ptr(),
+                                                  v.shape[0], row_off.data_ptr(), var_off.data_ptr(),
+                                                  err_mask.data_ptr() if err_mask is not None else None, var_values.data_ptr(),
+                                                  self._stream())
+        if st != 0:
+            raise PgError(st, "pg_scalar_mix_values_batch")
+        return var_values
+
     # ---- asynchronous plans (no host round trip between plan and emit; totals read back later) -----------------
     def max_bound_ragged_plan_async(self, max_range: torch.Tensor, num_bits, row_off, var_off):
         st = self._lib.pg_max_bound_ragged_plan_async(self._h, max_range.data_ptr(), max_range.shape[0], num_bits.data_ptr(),

@@ -44,3 +44,51 @@ def test_gpu_needed_at_runtime_paths_do_not_read_reference():
         code = re.sub(r"#.*", "", open(os.path.join(ROOT, name)).read())
         code = re.sub(r'""".*?"""', "", code, flags=re.S)
         assert "/root/reference" not in code, name
+
+
+# ---- build options: the shipped library is built with none (csrc/experiment.hpp) ------------------------------------
+
+CSRC = os.path.join(ROOT, "plonk_gadgets_amd", "csrc")
+NOT_OPTIONS = {"PG_EXPERIMENT", "PG_HD"}  # the fence's own key; a function attribute macro
+
+
+def tested_options():
+    """every PG_... macro a preprocessor conditional of csrc/ looks at"""
+    found = set()
+    for f in os.listdir(CSRC):
+        if f == "experiment.hpp":
+            continue
+        for line in open(os.path.join(CSRC, f)):
+            if re.match(r"\s*#\s*(if|ifdef|ifndef|elif)\b", line):
+                found.update(re.findall(r"\bPG_[A-Z0-9_]+\b", line))
+    return found - NOT_OPTIONS
+
+
+def test_the_library_is_built_without_build_options():
+    from plonk_gadgets_amd import build as pg_build
+    cmd = pg_build.command("/tmp/x.so")
+    assert not [a for a in cmd if a.startswith("-D")], cmd
+    assert "-O3" in cmd and "--offload-arch=gfx950" in cmd
+
+
+def test_every_build_option_is_behind_the_experiment_fence():
+    fence = open(os.path.join(CSRC, "experiment.hpp")).read()
+    fenced = set(re.findall(r"defined\((PG_[A-Z0-9_]+)\)", fence)) - NOT_OPTIONS
+    opts = tested_options()
+    assert opts, "no options found: the scan is broken"
+    assert opts <= fenced, f"options the sources test but the fence does not name: {sorted(opts - fenced)}"
+    assert fenced <= opts, f"the fence names options no source tests any more: {sorted(fenced - opts)}"
+    # no build that changes the OUTPUT lives in the sources (they are patches under tools/patches/)
+    assert not [o for o in opts if "ABLATE" in o]
+
+
+def test_an_option_without_the_fence_key_does_not_compile():
+    import subprocess
+    hdr = os.path.join(CSRC, "experiment.hpp")
+    ok = subprocess.run(["g++", "-fsyntax-only", "-x", "c++", hdr], capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr
+    for opt in ("-DPG_RC_W=16", "-DPG_MIX_STAMPS", "-DPG_INVERT_FERMAT"):
+        bad = subprocess.run(["g++", "-fsyntax-only", "-x", "c++", opt, hdr], capture_output=True, text=True)
+        assert bad.returncode != 0 and "PG_EXPERIMENT" in bad.stderr, (opt, bad.stderr)
+        good = subprocess.run(["g++", "-fsyntax-only", "-x", "c++", opt, "-DPG_EXPERIMENT", hdr], capture_output=True, text=True)
+        assert good.returncode == 0, (opt, good.stderr)

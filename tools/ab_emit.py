@@ -24,11 +24,33 @@ VARIANTS = {
     "mix_stamps_nofwdld": ["-DPG_MIX_STAMPS", "-DPG_MIX_ABLATE_FWD_LOADS"],
     "mix_stamps_nofwdst": ["-DPG_MIX_STAMPS", "-DPG_MIX_ABLATE_FWD_STORES"],
     "mix_nomem": ["-DPG_MIX_ABLATE_MEM"],  # timing only (wrong output): the arithmetic launch without its global loads and stores
+    "ablate_amul": ["-DPG_ABLATE_AMUL"],   # timing only (wrong output): the big-item emitters without the per-accumulator multiplication
     "rows_wps4": ["-DPG_ROWS_WAVES_PER_SIMD=4"],  # the periodic rows launch allowed 128 registers
     "rows_prio3": ["-DPG_ROWS_SETPRIO=3"],      # the rows launch's waves at the highest issue priority
     "rows_prio1": ["-DPG_ROWS_SETPRIO=1"],
+    # round 4 experiments on the mix
+    "sbit": ["-DPG_EXP_SBIT"],
+    "side_normal": ["-DPG_SIDE_STREAM_NORMAL_PRIORITY"],
+    "inv_grp2": ["-DPG_INV_GRP=2"],
+    "p1": ["-DPG_EXP_PREFETCH_INV"],
+    "g8": ["-DPG_MIX_ROWS_GRID_PER_CU=8"],
+    "p1g8": ["-DPG_EXP_PREFETCH_INV", "-DPG_MIX_ROWS_GRID_PER_CU=8"],
+    "f1": ["-DPG_EXP_PARK_BLOCKS"],
+    "f1_stamps": ["-DPG_EXP_PARK_BLOCKS", "-DPG_MIX_STAMPS"],
+    "f2a_stamps": ["-DPG_EXP_WAVE_STAGGER=2", "-DPG_MIX_STAMPS"],
+    "f2b_stamps": ["-DPG_EXP_WAVE_STAGGER=5", "-DPG_MIX_STAMPS"],
+    "f3": ["-DPG_EXP_PARK_BLOCKS", "-DPG_EXP_WAVE_STAGGER=2"],
+    "f3_stamps": ["-DPG_EXP_PARK_BLOCKS", "-DPG_EXP_WAVE_STAGGER=2", "-DPG_MIX_STAMPS"],
+    "iplenv": ["-DPG_EXP_MIX_IPL_ENV"],
+    "iplenv_stamps": ["-DPG_EXP_MIX_IPL_ENV", "-DPG_MIX_STAMPS"],
+    "rows128": ["-DPG_MIX_ROWS_W=128"],
+    "rows512": ["-DPG_MIX_ROWS_W=512"],
+    "rowsgrid8": ["-DPG_MIX_ROWS_GRID_PER_CU=8"],
+    "rowsgrid12": ["-DPG_MIX_ROWS_GRID_PER_CU=12"],
+    "gen_side": ["-DPG_EXP_GENERIC_SIDE"],
+    "stag50": ["-DPG_MIX_STAMPS", "-DPG_EXP_STAGGER_TICKS=5000"],
+    "stag100": ["-DPG_MIX_STAMPS", "-DPG_EXP_STAGGER_TICKS=10000"],
     # every emitter
-    "sequential_prepass": ["-DPG_PREPASS_ON_CALLER_STREAM"],  # big-item gadgets: pre-pass, then the emit launch, on one stream
     "invert_fermat": ["-DPG_INVERT_FERMAT"],
     "full_barriers": ["-DPG_FULL_BARRIERS"],
     "unaligned_sweeps": ["-DPG_UNALIGNED_SWEEPS"],  # generic sweeps start at the tile's first unit wherever it falls in a 128-byte line
@@ -43,14 +65,41 @@ VARIANTS = {
 }
 
 
+PATCHES = {  # builds that are NOT in the sources: a patch (tools/patches/) applied to a copy of csrc/ first
+    "mix_stamps_nomem": "ablations_wrong_output.patch", "mix_stamps_nofwdld": "ablations_wrong_output.patch",
+    "mix_stamps_nofwdst": "ablations_wrong_output.patch", "mix_nomem": "ablations_wrong_output.patch",
+    "ablate_amul": "ablations_wrong_output.patch",
+    # round 4's rejected schedules of the fused mix (profiles/NOTES_r04.md): apply to the sources of commit "round 4: values" --
+    # kept as a record of what was measured, it may no longer apply cleanly
+    "f1": "r04_mix_experiments.patch", "f3": "r04_mix_experiments.patch", "p1": "r04_mix_experiments.patch", "g8": "r04_mix_experiments.patch",
+    "p1g8": "r04_mix_experiments.patch", "iplenv": "r04_mix_experiments.patch", "iplenv_stamps": "r04_mix_experiments.patch",
+    "f1_stamps": "r04_mix_experiments.patch", "f2a_stamps": "r04_mix_experiments.patch", "f2b_stamps": "r04_mix_experiments.patch",
+    "f3_stamps": "r04_mix_experiments.patch", "stag50": "r04_mix_experiments.patch", "stag100": "r04_mix_experiments.patch",
+    "rows128": "r04_mix_experiments.patch", "rows512": "r04_mix_experiments.patch", "rowsgrid8": "r04_mix_experiments.patch",
+    "rowsgrid12": "r04_mix_experiments.patch", "gen_side": "r04_mix_experiments.patch",
+}
+
+
 def build(only=None):
+    import shutil
+    import subprocess
+    import tempfile
     from plonk_gadgets_amd import build as b
     os.makedirs(VDIR, exist_ok=True)
     for name, flags in VARIANTS.items():
         if flags is None or (only and name not in only):
             continue
         out = os.path.join(VDIR, f"lib_{name}.so")
-        b.build(force=True, extra_flags=flags, out=out)
+        flags = (["-DPG_EXPERIMENT"] + flags) if flags else []  # csrc/experiment.hpp: no option without it
+        if name in PATCHES:
+            with tempfile.TemporaryDirectory() as tmp:
+                shutil.copytree(os.path.join(ROOT, "plonk_gadgets_amd"), os.path.join(tmp, "plonk_gadgets_amd"),
+                                ignore=shutil.ignore_patterns("*.so", "__pycache__"))
+                shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))
+                subprocess.check_call(["patch", "-p0", "-s", "-d", tmp, "-i", os.path.join(ROOT, "tools", "patches", PATCHES[name])])
+                b.build(force=True, extra_flags=flags, out=out, csrc=os.path.join(tmp, "plonk_gadgets_amd", "csrc"))
+        else:
+            b.build(force=True, extra_flags=flags, out=out)
         print("built", out)
 
 

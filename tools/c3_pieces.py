@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/c3_pieces.py LIB -- the C3 step (pg_scalar_mix_planned_batch) through library LIB, a few times; run under
-`rocprofv3 --kernel-trace --stats` with a PG_MIX_SEQUENTIAL build to read every kernel's duration when it has the
-chip to itself."""
+`rocprofv3 --kernel-trace --stats` (tools/c3_timeline.sh) to read every kernel's start, end and duration: the step's
+launches run one after the other on one stream, so each has the chip to itself."""
 import ctypes as C
 import os
 import sys

@@ -30,11 +30,20 @@ cc = cols.as_c()
 h = C.c_void_p()
 assert lib.pg_engine_create(0, C.byref(h)) == 0
 out = (C.c_ulonglong * 8)()
+ipl = int(os.environ.get("PG_EXP_MIX_IPL", "16"))
 for rep in range(6):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     assert lib.pg_scalar_mix_planned_batch(h, *[t.data_ptr() for t in ins], n, roff.data_ptr(), voff.data_ptr(), None, 3, 5, 0,
                                            C.byref(cc), res.data_ptr(), None) == 0
+    e1.record()
     torch.cuda.synchronize()
     assert lib.pg_debug_mix_phases(out) == 0
     if rep:
-        waves = 2048
-        print("us per wave: forward %.1f  look-back %.1f  inversion %.1f  backward %.1f" % tuple(out[k] / waves / 100.0 for k in range(4)))
+        if any(out[k] for k in range(4, 8)):  # a staggered build (PG_EXP_STAGGER_TICKS): even / odd workgroups apart
+            for g, name in ((0, "even"), (4, "odd ")):
+                print("us per wave (%s workgroups): forward %.1f  look-back %.1f  inversion %.1f  backward %.1f" % ((name,) + tuple(out[g + k] / 1024 / 100.0 for k in range(4))))
+        else:
+            waves = (n + 32 * ipl - 1) // (32 * ipl)
+            print("us per wave: forward %.1f  look-back %.1f  inversion %.1f  backward %.1f   (%d waves; the whole call %.1f us)"
+                  % (tuple(out[k] / waves / 100.0 for k in range(4)) + (waves, 1e3 * e0.elapsed_time(e1))))
