@@ -52,7 +52,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2")
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c2_values"], default="c2")
     ap.add_argument("--log2-batch", type=int, default=20, help="items per GPU per step = 2^this")
     ap.add_argument("--log2-chunk", type=int, default=-1, help="items per launch = 2^this (-1: largest that fits)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="items timed on the CPU oracle (0: workload default)")
@@ -161,6 +161,8 @@ def cpu_baseline(workload: str, sample: int):
     from oracle import pyoracle as po
     from plonk_gadgets_amd import synth
     po.lib()
+    if workload == "c2_values":  # (the CPU side has no refresh: the reference rebuilds every row, which is what C2's baseline times)
+        workload = "c2"
     if workload == "c2":
         sample = sample or 512
         wit = synth.random_scalars(sample, seed=synth.SEED)
@@ -251,6 +253,24 @@ class Workload:
             self.kernel = "pg::emit_kernel<pg::RangeCheckGD>"
             self.desc = ("C2: 2^%d witnesses/GPU x (allocate + range_check(min=0,max=2^254)), n=255, 1031 rows + 1034 "
                          "vars per witness" % log2_batch)
+        elif name == "c2_values":
+            # the witness refresh of C2's circuit (prover.clear_witness() and the same calls on other witnesses,
+            # /root/reference/tests/scalar_gadgets_tests.rs:108-119): the variable table alone, 1034 x 32 B per witness
+            mn, mx = pg.BlsScalar.from_int(0), pg.BlsScalar.from_int(2**254)
+            G, V = 1031, 1034
+            wit = to_dev(synth.random_scalars(batch, seed=synth.SEED + 1))
+            lay = eng.range_check_layout(mn, mx, chunk)
+            table = torch.empty((lay.n_vars, 4), dtype=torch.int64, device=dev)
+            self.rows_per_launch, self.vars_per_launch = lay.n_gates, lay.n_vars  # (rows of the circuit: found in place, not written)
+            self.rows_written_per_launch = 0
+            self.read_bytes = chunk * 32
+            cols, res = table, None
+
+            def launch(c):
+                eng.range_check_values_batch(mn, mx, wit[c * chunk:(c + 1) * chunk], table)
+            self.kernel = "pg::emit_kernel<pg::RangeCheckGD, EMIT_VALUES> (pg_range_check_values_batch)"
+            self.desc = ("C2 witness refresh: 2^%d witnesses/GPU x the assignments of (allocate + range_check(min=0,max=2^254)), "
+                         "1034 variables per witness, no rows" % log2_batch)
         elif name == "c3":
             ins = [to_dev(x) for x in mix_inputs(batch, seed=0xC3 + rank)]
             _, roff, voff = eng.ragged_buffers(chunk)
@@ -294,7 +314,8 @@ class Workload:
                          "length, ragged rows" % log2_batch)
         self.launch, self.cols, self.res = launch, cols, res
         self.batch, self.chunk, self.n_chunks = batch, chunk, batch // chunk
-        self.algo_bytes_per_launch = self.rows_per_launch * BYTES_PER_GATE + self.vars_per_launch * BYTES_PER_VAR
+        rows_written = getattr(self, "rows_written_per_launch", self.rows_per_launch)
+        self.algo_bytes_per_launch = rows_written * BYTES_PER_GATE + self.vars_per_launch * BYTES_PER_VAR
 
     def release(self):
         self.launch = self.cols = self.res = None
@@ -395,10 +416,13 @@ def main():
     emitted = []
 
     def emit_once(obj):
+        """True if this call wrote the line (exactly one line is ever written)"""
         with emit_lock:
-            if not emitted:
-                emitted.append(True)
-                emit(obj)
+            if emitted:
+                return False
+            emitted.append(True)
+            emit(obj)
+            return True
 
     import numpy as np  # noqa: F401
     import torch
@@ -470,11 +494,12 @@ def main():
     secondary = None
     if world == 1 and args.workload == "c2" and not args.no_secondary:
         secondary = {}
-        for name in ("c3", "c4"):
+        for name in ("c3", "c4", "c2_values"):
             try:
                 w2 = Workload(name, eng, dev, rank, world, args.log2_batch, -1)
                 el2, ms2 = measure(w2, args.steps, args.warmup, sync_all)
-                secondary[name] = {"metric": f"gadget constraints/sec ({name})",
+                secondary[name] = {"metric": f"gadget constraints/sec ({name})" if name != "c2_values" else
+                                             "constraints whose witnesses are refreshed /sec (range_check 256-bit, values only)",
                                    "value": w2.rows_per_launch * w2.n_chunks * args.steps / el2, "unit": "constraints/s",
                                    "ms_per_step": el2 / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
                                    "config": {"workload": w2.desc, "items_per_gpu": w2.batch, "items_per_launch": w2.chunk},
@@ -509,15 +534,19 @@ def main():
     # ---- N > 1: gather-inclusive rate of the chunked all-gather pipeline (bounded sample) -----------------
     allgather = None
     watchdog = None
+    finished = threading.Event()
     if distributed and backend == "nccl" and args.workload == "c2" and args.allgather_chunks > 0:
         # the headline is measured; a collective that hangs (a link, a rank that died) must not cost it: after the limit
         # rank 0 prints the line it has, and every rank leaves
         def bail():
             # exactly one line is ever written (emit_once), and a run whose collective hung does not exit 0: code 3 = "the
-            # headline was measured and printed, the gather-inclusive sample was abandoned"
-            if rank == 0:
-                emit_once(dict(line, allgather={"error": f"the gather-inclusive sample did not finish within "
-                                                         f"{args.allgather_timeout} s; abandoned"}))
+            # headline was measured and printed, the gather-inclusive sample was abandoned".  A timer that fires when the
+            # run has in fact finished (the complete line is out, or about to be) changes nothing.
+            if finished.is_set():
+                return
+            if rank == 0 and not emit_once(dict(line, allgather={"error": f"the gather-inclusive sample did not finish within "
+                                                                          f"{args.allgather_timeout} s; abandoned"})):
+                return  # the complete line was written first
             os._exit(3)
         watchdog = threading.Timer(args.allgather_timeout, bail)
         watchdog.daemon = True
@@ -560,8 +589,9 @@ def main():
         except Exception as ex:
             allgather["variables_only"] = {"error": repr(ex)}
 
+    finished.set()
     if watchdog is not None:
-        watchdog.cancel()  # (before the final line is built; a timer that has already fired wins the lock below and exits)
+        watchdog.cancel()  # (a timer that fired before `finished` was set wins the lock below and exits with the short line)
     if rank == 0:
         final = dict(line)
         if allgather:

@@ -113,6 +113,18 @@ class StandardComposer {
         return q;
     }
 
+    // Prover::clear_witness() of the reference's tests (tests/scalar_gadgets_tests.rs:110,170,228): a fresh composer again; the
+    // same calls on other witnesses find their rows in place and write only the assignments
+    void clear_witness() { pg_throw(pg_composer_clear_witness(h), "clear_witness"); }
+    struct RefreshStats { uint64_t rows_in_place, rows_rewritten; bool refreshing; };
+    RefreshStats refresh_stats() const {
+        RefreshStats r{};
+        int on = 0;
+        pg_throw(pg_composer_refresh_stats(h, &r.rows_in_place, &r.rows_rewritten, &on), "refresh_stats");
+        r.refreshing = on != 0;
+        return r;
+    }
+
     uint64_t circuit_size() const { return pg_composer_circuit_size(h); }
     uint64_t num_variables() const { return pg_composer_num_variables(h); }
     Variable zero_var() const { return Variable{pg_composer_zero_var(h)}; }

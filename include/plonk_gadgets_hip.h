@@ -331,6 +331,21 @@ pg_status pg_composer_flush(pg_composer *c);
 /* entries waiting, flushes so far, launches those flushes took (any pointer may be NULL) */
 pg_status pg_composer_queue_stats(const pg_composer *c, uint64_t *pending, uint64_t *flushes, uint64_t *launches);
 
+/* Witness refresh.  The reference's tests prove twice with one preprocessed circuit: prover.clear_witness(), the same
+ * gadget calls on other witnesses, prove again (tests/scalar_gadgets_tests.rs:108-119, 168-177, 226-235; dusk-plonk's
+ * Prover::clear_witness() = a fresh StandardComposer).  pg_composer_clear_witness does the same -- rows and Variables
+ * count from StandardComposer::new()'s state again, public inputs are forgotten -- but the device columns stay where
+ * they are: an append that repeats, at the same place in the call sequence, what the build before it did there (the same
+ * call with the same public parameters, landing on the same first row, first Variable and zero_var) finds its rows in the
+ * columns and writes only its assignments (32 B per variable instead of 184 B per row on top; pg_*_values_batch).  That
+ * holds for every single composer gate call, single pg_range_check / pg_max_bound calls, and the batched appends on witness
+ * scalars (pg_composer_range_check_batch, _max_bound_batch, _scalar_mix_batch when no item fails); appends whose rows depend
+ * on device arrays of Variables or bounds are simply emitted again.  The first append that differs from the previous build
+ * ends the refresh: from there on everything is emitted in full, so another circuit is built correctly too -- only slower. */
+pg_status pg_composer_clear_witness(pg_composer *c);
+/* since the last pg_composer_clear_witness: rows found in place, rows written again, still matching (any pointer may be NULL) */
+pg_status pg_composer_refresh_stats(const pg_composer *c, uint64_t *rows_in_place, uint64_t *rows_rewritten, int *refreshing);
+
 /* composer calls used by the gadgets (same argument order as dusk-plonk 0.8; `pi` may be NULL = None) */
 pg_status pg_composer_add_input(pg_composer *c, const pg_scalar *s, pg_variable *out);
 pg_status pg_composer_add_witness_to_circuit_description(pg_composer *c, const pg_scalar *value, pg_variable *out);

@@ -126,6 +126,8 @@ SIGNATURES = {
     "pg_composer_gate_capacity": (C.c_uint64, [C.c_void_p]),
     "pg_composer_var_capacity": (C.c_uint64, [C.c_void_p]),
     "pg_composer_sync": (C.c_int, [C.c_void_p]),
+    "pg_composer_clear_witness": (C.c_int, [C.c_void_p]),
+    "pg_composer_refresh_stats": (C.c_int, [C.c_void_p, _P(C.c_uint64), _P(C.c_uint64), _P(C.c_int)]),
     "pg_composer_queue": (C.c_int, [C.c_void_p, C.c_int]),
     "pg_composer_flush": (C.c_int, [C.c_void_p]),
     "pg_composer_queue_stats": (C.c_int, [C.c_void_p, _P(C.c_uint64), _P(C.c_uint64), _P(C.c_uint64)]),

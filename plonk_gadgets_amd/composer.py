@@ -87,6 +87,19 @@ class StandardComposer:
         _chk(self._lib.pg_composer_queue_stats(self._h, C.byref(a), C.byref(b), C.byref(c)), "pg_composer_queue_stats")
         return int(a.value), int(b.value), int(c.value)
 
+    # -- witness refresh ---------------------------------------------------------------------
+    def clear_witness(self):
+        """prover.clear_witness() of the reference's tests (tests/scalar_gadgets_tests.rs:110): the composer counts from
+        StandardComposer::new()'s state again; the same calls with other witnesses then find their rows in place and
+        write only assignments (pg_composer_clear_witness)"""
+        _chk(self._lib.pg_composer_clear_witness(self._h), "pg_composer_clear_witness")
+
+    def refresh_stats(self) -> tuple:
+        """(rows found in place, rows written again, still matching the previous build) since the last clear_witness"""
+        a, b, r = C.c_uint64(), C.c_uint64(), C.c_int()
+        _chk(self._lib.pg_composer_refresh_stats(self._h, C.byref(a), C.byref(b), C.byref(r)), "pg_composer_refresh_stats")
+        return int(a.value), int(b.value), bool(r.value)
+
     # -- state ------------------------------------------------------------------------------
     def circuit_size(self) -> int:
         return int(self._lib.pg_composer_circuit_size(self._h))
@@ -297,6 +310,23 @@ class StandardComposer:
         out = torch.empty((self.circuit_size(), 4), dtype=torch.int64, device=self.engine.device)
         _chk(self._lib.pg_composer_dense_pi(self._h, out.data_ptr()), "dense_pi")
         return out
+
+    def device_columns(self) -> Columns:
+        """the composer's OWN columns as tensors (no copy): rows [0, circuit_size), Variables [0, num_variables); valid until
+        the composer grows or is destroyed; what is recorded is flushed to the stream first (pg_composer_columns)"""
+        cc = _lib.ColumnsC()
+        _chk(self._lib.pg_composer_columns(self._h, C.byref(cc)), "pg_composer_columns")
+        n, nv, dev = self.circuit_size(), self.num_variables(), self.engine.device
+
+        class _Mem:
+            def __init__(self, ptr, words):
+                self.__cuda_array_interface__ = {"shape": (words,), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+
+        def words(ptr, count):
+            return torch.as_tensor(_Mem(ptr, count), device=dev)
+        sc = [words(getattr(cc, k), n * 4).view(n, 4) for k in Columns.SCALAR_COLS]
+        wc = [words(getattr(cc, k), n) for k in Columns.WIRE_COLS]
+        return Columns(*sc, *wc, words(cc.var_values, nv * 4).view(nv, 4))
 
     def export(self, gate_base: int = 0, var_base: int = 0) -> dict:
         """numpy copy of the live columns (rows >= gate_base, variables >= var_base)"""

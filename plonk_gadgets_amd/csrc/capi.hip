@@ -919,10 +919,10 @@ pg_status pg_scalar_mix_plan_async(pg_engine *e, const pg_scalar *d_v, uint64_t 
     return error_plan(e, pg::scalar_mix_plan_kernel, d_v, batch, d_row_off, d_var_off, d_err_mask, nullptr, nullptr, stream);
 }
 
-pg_status pg_scalar_mix_batch(pg_engine *e, const pg_scalar *d_v, const pg_scalar *d_y, const pg_scalar *d_s,
-                              const pg_scalar *d_a, const pg_scalar *d_b, uint64_t batch, const uint64_t *d_row_off,
-                              const uint64_t *d_var_off, uint64_t gate_base, uint64_t var_base, pg_variable zero_var,
-                              const pg_columns *out, pg_variable *d_result_vars, void *stream) {
+static pg_status scalar_mix_common(pg_engine *e, const pg_scalar *d_v, const pg_scalar *d_y, const pg_scalar *d_s,
+                                   const pg_scalar *d_a, const pg_scalar *d_b, uint64_t batch, const uint64_t *d_row_off,
+                                   const uint64_t *d_var_off, uint64_t gate_base, uint64_t var_base, pg_variable zero_var,
+                                   const pg_columns *out, pg_variable *d_result_vars, void *stream, bool values_only) {
     if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
     if (batch == 0) return PG_OK;
     const pg_scalar *in[5] = {d_v, d_y, d_s, d_a, d_b};
@@ -938,7 +938,15 @@ pg_status pg_scalar_mix_batch(pg_engine *e, const pg_scalar *d_v, const pg_scala
     A.a = reinterpret_cast<const uint4 *>(d_a);
     A.b = reinterpret_cast<const uint4 *>(d_b);
     A.result_vars = d_result_vars;
-    return launch<pg::ScalarMixGD>(e, A, out, batch, gate_base, var_base, zero_var, d_row_off, d_var_off, stream);
+    return launch<pg::ScalarMixGD>(e, A, out, batch, gate_base, var_base, zero_var, d_row_off, d_var_off, stream, nullptr, values_only);
+}
+
+pg_status pg_scalar_mix_batch(pg_engine *e, const pg_scalar *d_v, const pg_scalar *d_y, const pg_scalar *d_s,
+                              const pg_scalar *d_a, const pg_scalar *d_b, uint64_t batch, const uint64_t *d_row_off,
+                              const uint64_t *d_var_off, uint64_t gate_base, uint64_t var_base, pg_variable zero_var,
+                              const pg_columns *out, pg_variable *d_result_vars, void *stream) {
+    return scalar_mix_common(e, d_v, d_y, d_s, d_a, d_b, batch, d_row_off, d_var_off, gate_base, var_base, zero_var, out, d_result_vars,
+                             stream, false);
 }
 
 static pg_status scalar_mix_planned_common(pg_engine *e, const pg_scalar *d_v, const pg_scalar *d_y, const pg_scalar *d_s,

@@ -16,6 +16,9 @@ struct ComposerCols {
 };
 
 enum GateOp : uint32_t { OP_ADD_INPUT = 0, OP_ROW = 1, OP_ADD = 2, OP_MUL = 3 };
+// OR-ed into GateCmd::op: the row is already in the columns (a witness refresh, pg_composer_clear_witness) -- only the
+// assignment the call creates is written
+constexpr uint32_t OP_ROW_IN_PLACE = 0x80000000u;
 
 // one composer call, passed by value as the kernel argument
 struct GateCmd {
@@ -44,19 +47,21 @@ __device__ __forceinline__ Fr get_fr(const uint4 *col, uint64_t i) {
 
 __global__ void gate_kernel(const GateCmd cmd, const ComposerCols C) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (cmd.op == OP_ADD_INPUT) {
+    const uint32_t op = cmd.op & ~OP_ROW_IN_PLACE;
+    if (op == OP_ADD_INPUT) {
         put_fr(C.vars, cmd.var, cmd.value);
         return;
     }
     uint64_t out = cmd.c;
-    if (cmd.op == OP_ADD || cmd.op == OP_MUL) {
+    if (op == OP_ADD || op == OP_MUL) {
         const Fr a = get_fr(C.vars, cmd.a), b = get_fr(C.vars, cmd.b);
         // big_add / big_mul with no fourth wire: c = q_l a + q_r b + q_c + pi   |   c = q_m a b + q_c + pi
-        Fr v = cmd.op == OP_ADD ? fr_add(fr_mul(cmd.q_l, a), fr_mul(cmd.q_r, b)) : fr_mul(fr_mul(cmd.q_m, a), b);
+        Fr v = op == OP_ADD ? fr_add(fr_mul(cmd.q_l, a), fr_mul(cmd.q_r, b)) : fr_mul(fr_mul(cmd.q_m, a), b);
         v = fr_add(fr_add(v, cmd.q_c), cmd.pi);
         put_fr(C.vars, cmd.var, v);
         out = cmd.var;
     }
+    if (cmd.op & OP_ROW_IN_PLACE) return;
     put_fr(C.q[0], cmd.gate, cmd.q_m);
     put_fr(C.q[1], cmd.gate, cmd.q_l);
     put_fr(C.q[2], cmd.gate, cmd.q_r);
@@ -79,12 +84,14 @@ __global__ __launch_bounds__(1024) void gate_queue_kernel(const GateCmd *cmds, u
     const uint32_t tid = threadIdx.x;
     GateCmd cmd{};
     if (tid < n) cmd = cmds[tid];
+    const bool in_place = (cmd.op & OP_ROW_IN_PLACE) != 0;
+    cmd.op &= ~OP_ROW_IN_PLACE;
     const bool creates = tid < n && (cmd.op == OP_ADD || cmd.op == OP_MUL);
     if (tid < n) {
         if (cmd.op == OP_ADD_INPUT) {
             put_fr(C.vars, cmd.var, cmd.value);
             put_fr(s_val, cmd.var - first_var, cmd.value);
-        } else {
+        } else if (!in_place) {
             put_fr(C.q[0], cmd.gate, cmd.q_m);
             put_fr(C.q[1], cmd.gate, cmd.q_l);
             put_fr(C.q[2], cmd.gate, cmd.q_r);

@@ -225,6 +225,18 @@ static void test_conditionally_select_0(Engine &e) {
     circuit(prover2, random_scalar(), BlsScalar::one());
     CHECK(prover2.check() >= 0);
     CHECK(same_structure(download(prover2), download(verifier)));
+    // ... and as the reference does it (tests/scalar_gadgets_tests.rs:108-119): prover.clear_witness(), the circuit again on
+    // the SAME prover with the other witnesses -- same rows (found in place), other assignments, and it no longer verifies
+    prover.clear_witness();
+    CHECK(prover.circuit_size() == 3 && prover.num_variables() == 5);
+    circuit(prover, random_scalar(), BlsScalar::one());
+    CHECK(prover.check() >= 0);
+    CHECK(same_structure(download(prover), download(verifier)));
+    const auto st = prover.refresh_stats();
+    CHECK(st.refreshing && st.rows_in_place == 1 && st.rows_rewritten == 0);  // constrain_to_constant's row (the select is emitted)
+    prover.clear_witness();
+    circuit(prover, random_scalar(), BlsScalar::zero());
+    CHECK(prover.check() == -1);
 }
 
 static void test_conditionally_select_1(Engine &e) {
@@ -244,6 +256,11 @@ static void test_conditionally_select_1(Engine &e) {
     circuit(prover2, rand, BlsScalar::one(), rand);
     CHECK(prover2.check() == -1);
     CHECK(same_structure(download(prover), download(prover2)));  // public inputs are not part of the structure
+    // tests/scalar_gadgets_tests.rs:168-177: clear_witness, then the second case on the first prover
+    prover.clear_witness();
+    circuit(prover, rand, BlsScalar::one(), rand);
+    CHECK(prover.check() == -1);
+    CHECK(same_structure(download(prover), download(prover2)));
     // a wrong public input does not verify
     StandardComposer wrong(e);
     circuit(wrong, rand, BlsScalar::one(), rand + BlsScalar::one());

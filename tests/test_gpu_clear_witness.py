@@ -1,0 +1,264 @@
+"""GPU: the reference's prove-twice flow on the device composer -- pg_composer_clear_witness.
+
+/root/reference/tests/scalar_gadgets_tests.rs:108-119, 168-177, 226-235: a circuit is built and preprocessed, then
+`prover.clear_witness()` and the same gadget calls on OTHER witnesses, then the second proof.  Here: after clear_witness the
+composer counts from StandardComposer::new()'s state again; appends that repeat the previous build find their rows in
+place and write only assignments.  Every test compares the whole composer (all nine columns, every limb) with the CPU oracle's
+composer built FRESH from the second witnesses: rows kept from the first build must equal rows the reference would emit for
+the second (structure is witness-independent), assignments must be the second build's.  A deliberately corrupted limb in a
+kept row must survive the refresh (nothing rewrites rows in place) and vanish when the circuit changes (everything is
+emitted again)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import plonk_gadgets_amd as pg
+from plonk_gadgets_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+COLS = ("q_m", "q_l", "q_r", "q_o", "q_c", "w_l", "w_r", "w_o", "var_values")
+Q = synth.Q
+S = pg.BlsScalar.from_int
+
+
+@pytest.fixture(scope="module")
+def engine():
+    e = pg.Engine(0)
+    yield e
+    e.close()
+
+
+def same(dev, ora):
+    got, exp = dev.export(), ora.export()
+    assert dev.circuit_size() == ora.n and dev.num_variables() == ora.num_vars
+    for k in COLS:
+        assert got[k].shape == exp[k].shape, k
+        if not np.array_equal(got[k], exp[k]):
+            bad = np.argwhere(got[k] != exp[k])[0]
+            raise AssertionError(f"{k} differs first at {bad.tolist()}")
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:0")
+
+
+def F(x):
+    from oracle import pyoracle as po
+    return po.fr(synth.mont(x))
+
+
+def program(dev, ora, ws, bounds=(50_000, 250_000), extra_rows=0):
+    """the reference's loop (allocate, range_check, constrain the outcome) over `ws`, then single composer calls with and
+    without public inputs, a max_bound, a select (a call on existing Variables: always emitted in full); on the device
+    composer and on the oracle's.  Returns the outcomes' Variables."""
+    from oracle import pyoracle as po
+    mn, mx = bounds
+    out = []
+    for w in ws:
+        a = pg.AllocatedScalar.allocate(dev, S(w))
+        r = pg.range_check(dev, S(mn), S(mx), a)
+        oa = ora.allocate(synth.mont(w))
+        orr = int(ora.L.range_check(ora.c, F(mn), F(mx), oa))
+        assert r == orr
+        out.append(r)
+    x, y = dev.add_input(S(ws[0] + 1)), dev.add_input(S(ws[-1] + 2))
+    ox, oy = ora.add_input(synth.mont(ws[0] + 1)), ora.add_input(synth.mont(ws[-1] + 2))
+    s1 = dev.add((S(3), x), (S(-5), y), S(7), None)
+    assert s1 == ora.L.composer_add(ora.c, F(3), ox, F(-5), oy, F(7), None)
+    pi = F(77)
+    s2 = dev.mul(S(2), s1, x, S(1), S(77))
+    assert s2 == ora.L.composer_mul(ora.c, F(2), s1, ox, F(1), C.byref(pi))
+    one = dev.add_witness_to_circuit_description(S(1))
+    assert one == ora.L.composer_add_witness_to_circuit_description(ora.c, F(1))
+    dev.boolean_gate(one)
+    ora.L.composer_boolean_gate(ora.c, one)
+    mb, nb = pg.max_bound(dev, S(2**40), pg.AllocatedScalar(x, S(ws[0] + 1)))
+    onb = C.c_uint64()
+    assert mb == int(ora.L.max_bound(ora.c, F(2**40), po.AllocatedScalar(ox, F(ws[0] + 1)), C.byref(onb)))
+    z = pg.conditionally_select_zero(dev, s2, out[0])
+    assert z == int(ora.L.conditionally_select_zero(ora.c, s2, out[0]))
+    for _ in range(extra_rows):
+        dev.assert_equal(x, x)
+        ora.L.composer_assert_equal(ora.c, ox, ox)
+    return out
+
+
+def test_prove_twice_flow(engine):
+    """build, clear_witness, the same calls on other witnesses: == a fresh oracle composer of the second witnesses; the rows
+    were found in place (stats), a corrupted limb in one of them survives, the public inputs are the second build's"""
+    from oracle import pyoracle as po
+    wa = [50_001, 250_000, 49_999, 123_456, 7]
+    wb = [249_999, 50_000, 260_000, 3, 100_000]
+    dev = pg.StandardComposer(engine, 1 << 12, 1 << 13)
+    ora_a = po.Composer()
+    program(dev, ora_a, wa)
+    same(dev, ora_a)
+    assert dev.check() == -1
+    n_rows = dev.circuit_size()
+    # a limb of a range_check row (a queued gadget call) and of a single gate row, bent
+    cols = dev.device_columns()
+    keep = (int(cols.q_l[40, 1]), int(cols.q_c[n_rows - 3, 0]))
+    cols.q_l[40, 1] ^= 0x55
+    torch.cuda.synchronize()
+    dev.clear_witness()
+    assert (dev.circuit_size(), dev.num_variables()) == (3, 5)
+    ora_b = po.Composer()
+    res = program(dev, ora_b, wb)
+    kept, rewritten, refreshing = dev.refresh_stats()
+    # everything but the select's row (a call on existing Variables: emitted in full, unsigned) was found in place
+    assert refreshing and rewritten == 0 and kept == n_rows - 3 - 1, (kept, rewritten, n_rows)
+    got = dev.export()
+    assert got["q_l"][40, 1] == np.uint64(keep[0] ^ 0x55), "a row found in place was written again"
+    cols = dev.device_columns()
+    cols.q_l[40, 1] ^= 0x55
+    torch.cuda.synchronize()
+    same(dev, ora_b)
+    assert dev.check() == -1
+    assert [dev.value(r).to_int() for r in res] == [1, 1, 0, 0, 1]
+    pi = dev.construct_dense_pi_vec().cpu().numpy().view(np.uint64)
+    assert int(np.count_nonzero(pi.any(axis=1))) == 1  # one public input, not two
+
+
+def test_another_circuit_after_clear_witness_is_emitted_in_full(engine):
+    """the second build changes a public bound half way: what matched before it stays in place, everything from there on is
+    written again -- a bent limb in a LATER row disappears -- and the composer equals the oracle's for the new circuit; a
+    third build then refreshes against the second"""
+    from oracle import pyoracle as po
+    wa = [50_001, 250_000, 49_999, 123_456]
+    dev = pg.StandardComposer(engine, 1 << 12, 1 << 13)
+    program(dev, po.Composer(), wa)
+    n1 = dev.circuit_size()
+    cols = dev.device_columns()
+    cols.q_c[n1 - 2, 0] ^= 0x1234  # the max_bound's last row region: will be rewritten
+    torch.cuda.synchronize()
+    dev.clear_witness()
+    ora = po.Composer()
+    # two loop iterations as before, then ANOTHER bound: a longer ladder, more rows
+    first = program_prefix(dev, ora, wa[:2], (50_000, 250_000))
+    rest = program(dev, ora, [5, 6], bounds=(0, 2**64), extra_rows=2)
+    kept, rewritten, refreshing = dev.refresh_stats()
+    assert not refreshing and kept == 2 * 87 and rewritten > 0
+    same(dev, ora)
+    assert dev.check() == -1
+    # third build == second: everything signed is in place again
+    dev.clear_witness()
+    ora3 = po.Composer()
+    program_prefix(dev, ora3, [70_000, 1], (50_000, 250_000))
+    program(dev, ora3, [2**63, 2**65], bounds=(0, 2**64), extra_rows=2)
+    kept3, rewritten3, refreshing3 = dev.refresh_stats()
+    assert refreshing3 and rewritten3 == 0 and kept3 == dev.circuit_size() - 3 - 1
+    same(dev, ora3)
+    assert dev.check() == -1 and first and rest
+
+
+def program_prefix(dev, ora, ws, bounds):
+    mn, mx = bounds
+    out = []
+    for w in ws:
+        a = pg.AllocatedScalar.allocate(dev, S(w))
+        out.append(pg.range_check(dev, S(mn), S(mx), a))
+        assert out[-1] == int(ora.L.range_check(ora.c, F(mn), F(mx), ora.allocate(synth.mont(w))))
+    return out
+
+
+@pytest.mark.parametrize("queue", [True, False])
+def test_shorter_and_longer_rebuilds(engine, queue):
+    """a rebuild that stops early, then one that runs past the first build's end; with the command queue and with one launch
+    per call"""
+    from oracle import pyoracle as po
+    dev = pg.StandardComposer(engine, 1 << 12, 1 << 13)
+    dev.queue(queue)
+    program(dev, po.Composer(), [60_000, 70_000, 80_000], extra_rows=3)
+    dev.clear_witness()
+    ora = po.Composer()
+    program_prefix(dev, ora, [1, 200_000], (50_000, 250_000))  # stops early
+    same(dev, ora)
+    assert dev.refresh_stats() == (2 * 87, 0, True)
+    dev.clear_witness()
+    ora = po.Composer()
+    program(dev, ora, [90_000, 2, 250_001], extra_rows=6)  # the whole first build again, and three rows more
+    kept, rewritten, _ = dev.refresh_stats()
+    assert rewritten == 3 and kept > 3 * 87
+    same(dev, ora)
+    assert dev.check() == -1
+
+
+def test_batched_appends_refresh(engine):
+    """pg_composer_range_check_batch / _max_bound_batch / _scalar_mix_batch on witness scalars: in place on the second build
+    (a mix batch with a failing item is not: its shape depends on its witnesses), equal to the oracle's composer throughout"""
+    from oracle import pyoracle as po
+    import test_gpu_gadgets as tg
+    mn, mx = 7, 2**40 + 3
+
+    def build(dev, ora, seed, zeros):
+        w = np.concatenate([synth.scalars_from_ints([mn + int(v) % (mx - mn) for v in synth.splitmix64(30, seed)]),
+                            synth.random_scalars(31, seed + 1)])
+        r = dev.range_check_batch(S(mn), S(mx), t(w))
+        o = [int(ora.L.range_check(ora.c, F(mn), F(mx), ora.allocate(x))) for x in w]
+        assert r.cpu().numpy().view(np.uint64).tolist() == o
+        w2 = synth.scalars_from_ints([int(v) % (2 * 10**9) for v in synth.splitmix64(50, seed + 2)])
+        r2, nb = dev.max_bound_batch(S(10**9), t(w2))
+        onb = C.c_uint64()
+        o2 = [int(ora.L.max_bound(ora.c, F(10**9), ora.allocate(x), C.byref(onb))) for x in w2]
+        assert r2.cpu().numpy().view(np.uint64).tolist() == o2 and nb == onb.value
+        v, y, s, a, b = tg.mix_inputs(300, seed + 3, zeros)
+        _, err, nerr = dev.scalar_mix_batch(t(v), t(y), t(s), t(a), t(b))
+        assert nerr == len(zeros)
+        for i in range(300):  # the fused item on the oracle's composer: five add_input, is_non_zero, select_one, maybe_equal
+            vv, yy, ss = ora.add_input(v[i]), ora.add_input(y[i]), ora.add_input(s[i])
+            aa, bb = ora.allocate(a[i]), ora.allocate(b[i])
+            ora.L.is_non_zero(ora.c, vv, po.fr(v[i]))
+            ora.L.conditionally_select_one(ora.c, yy, ss)
+            ora.L.maybe_equal(ora.c, aa, bb)
+        x = dev.add_input(S(5))  # (a constant is public: the same in every build)
+        assert x == ora.add_input(synth.mont(5))
+        dev.constrain_to_constant(x, S(5), None)
+        ora.L.composer_constrain_to_constant(ora.c, x, F(5), None)
+
+    dev = pg.StandardComposer(engine, 1 << 16, 1 << 17)
+    ora = po.Composer()
+    build(dev, ora, 100, ())
+    same(dev, ora)
+    n1 = dev.circuit_size()
+    dev.clear_witness()
+    ora = po.Composer()
+    build(dev, ora, 200, ())
+    kept, rewritten, refreshing = dev.refresh_stats()
+    assert refreshing and kept == n1 - 3 and rewritten == 0, (kept, rewritten, n1)
+    same(dev, ora)
+    assert dev.check() == -1
+    # a failing item in the mix: that append (and nothing before it) is emitted in full, and what follows it too
+    dev.clear_witness()
+    ora = po.Composer()
+    build(dev, ora, 300, (17,))
+    kept, rewritten, refreshing = dev.refresh_stats()
+    assert not refreshing and kept == 61 * (4 * 42 + 11) + 50 * (2 * 31 + 5) and rewritten == 10 * 300 - 2 + 1
+    same(dev, ora)
+
+
+def test_growing_during_a_refresh_keeps_the_rows_in_place(engine):
+    from oracle import pyoracle as po
+    dev = pg.StandardComposer(engine, 400, 2600)
+    program(dev, po.Composer(), [60_000, 70_000, 80_000])
+    n1 = dev.circuit_size()
+    dev.clear_witness()
+    dev.reserve(5000, 9000)  # new buffers while only the initial rows are live: the first build's rows must come along
+    ora = po.Composer()
+    program(dev, ora, [1, 2, 100_000])
+    assert dev.refresh_stats() == (n1 - 3 - 1, 0, True)
+    same(dev, ora)
+    assert dev.check() == -1
+
+
+def test_clear_witness_argument_checks(engine):
+    from plonk_gadgets_amd import _lib
+    lib = _lib.load()
+    assert lib.pg_composer_clear_witness(None) == 2
+    assert lib.pg_composer_refresh_stats(None, None, None, None) == 2
+    dev = pg.StandardComposer(engine)
+    dev.clear_witness()  # nothing built yet
+    assert dev.refresh_stats() == (0, 0, False) and (dev.circuit_size(), dev.num_variables()) == (3, 5)
+    assert dev.check() == -1
