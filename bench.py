@@ -200,14 +200,15 @@ def cpu_baseline(workload: str, sample: int):
         wit = synth.random_scalars(nwit, seed=synth.SEED)
         sweep = []
         for threads in sorted({min(16, ncpu), min(64, ncpu), ncpu}):
-            best_of = min((po.range_check_fast(synth.mont(0), synth.mont(2**254), wit, threads=threads) for _ in range(2)),
-                          key=lambda r: r["seconds"])
+            # (three passes over fresh arrays, the last one timed: the first lets every thread first-touch the output pages
+            # it writes -- timed from the main thread's zero-fill instead, 256 threads were slower than 16: page placement)
+            best_of = po.range_check_fast(synth.mont(0), synth.mont(2**254), wit, threads=threads, timed_passes=3)
             sweep.append({"cores": threads, "value": best_of["n_gates"] / best_of["seconds"], "seconds": round(best_of["seconds"], 4)})
         best = max(sweep, key=lambda r: r["value"])
         base["fast_variant"] = {"value": best["value"], "unit": "constraints/s", "cores": best["cores"],
                                 "kind": "port (table-driven, threaded: oracle/fast.c)", "nproc": ncpu, "thread_sweep": sweep,
                                 "sample": f"{nwit} witnesses, {best_of['n_gates']} rows, {best['seconds']:.3f} s with {best['cores']} "
-                                          "threads (7.3 GB written to host memory; best of two runs per thread count)"}
+                                          "threads (7.3 GB written to host memory; the third pass over arrays the threads touched first themselves)"}
     return base
 
 
@@ -348,6 +349,62 @@ def measure(wl: Workload, steps: int, warmup: int, sync_all):
     elapsed = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in events]
     return elapsed, kernel_ms
+
+
+def next_rows_secondary(eng, dev, log2_batch: int, steps: int):
+    """SURVEY 8f rows on a composer holding 2^log2_batch x range_check(0, 2^254): f1 pg_composer_materialize (per row 328 B
+    written -- seven constant columns, w_4, three wire-value columns -- and 24 B of wire indices + 96 B of gathered assignments
+    read) and f2 pg_composer_permutation (24 B of wire indices read per row, four sigma columns of 8 B written per PADDED
+    row).  Both calls are synchronous; outputs are allocated once, ahead of the timed calls."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    import plonk_gadgets_amd as pg
+    from plonk_gadgets_amd import _lib, synth
+    lib = _lib.load()
+    batch = 1 << log2_batch
+    comp = pg.StandardComposer(eng, 3 + batch * 1031 + 8, 5 + batch * 1034 + 8)
+    wit = torch.from_numpy(synth.random_scalars(batch, seed=synth.SEED + 2).view(np.int64)).to(dev)
+    comp.range_check_batch(pg.BlsScalar.from_int(0), pg.BlsScalar.from_int(2**254), wit)
+    n = comp.circuit_size()
+    padded = 1 << (n - 1).bit_length()
+    names = ("q_4", "q_arith", "q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add", "w_4_value", "w_l_value",
+             "w_r_value", "w_o_value")
+    t = {k: torch.empty((n, 4), dtype=torch.int64, device=dev) for k in names}
+    t["w_4"] = torch.empty((n,), dtype=torch.int64, device=dev)
+    sigma = torch.empty((4, padded), dtype=torch.int64, device=dev)
+    fc = _lib.FullColumnsC(**{k: v.data_ptr() for k, v in t.items()})
+
+    def timed(fn):
+        fn()  # warm-up (scratch of the permutation is grow-only)
+        ms = []
+        for _ in range(max(3, min(steps, 10))):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            assert fn() == 0
+            torch.cuda.synchronize(dev)
+            ms.append((time.perf_counter() - t0) * 1e3)
+        ms.sort()
+        return ms[len(ms) // 2], ms[0], ms[-1]
+
+    out = {"config": {"workload": "composer of 2^%d x (allocate + range_check(0, 2^254)): %d rows, sigma padded to %d" % (log2_batch, n, padded)}}
+    med, lo, hi = timed(lambda: lib.pg_composer_materialize(comp._h, C.byref(fc)))
+    wr, rd = 328 * n, 120 * n
+    out["materialize"] = {"ms": {"min": lo, "median": med, "max": hi}, "rows_per_s": n / (med / 1e3),
+                          "roofline": {"bound": "hbm", "achieved": (wr + rd) / (med / 1e3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                       "frac": (wr + rd) / (med / 1e3) / 1e9 / HBM_PEAK_GBPS,
+                                       "algorithmic_bytes": {"written": wr, "read": rd},
+                                       "frac_counting_writes_only": wr / (med / 1e3) / 1e9 / HBM_PEAK_GBPS,
+                                       "kernel": "pg::materialize_kernel (one launch: constant columns, w_4, three gathers)"}}
+    med, lo, hi = timed(lambda: lib.pg_composer_permutation(comp._h, padded, sigma.data_ptr()))
+    pb = 24 * n + 32 * padded
+    out["permutation"] = {"ms": {"min": lo, "median": med, "max": hi}, "rows_per_s": n / (med / 1e3),
+                          "roofline": {"bound": "hbm", "achieved": pb / (med / 1e3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                       "frac": pb / (med / 1e3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": pb,
+                                       "kernel": "pg::perm_item_kernel + perm_identity_kernel (+ the sparse list's sort)"}}
+    del comp, t, sigma
+    torch.cuda.empty_cache()
+    return out
 
 
 def kernel_sources_sha256() -> str:
@@ -509,6 +566,10 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as ex:  # a secondary figure must never cost the headline line
                 secondary[name] = {"error": repr(ex)}
+        try:  # the rows that come next: materialisation and sigma on a 270 M-row composer
+            secondary["next_rows"] = next_rows_secondary(eng, dev, min(18, args.log2_batch), args.steps)
+        except Exception as ex:
+            secondary["next_rows"] = {"error": repr(ex)}
 
     line = {
         "metric": "gadget constraints/sec (range_check 256-bit)" if args.workload == "c2"

@@ -237,24 +237,23 @@ pg_status ensure_inv_scratch(pg_engine *e, uint64_t elems) {
 
 // The engine's scratch (plan counts, pre-pass products, the pinned plan result) is shared by consecutive calls and is
 // ordered only by the stream they are issued on.  A caller that moves to ANOTHER stream is made to wait for everything
-// the engine still has in flight on the previous one (and on the side stream, which joins it).
+// the engine still has in flight on the previous one (and on the side stream, which joins it): every call records, when
+// it has enqueued its last work, an event on ITS OWN stream (StreamScope), and a call that finds itself on another
+// stream than the last waits for that event.  The previous stream's handle is only ever compared, never used: the caller
+// may have destroyed that stream since (the header allows it), and a handle that has been recycled for a new stream would
+// otherwise have an event recorded on it that orders nothing.
 pg_status enter_stream(pg_engine *e, hipStream_t st) {
     PG_HIP_TRY(hipSetDevice(e->device));
-    if (e->have_last && e->last_stream != st) {
-        // (the previous stream may be gone -- a caller may destroy a stream it has synchronised: then nothing of the engine
-        // is in flight on it, but to be safe against handles that merely look dead the device is synchronised once)
-        if (hipEventRecord(e->ev_switch, e->last_stream) == hipSuccess) {
-            PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_switch, 0));
-        } else {
-            (void)hipGetLastError();
-            e->have_last = false;
-            PG_HIP_TRY(hipDeviceSynchronize());
-        }
-    }
+    if (e->have_last && e->last_stream != st) PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_switch, 0));
     e->last_stream = st;
     e->have_last = true;
     return PG_OK;
 }
+struct StreamScope {  // declared right after enter_stream succeeds; its destructor runs on every way out of the call
+    pg_engine *e;
+    hipStream_t st;
+    ~StreamScope() { (void)hipEventRecord(e->ev_switch, st); }
+};
 
 #ifndef PG_INV_LANES_PER_CU  // lanes of the pre-pass per CU (256 = one wave per SIMD)
 #define PG_INV_LANES_PER_CU 256
@@ -324,6 +323,7 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
     if ((batch + GD::W - 1) / GD::W > 0xffffffffull) return fail(PG_ERR_INVALID_ARGUMENT, "batch too large for one call");
     hipStream_t st = static_cast<hipStream_t>(stream);
     PG_TRY(enter_stream(e, st));
+    StreamScope scope{e, st};
     if constexpr (pg::Split<GD>::ok) {
         return launch_mix(e, A, c, batch, gate_base, var_base, zero_var, row_off, var_off, st, planned, values_only);
     } else {
@@ -407,6 +407,7 @@ pg_status error_plan(pg_engine *e, PlanKernel kernel, const pg_scalar *d_value, 
     if (err_count) *err_count = 0;
     if (batch == 0) {  // stream-ordered like every other write of the plan result
         PG_TRY(enter_stream(e, static_cast<hipStream_t>(stream)));
+        StreamScope scope{e, static_cast<hipStream_t>(stream)};
         PG_HIP_TRY(hipMemsetAsync(e->h_plan, 0, sizeof(pg_engine::PlanResult), static_cast<hipStream_t>(stream)));
         return PG_OK;
     }
@@ -416,6 +417,7 @@ pg_status error_plan(pg_engine *e, PlanKernel kernel, const pg_scalar *d_value, 
     PG_TRY(ensure_scratch(e, batch));
     hipStream_t st = static_cast<hipStream_t>(stream);
     PG_TRY(enter_stream(e, st));
+    StreamScope scope{e, st};
     if (!out) return error_plan_launch(e, kernel, d_value, batch, d_row_off, d_var_off, d_err_mask, st);
     // e->d_err_count is zero between calls: whoever reads it (scan_final_kernel, the bulk decoder) leaves it so
     const uint32_t grid = (uint32_t)((batch + pg::kScanBlock - 1) / pg::kScanBlock);
@@ -771,6 +773,7 @@ static pg_status max_bound_ragged_plan_common(pg_engine *e, const pg_scalar *d_m
     if (out) std::memset(out, 0, sizeof *out);
     if (batch == 0) {
         PG_TRY(enter_stream(e, static_cast<hipStream_t>(stream)));
+        StreamScope scope{e, static_cast<hipStream_t>(stream)};
         PG_HIP_TRY(hipMemsetAsync(e->h_plan, 0, sizeof(pg_engine::PlanResult), static_cast<hipStream_t>(stream)));
         return PG_OK;
     }
@@ -781,6 +784,7 @@ static pg_status max_bound_ragged_plan_common(pg_engine *e, const pg_scalar *d_m
     PG_TRY(ensure_scratch(e, batch));
     hipStream_t st = static_cast<hipStream_t>(stream);
     PG_TRY(enter_stream(e, st));
+    StreamScope scope{e, st};
     const uint32_t grid = (uint32_t)((batch + pg::kScanBlock - 1) / pg::kScanBlock);
     hipLaunchKernelGGL(pg::max_bound_plan_kernel, dim3(grid), dim3(pg::kThreads), 0, st,
                        reinterpret_cast<const uint4 *>(d_max_range), batch, e->d_pow2, d_num_bits, e->d_rows, e->d_vars,

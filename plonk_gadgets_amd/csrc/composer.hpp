@@ -38,6 +38,12 @@ __device__ __forceinline__ void put_fr(uint4 *col, uint64_t i, const Fr &f) {
     col[2 * i] = t.v[0];
     col[2 * i + 1] = t.v[1];
 }
+// the same from a scalar that lies in memory (a queued command's field), limb by limb: no copy of the aggregate
+__device__ __forceinline__ void put_fr_at(uint4 *col, uint64_t i, const Fr *src) {
+    const uint64_t l0 = src->l[0], l1 = src->l[1], l2 = src->l[2], l3 = src->l[3];
+    col[2 * i] = make_uint4((uint32_t)l0, (uint32_t)(l0 >> 32), (uint32_t)l1, (uint32_t)(l1 >> 32));
+    col[2 * i + 1] = make_uint4((uint32_t)l2, (uint32_t)(l2 >> 32), (uint32_t)l3, (uint32_t)(l3 >> 32));
+}
 __device__ __forceinline__ Fr get_fr(const uint4 *col, uint64_t i) {
     FrVec t;
     t.v[0] = col[2 * i];
@@ -78,40 +84,47 @@ __global__ void gate_kernel(const GateCmd cmd, const ComposerCols C) {
 // outputs of add / mul level by level; the assignments the run creates live in LDS (Variables first_var .. first_var +
 // up to kQueueRun - 1) so that a command reads its predecessors' outputs without a trip through memory.
 constexpr uint32_t kQueueRun = 1024;
-__global__ __launch_bounds__(1024) void gate_queue_kernel(const GateCmd *cmds, uint32_t n, uint64_t first_var, uint32_t max_level,
+// (one workgroup per launch: nothing is gained by leaving registers to a second one, and the compiler, aiming at the two
+// workgroups per CU the LDS would allow, spilled)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void gate_queue_kernel(const GateCmd *cmds, uint32_t n, uint64_t first_var, uint32_t max_level,
                                                           const ComposerCols C) {
     __shared__ uint4 s_val[2 * kQueueRun];
     const uint32_t tid = threadIdx.x;
-    GateCmd cmd{};
-    if (tid < n) cmd = cmds[tid];
-    const bool in_place = (cmd.op & OP_ROW_IN_PLACE) != 0;
-    cmd.op &= ~OP_ROW_IN_PLACE;
-    const bool creates = tid < n && (cmd.op == OP_ADD || cmd.op == OP_MUL);
+    // (a command is 224 bytes: what a phase needs of it is read when the phase needs it -- held in registers across the
+    // level loop, the five selectors and the public input spilled)
+    const GateCmd *mine = cmds + (tid < n ? tid : 0);
+    uint32_t op = tid < n ? mine->op : (uint32_t)OP_ROW | OP_ROW_IN_PLACE;
+    const bool in_place = (op & OP_ROW_IN_PLACE) != 0;
+    op &= ~OP_ROW_IN_PLACE;
+    const bool creates = tid < n && (op == OP_ADD || op == OP_MUL);
+    const uint32_t level = creates ? mine->pad : 0;
+    const uint64_t var = mine->var, wa = mine->a, wb = mine->b;
     if (tid < n) {
-        if (cmd.op == OP_ADD_INPUT) {
-            put_fr(C.vars, cmd.var, cmd.value);
-            put_fr(s_val, cmd.var - first_var, cmd.value);
+        if (op == OP_ADD_INPUT) {
+            put_fr_at(C.vars, var, &mine->value);
+            put_fr_at(s_val, var - first_var, &mine->value);
         } else if (!in_place) {
-            put_fr(C.q[0], cmd.gate, cmd.q_m);
-            put_fr(C.q[1], cmd.gate, cmd.q_l);
-            put_fr(C.q[2], cmd.gate, cmd.q_r);
-            put_fr(C.q[3], cmd.gate, cmd.q_o);
-            put_fr(C.q[4], cmd.gate, cmd.q_c);
-            C.w[0][cmd.gate] = cmd.a;
-            C.w[1][cmd.gate] = cmd.b;
-            C.w[2][cmd.gate] = creates ? cmd.var : cmd.c;
+            const uint64_t gate = mine->gate;
+            put_fr_at(C.q[0], gate, &mine->q_m);
+            put_fr_at(C.q[1], gate, &mine->q_l);
+            put_fr_at(C.q[2], gate, &mine->q_r);
+            put_fr_at(C.q[3], gate, &mine->q_o);
+            put_fr_at(C.q[4], gate, &mine->q_c);
+            C.w[0][gate] = wa;
+            C.w[1][gate] = wb;
+            C.w[2][gate] = creates ? var : mine->c;
         }
     }
     __syncthreads();
     for (uint32_t lvl = 1; lvl <= max_level; lvl++) {
-        if (creates && cmd.pad == lvl) {
+        if (level == lvl) {
             // an operand created by this run sits in LDS (its command has a lower level: done); any other is older
-            const Fr a = cmd.a >= first_var && cmd.a - first_var < kQueueRun ? get_fr(s_val, cmd.a - first_var) : get_fr(C.vars, cmd.a);
-            const Fr b = cmd.b >= first_var && cmd.b - first_var < kQueueRun ? get_fr(s_val, cmd.b - first_var) : get_fr(C.vars, cmd.b);
-            Fr v = cmd.op == OP_ADD ? fr_add(fr_mul(cmd.q_l, a), fr_mul(cmd.q_r, b)) : fr_mul(fr_mul(cmd.q_m, a), b);
-            v = fr_add(fr_add(v, cmd.q_c), cmd.pi);
-            put_fr(C.vars, cmd.var, v);
-            put_fr(s_val, cmd.var - first_var, v);
+            const Fr a = wa >= first_var && wa - first_var < kQueueRun ? get_fr(s_val, wa - first_var) : get_fr(C.vars, wa);
+            const Fr b = wb >= first_var && wb - first_var < kQueueRun ? get_fr(s_val, wb - first_var) : get_fr(C.vars, wb);
+            Fr v = op == OP_ADD ? fr_add(fr_mul(mine->q_l, a), fr_mul(mine->q_r, b)) : fr_mul(fr_mul(mine->q_m, a), b);
+            v = fr_add(fr_add(v, mine->q_c), mine->pi);
+            put_fr(C.vars, var, v);
+            put_fr(s_val, var - first_var, v);
         }
         __syncthreads();
     }
@@ -221,31 +234,62 @@ __global__ __launch_bounds__(kThreads) void check_kernel(const ComposerCols C, u
     }
 }
 
-// ---- the rest of a prover-ready row ------------------------------------
-// constant columns (the selectors this path never switches on, q_arith = 1, the value column of a fourth wire that is
-// zero_var on every row): up to 7 columns per launch, each workgroup writing contiguous 1 MiB pieces of each
-struct ConstCols {
-    uint4 *p[7];
-    uint32_t n, one_mask;  // column k holds 1 (Montgomery R) if bit k of one_mask is set, else 0
+// pg_composer_materialize in ONE pass: per row the seven constant columns (q_arith = 1, the rest 0, the value
+// of the fourth wire = 0), w_4 = zero_var, and the three wire-VALUE columns out[i] = variables[w[i]] -- 328 B written and
+// 24 B of indices + 96 B of assignments read per row.  Two lanes per row (16-byte halves, every wave store one contiguous
+// KiB per column), two rows' worth per lane and pass: the six dependent loads (index, then assignment) of a pass are in
+// flight together, and the constant stores keep the write queues busy meanwhile (as three kernels of one dependent chain per
+// lane the gathers ran at 2.3 TB/s).  Any output pointer may be NULL.
+struct MaterializeOut {
+    uint4 *konst[7];  // q_4, q_arith, q_range, q_logic, q_fixed_group_add, q_variable_group_add, w_4_value
+    uint4 *val[3];    // w_l_value, w_r_value, w_o_value
+    uint64_t *w_4;
 };
-__global__ __launch_bounds__(kThreads) void fill_columns_kernel(const ConstCols K, uint64_t n_rows) {
-    constexpr uint64_t kPiece = 65536;
+__global__ __launch_bounds__(kThreads) void materialize_kernel(const ComposerCols C, const MaterializeOut M, uint64_t n_rows,
+                                                              uint64_t zero_var) {
+    constexpr uint64_t kPiece = 16384;  // 16-byte units per workgroup piece = 8192 rows
+    constexpr int U = 2;            // (1 or 4, pieces of 64 Ki units: the same 5.9 TB/s of reads + writes, profiles/NOTES_r04.md)
     FrVec one;
     one.f = fr_one();
-    const uint4 v1 = one.v[threadIdx.x & 1], v0 = make_uint4(0, 0, 0, 0);
-    for (uint64_t base = (uint64_t)blockIdx.x * kPiece; base < 2 * n_rows; base += (uint64_t)gridDim.x * kPiece) {
-        const uint64_t end = base + kPiece < 2 * n_rows ? base + kPiece : 2 * n_rows;
-        for (uint32_t k = 0; k < K.n; k++) {
-            const uint4 v = K.one_mask >> k & 1 ? v1 : v0;
-            for (uint64_t i = base + threadIdx.x; i < end; i += kThreads) store16(K.p[k] + i, v);
+    const uint4 v1 = (threadIdx.x & 1) ? one.v[1] : one.v[0], v0 = make_uint4(0, 0, 0, 0);  // (a select: indexing the halves by the lane costs scratch)
+    const uint64_t units = 2 * n_rows;
+    for (uint64_t base = (uint64_t)blockIdx.x * kPiece; base < units; base += (uint64_t)gridDim.x * kPiece) {
+        const uint64_t end = base + kPiece < units ? base + kPiece : units;
+        for (uint64_t i0 = base + threadIdx.x; i0 < end; i0 += (uint64_t)U * kThreads) {
+            uint64_t idx[U][3];
+            uint4 got[U][3];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint64_t i = i0 + (uint64_t)u * kThreads, r = (i < end ? i : end - 1) >> 1;
+#pragma unroll
+                for (int k = 0; k < 3; k++) idx[u][k] = M.val[k] ? C.w[k][r] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint64_t i = i0 + (uint64_t)u * kThreads;
+#pragma unroll
+                for (int k = 0; k < 3; k++) got[u][k] = C.vars[2 * idx[u][k] + (i & 1)];  // (a column not asked for: Variable 0, unused)
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint64_t i = i0 + (uint64_t)u * kThreads;
+                if (i < end) {
+#pragma unroll
+                    for (int k = 0; k < 7; k++)
+                        if (M.konst[k]) store16(M.konst[k] + i, k == 1 ? v1 : v0);
+                    if (M.w_4 && !(i & 1)) M.w_4[i >> 1] = zero_var;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint64_t i = i0 + (uint64_t)u * kThreads;
+                if (i < end) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+                        if (M.val[k]) store16(M.val[k] + i, got[u][k]);
+                }
+            }
         }
-    }
-}
-__global__ __launch_bounds__(kThreads) void fill_u64_kernel(uint64_t *dst, uint64_t n, uint64_t value) {
-    constexpr uint64_t kPiece = 131072;
-    for (uint64_t base = (uint64_t)blockIdx.x * kPiece; base < n; base += (uint64_t)gridDim.x * kPiece) {
-        const uint64_t end = base + kPiece < n ? base + kPiece : n;
-        for (uint64_t i = base + threadIdx.x; i < end; i += kThreads) dst[i] = value;
     }
 }
 // rows with a live fourth wire: q_4, w_4 and the value of w_4 (each may be NULL)

@@ -69,7 +69,7 @@ struct PermCtx {
 
 constexpr uint32_t kPermIters = 16;                               // gates per thread of the gap kernel
 constexpr uint64_t kPermChunk = (uint64_t)kThreads * kPermIters;  // gates per workgroup of the gap kernel
-constexpr uint32_t kPermRowsPerThread = 5;  // item kernel: rows loaded per thread before any is processed
+constexpr uint32_t kPermRowsPerThread = 4;  // item kernel: rows loaded per thread before any is processed (5 spilled at the 72 registers seven workgroups per CU leave)
 constexpr uint32_t kPermLocalLdsLimit = 64 * 1024 - 256;
 constexpr uint32_t kPermNone = 0xFFFF, kPermDone = 0xFFFE;
 
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kThreads, 7) void perm_item_kernel(const PermCtx X,
         for (uint32_t id = tid; id < V; id += kThreads) cnt[id] = 0;
         if (tid == 0) s_foreign = s_rank = 0;
         __syncthreads();
-        for (uint32_t rb = 0; rb < L; rb += kPermRowsPerThread * kThreads) {  // 15 loads in flight per thread
+        for (uint32_t rb = 0; rb < L; rb += kPermRowsPerThread * kThreads) {  // 12 loads in flight per thread
             uint64_t var[kPermRowsPerThread][3];
 #pragma unroll
             for (uint32_t u = 0; u < kPermRowsPerThread; u++) {

@@ -147,8 +147,15 @@ def test_config_c4_full_size_properties(engine, form):
     assert (lay.n_gates, lay.n_vars) == (int((2 * n64 + 5).sum()), int((n64 + 262).sum()))
     assert bool((roff[1:] - roff[:-1] == 2 * n64 + 5).all()) and int(roff[0]) == 0 and int(roff[-1]) == lay.n_gates
     assert bool((voff[1:] - voff[:-1] == n64 + 262).all()) and int(voff[0]) == 0 and int(voff[-1]) == lay.n_vars
-    cols = pg.Columns.allocate(lay.n_gates, lay.n_vars, "cuda:0", 3, 5)
-    res = torch.empty((BATCH,), dtype=torch.int64, device="cuda:0")
+    # every output array 64 entries longer than the layout and filled with a sentinel: a slot nobody writes fails the row check
+    # below, a store beyond the layout shows in the tails
+    GUARD = 64
+    big = pg.Columns.allocate(lay.n_gates + GUARD, lay.n_vars + GUARD, "cuda:0", 3, 5)
+    for name in SEL + WIRES + ("var_values",):
+        getattr(big, name).fill_(-1)
+    cols = pg.Columns(**{n: getattr(big, n)[:lay.n_gates] for n in SEL + WIRES}, var_values=big.var_values[:lay.n_vars],
+                      gate_base=3, var_base=5)
+    res = torch.full((BATCH + GUARD,), -1, dtype=torch.int64, device="cuda:0")[:BATCH]
     if form == "async_plan":  # plan again, this time without the round trip, straight into the emit call
         nb.fill_(0)
         roff.fill_(-1)
@@ -162,6 +169,9 @@ def test_config_c4_full_size_properties(engine, form):
         assert bool((nb.to(torch.int64) == n64).all())
         assert bool((roff[1:] - roff[:-1] == 2 * n64 + 5).all()) and int(roff[0]) == 0 and int(roff[-1]) == lay.n_gates
         assert bool((voff[1:] - voff[:-1] == n64 + 262).all()) and int(voff[0]) == 0 and int(voff[-1]) == lay.n_vars
+    for name in SEL + WIRES:  # nothing beyond the layout was touched
+        assert bool((getattr(big, name)[lay.n_gates:] == -1).all()), name
+    assert bool((big.var_values[lay.n_vars:] == -1).all())
     # every one of the 5.3e8 rows satisfies its gate equation over the emitted variable table
     assert engine.check_rows(cols, var_base=5) == -1
     # witness = the item's first variable, result = its last
@@ -184,7 +194,7 @@ def test_config_c4_full_size_properties(engine, form):
     compare_items(cols, roff.cpu().numpy(), voff.cpu().numpy(), idx, ora, 2 * ns + 5, ns + 262)
     assert u64(acc[torch.tensor(idx, device="cuda:0")].to(torch.int64)).tolist() == [
         int(synth.to_int(ora["var_values"][int(r) - 5]) == 1) for r in ora["result_vars"]]
-    del cols
+    del cols, big
     torch.cuda.empty_cache()
 
 
@@ -233,6 +243,45 @@ def test_calls_that_move_to_another_stream(engine):
         for k in SEL + WIRES + ("var_values",):
             assert np.array_equal(got[k], ora_small[k]), k
         assert engine.check_rows(big[0], var_base=5, zero_var=0) == -1
+
+
+def test_a_call_after_its_predecessors_stream_was_destroyed(engine):
+    """the header lets a caller destroy a stream it has used: the engine only ever COMPARES the previous stream's handle (the
+    event that orders a later call behind it was recorded on that stream when the earlier call ended) -- a big call on a
+    raw HIP stream that is destroyed at once (its work still pending), then a call on another stream, three times over so
+    that a recycled handle occurs too"""
+    import ctypes as C
+    import bench
+    from oracle import pyoracle as po
+    from plonk_gadgets_amd import _lib
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamCreate.argtypes, hip.hipStreamDestroy.argtypes = [C.POINTER(C.c_void_p)], [C.c_void_p]
+    lib = _lib.load()
+    n = 1 << 16
+    ins = [dev(x) for x in bench.mix_inputs(n, seed=5)]
+    small_np = bench.mix_inputs(300, seed=6)
+    small = [dev(x) for x in small_np]
+    ora_small = po.scalar_mix_batch(*small_np)
+    _, roff, voff = engine.ragged_buffers(n)
+    import plonk_gadgets_amd as pg
+    big = pg.Columns.allocate(10 * n, 15 * n, "cuda:0", 3, 5)
+    bc = big.as_c()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        raw = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(raw)) == 0
+        st = lib.pg_scalar_mix_planned_batch(engine._h, *[t.data_ptr() for t in ins], n, roff.data_ptr(), voff.data_ptr(), None, 3, 5, 0,
+                                             C.byref(bc), None, raw)
+        assert st == 0, lib.pg_last_error()
+        assert hip.hipStreamDestroy(raw) == 0  # no synchronisation: the launches are still in flight
+        out = engine.scalar_mix_batch(*small, 3, 5, zero_var=0)  # same scratch, torch's current stream
+        torch.cuda.synchronize()
+        got = out[0].to_numpy()
+        for k in SEL + WIRES + ("var_values",):
+            assert np.array_equal(got[k], ora_small[k]), k
+        lay, nerr = engine.plan_result()
+    assert engine.check_rows(pg.Columns(**{k: getattr(big, k) for k in SEL + WIRES}, var_values=big.var_values, gate_base=3, var_base=5),
+                             var_base=5, zero_var=0) == -1
 
 
 @pytest.mark.parametrize("batch", [1, 1023, 1025, 65 * 1024 + 7, 2_000_000, 2_500_000])

@@ -215,8 +215,21 @@ def test_config_c2_full_size_properties(engine):
     mn, mx = 0, 2**254
     wit = synth.random_scalars(batch, seed=synth.SEED)
     w = torch.from_numpy(wit.view(np.int64)).to("cuda:0")
-    cols, res = engine.range_check_batch(pg.BlsScalar.from_int(mn), pg.BlsScalar.from_int(mx), w, 3, 5)
+    # every output array 64 entries longer than the layout and filled with a sentinel: a slot nobody writes fails the row
+    # check and the comparisons below, a store beyond the layout shows in the tails
+    GUARD = 64
+    big = pg.Columns.allocate(batch * G + GUARD, batch * V + GUARD, "cuda:0", 3, 5)
+    for name in SCALAR_COLS + WIRE_COLS:
+        getattr(big, name).fill_(-1)
+    cols = pg.Columns(**{n: getattr(big, n)[:batch * G] for n in SCALAR_COLS[:-1] + WIRE_COLS}, var_values=big.var_values[:batch * V],
+                      gate_base=3, var_base=5)
+    res = torch.full((batch + GUARD,), -1, dtype=torch.int64, device="cuda:0")
+    engine.range_check_batch(pg.BlsScalar.from_int(mn), pg.BlsScalar.from_int(mx), w, 3, 5, out=cols, result_vars=res[:batch])
     torch.cuda.synchronize()
+    for name in SCALAR_COLS[:-1] + WIRE_COLS:
+        assert bool((getattr(big, name)[batch * G:] == -1).all()), name
+    assert bool((big.var_values[batch * V:] == -1).all()) and bool((res[batch:] == -1).all())
+    res = res[:batch]
     step = 1 << 14  # compare in slabs to bound temporary memory
     for name in ("q_m", "q_l", "q_r", "q_o", "q_c"):
         c = getattr(cols, name).view(batch, G, 4)
@@ -248,7 +261,7 @@ def test_config_c2_full_size_properties(engine):
         for name in WIRE_COLS:
             got = getattr(cols, name)[i * G:(i + 1) * G].cpu().numpy().view(np.uint64) - np.uint64(i * V)
             assert np.array_equal(got, ora[name][s * G:(s + 1) * G] - np.uint64(s * V)), (name, i)
-    del cols, vv
+    del cols, vv, big
     torch.cuda.empty_cache()
 
 
