@@ -203,6 +203,17 @@ template <class GD>
 struct Split<GD, std::void_t<decltype(GD::kSplit)>> {
     static constexpr bool ok = GD::kSplit;
 };
+// kPairVars (optional, gadgets with a ladder): the variable sweep gives every lane TWO consecutive variables, the second
+// derived from the first where GD::var_next knows a shortcut (the accumulators: one modular addition instead of a Montgomery
+// multiplication), and goes through a wave-private LDS transpose so that every wave store is one contiguous KiB
+template <class GD, class = void>
+struct PairVars {
+    static constexpr bool ok = false;
+};
+template <class GD>
+struct PairVars<GD, std::void_t<decltype(GD::kPairVars)>> {
+    static constexpr bool ok = GD::kPairVars;
+};
 template <class GD, int MODE>
 struct EmitShape {
     using Rec = typename GD::ItemRec;
@@ -403,28 +414,135 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
 #else
             const uint32_t smis = (uint32_t)((reinterpret_cast<uintptr_t>(O.vars + var0 * 2) >> 5) & 3u);
 #endif
-            const uint32_t sv0 = tid < smis ? tid + kThreads : tid;
-            uint32_t it = 0, k = sv0 - smis;
-            if constexpr (!GD::kRagged) { it = k / V; k -= it * V; }
-            for (uint32_t sv = sv0; sv < total_vars + smis; sv += kThreads) {
-                const uint32_t s = sv - smis;
-                if constexpr (GD::kRagged) {
-                    it = find_item<W >= 64, kUniV>(s_voff, Wt, s, it, uni_vars);
-                    k = uni_vars ? s - it * kUniV : s - s_voff[it];
-                }
-                uint4 *dst = O.vars + (var0 + s) * 2;
-                if (!GD::is_inv_slot(A, s_item[it], k)) {  // the pre-pass's, written in place
-                    FrVec val;
-                    val.f = GD::var_value(A, s_item[it], s_table, k);
-                    store16(dst, val.v[0]);
-                    store16(dst + 1, val.v[1]);
-                }
+#if !defined(PG_VAR_SWEEP_SINGLE)
+#if defined(PG_VAR_SWEEP_PAIRS_ALWAYS)  // A/B build: the paired sweep in the full emission too (130 registers there: three waves per SIMD instead of four)
+            if constexpr (PairVars<GD>::ok) {
+#else
+            if constexpr (PairVars<GD>::ok && MODE == EMIT_VALUES) {
+#endif
+                // R = 2 consecutive variables per lane.  Half of a ladder block's variables are accumulators, one Montgomery
+                // multiplication each when computed alone (A_i = mont(T mod 2^i)): with rows to write that hides behind the
+                // store stream, a launch that writes ONLY variables (EMIT_VALUES) was bound by it and by its half-line stores
+                // (0.54 of the HBM peak).  A variable that follows one of the same item costs a modular addition where
+                // GD::var_next has a shortcut, and a lane's R scalars leave through a wave-private LDS buffer, two per round,
+                // so that with R = 2 every wave store is one contiguous KiB (7.3 against 8.0 ms per 2^20 witnesses).  R = 4
+                // (two rounds, each writing the 64-byte halves of 64 lines) executes fewer multiplications still but stands at
+                // its stores: 9.9 ms -- what a wave-instruction costs is decided per WAVE, a pass that holds one accumulator
+                // pays the multiplication for all 64 lanes, and the store shape weighs more (profiles/NOTES_r04.md).
+                constexpr int R = 2;
+                static_assert(R == 2 || R == 4, "two scalars per lane and round");
+                __shared__ uint4 s_pair[4 * 272];  // per wave 256 units of 16 bytes, one unit of padding after every 16
+                __shared__ uint8_t s_pflag[kThreads * 2];
+                const uint32_t wave = tid >> 6, lane = tid & 63;
+                uint4 *wp = s_pair + wave * 272;
+                uint8_t *wf = s_pflag + wave * 128;
+                const uint32_t span = total_vars + smis;  // slots counted from the line before the tile's first variable
+                // (item, variable) of the lane's first slot that holds a variable; uniform items: advanced per pass
+                uint32_t it0 = 0, k0 = 0;
                 if constexpr (!GD::kRagged) {
-                    k += kThreads;
-                    if (k >= V) { const uint32_t d = k / V; it += d; k -= d * V; }
+                    const uint32_t first = wave * 64 * R + R * lane;
+                    const uint32_t s = first >= smis ? first - smis : 0;
+                    it0 = s / V;
+                    k0 = s - it0 * V;
+                }
+                for (uint32_t base = wave * 64 * R; base < span; base += R * kThreads) {
+                    const uint32_t p0 = base + R * lane;
+                    uint32_t vcount = V;
+                    if constexpr (GD::kRagged) {
+                        if (p0 + (R - 1) >= smis && p0 < span) {
+                            const uint32_t s = p0 >= smis ? p0 - smis : 0;
+                            it0 = find_item<W >= 64, kUniV>(s_voff, Wt, s, it0, uni_vars);
+                            k0 = uni_vars ? s - it0 * kUniV : s - s_voff[it0];
+                            vcount = uni_vars ? kUniV : s_voff[it0 + 1] - s_voff[it0];
+                        }
+                    }
+                    FrVec v[R];
+                    bool st[R];
+                    {
+                        uint32_t it = it0, k = k0;
+                        bool have_prev = false;
+                        Fr prev = fr_zero();
+#pragma unroll
+                        for (int t = 0; t < R; t++) {
+                            const uint32_t slot = p0 + t;
+                            st[t] = false;
+                            v[t].f = fr_zero();
+                            if (slot >= smis && slot < span) {
+                                st[t] = !GD::is_inv_slot(A, s_item[it], k);
+                                if (st[t]) {
+                                    if (!(have_prev && GD::var_next(A, s_item[it], s_table, k, prev, v[t].f)))
+                                        v[t].f = GD::var_value(A, s_item[it], s_table, k);
+                                    prev = v[t].f;
+                                }
+                                have_prev = st[t];
+                                if (++k >= vcount) {  // the next slot opens the next item
+                                    k = 0;
+                                    it++;
+                                    have_prev = false;
+                                    if constexpr (GD::kRagged) {
+                                        if (slot + 1 < span) vcount = uni_vars ? kUniV : s_voff[it + 1] - s_voff[it];
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    // global 16-byte unit, relative to the wave's chunk, that lane l stores with store j of round r:
+                    // 32 R j + 2 R (l / 4) + 4 r + (l & 3)  [LDS unit 64 j + l = lane 16 j + l / 4's scalar (l / 2) & 1 of the round]
+                    uint4 *dst = O.vars + ((int64_t)(var0 + base) - (int64_t)smis) * 2 + 2 * R * (lane >> 2) + (lane & 3);
+#pragma unroll
+                    for (int r = 0; r < R / 2; r++) {
+                        // unit u of the round's 4 KiB lives at wp[u + u / 16]: the lanes of a 16-lane group then write 16
+                        // different 16-byte columns of the LDS (64 bytes apart unpadded, four of them would share each)
+                        const uint32_t u0 = 4 * lane, w0i = u0 + (u0 >> 4);
+                        wp[w0i + 0] = v[2 * r].v[0];
+                        wp[w0i + 1] = v[2 * r].v[1];
+                        wp[w0i + 2] = v[2 * r + 1].v[0];
+                        wp[w0i + 3] = v[2 * r + 1].v[1];
+                        wf[2 * lane] = st[2 * r] ? 1 : 0;
+                        wf[2 * lane + 1] = st[2 * r + 1] ? 1 : 0;
+                        // (wave-private, and the LDS runs a wave's instructions in order: the reads below see the other lanes' writes
+                        // above, the next round's writes come after these reads -- no wait, the compiler must only keep the order)
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t u = 64 * j + lane;
+                            const uint4 val = wp[u + (u >> 4)];
+                            if (wf[u >> 1]) store16(dst + 32 * R * j + 4 * r, val);
+                        }
+                        asm volatile("" ::: "memory");
+                    }
+                    if constexpr (!GD::kRagged) {
+                        // (a lane whose first slots lay before the tile's first variable stood at variable 0 of item 0)
+                        k0 += p0 >= smis ? R * kThreads : R * kThreads - (smis - p0);
+                        while (k0 >= V) { k0 -= V; it0++; }
+                    }
+                }
+            } else
+#endif
+            {
+            const uint32_t sv0 = tid < smis ? tid + kThreads : tid;
+                uint32_t it = 0, k = sv0 - smis;
+                if constexpr (!GD::kRagged) { it = k / V; k -= it * V; }
+                for (uint32_t sv = sv0; sv < total_vars + smis; sv += kThreads) {
+                    const uint32_t s = sv - smis;
+                    if constexpr (GD::kRagged) {
+                        it = find_item<W >= 64, kUniV>(s_voff, Wt, s, it, uni_vars);
+                        k = uni_vars ? s - it * kUniV : s - s_voff[it];
+                    }
+                    uint4 *dst = O.vars + (var0 + s) * 2;
+                    if (!GD::is_inv_slot(A, s_item[it], k)) {  // the pre-pass's, written in place
+                        FrVec val;
+                        val.f = GD::var_value(A, s_item[it], s_table, k);
+                        store16(dst, val.v[0]);
+                        store16(dst + 1, val.v[1]);
+                    }
+                    if constexpr (!GD::kRagged) {
+                        k += kThreads;
+                        if (k >= V) { const uint32_t d = k / V; it += d; k -= d * V; }
+                    }
                 }
             }
-        }
+            }
         lds_barrier();  // records and offsets are rewritten by the next tile
     }
 }

@@ -30,6 +30,8 @@ VARIANTS = {
     "rows_prio1": ["-DPG_ROWS_SETPRIO=1"],
     # round 4 experiments on the mix
     "sbit": ["-DPG_EXP_SBIT"],
+    "var_single": ["-DPG_VAR_SWEEP_SINGLE"],        # the variable sweep one scalar per lane everywhere (before round 4)
+    "var_pairs_always": ["-DPG_VAR_SWEEP_PAIRS_ALWAYS"],  # the paired sweep in the full emission too
     "side_normal": ["-DPG_SIDE_STREAM_NORMAL_PRIORITY"],
     "inv_grp2": ["-DPG_INV_GRP=2"],
     "p1": ["-DPG_EXP_PREFETCH_INV"],
@@ -266,6 +268,52 @@ def run(log2_chunk=18, rounds=4, mn_int=0, mx_int=2**254):
                           "gbps_median": nbytes / ts[len(ts) // 2] / 1e6, "gbps_best": nbytes / ts[0] / 1e6}))
 
 
+def run_values(log2_chunk=20, rounds=6):
+    """the witness refresh of C2's circuit (pg_range_check_values_batch: 1034 variables per witness, no rows)"""
+    import numpy as np
+    import torch
+    from plonk_gadgets_amd import _lib, synth
+    import plonk_gadgets_amd as pg
+    dev = torch.device("cuda", 0)
+    chunk = 1 << log2_chunk
+    wit = torch.from_numpy(synth.random_scalars(chunk).view(np.int64)).to(dev)
+    mn, mx = pg.BlsScalar.from_int(0), pg.BlsScalar.from_int(2**254)
+    table = torch.empty((chunk * 1034, 4), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    libs = {}
+    for name in VARIANTS:
+        path = os.path.join(VDIR, f"lib_{name}.so")
+        if not os.path.exists(path):
+            continue
+        lib = C.CDLL(path)
+        for fn, (r, a) in _lib.SIGNATURES.items():
+            if hasattr(lib, fn):
+                f = getattr(lib, fn)
+                f.restype, f.argtypes = r, a
+        h = C.c_void_p()
+        assert lib.pg_engine_create(0, C.byref(h)) == 0
+        libs[name] = (lib, h)
+    times = {n: [] for n in libs}
+    nbytes = chunk * 1034 * 32
+    for r in range(rounds + 1):
+        order = list(libs.items())
+        order = order[r % len(order):] + order[:r % len(order)]
+        for name, (lib, h) in order:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            st = lib.pg_range_check_values_batch(h, C.byref(mn.c), C.byref(mx.c), wit.data_ptr(), chunk, table.data_ptr(),
+                                                 C.c_void_p(stream.cuda_stream))
+            assert st == 0
+            e1.record(stream)
+            torch.cuda.synchronize()
+            if r:
+                times[name].append(e0.elapsed_time(e1))
+    for name, ts in times.items():
+        ts = sorted(ts)
+        print(json.dumps({"variant": name, "flags": VARIANTS[name], "median_ms": ts[len(ts) // 2], "min_ms": ts[0],
+                          "gbps_median": nbytes / ts[len(ts) // 2] / 1e6}))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build(sys.argv[2:])
@@ -273,5 +321,7 @@ if __name__ == "__main__":
         run_c3(*(int(x) for x in sys.argv[2:]))
     elif sys.argv[1] == "run_c4":
         run_c4(*(int(x) for x in sys.argv[2:]))
+    elif sys.argv[1] == "run_values":
+        run_values(*(int(x) for x in sys.argv[2:]))
     else:
         run(*(int(x) for x in sys.argv[2:]))

@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
 DST = os.path.join(ROOT, "profiles")
 summary = {}
@@ -25,7 +25,9 @@ def newest(pattern):
     return max(glob.glob(pattern), key=os.path.getmtime)
 
 
-for w in ("c2", "c3", "c4"):
+for w in ("c2", "c3", "c4", "c2_values"):
+    if not glob.glob(os.path.join(SRC, f"stats_{w}", "*", "*kernel_stats.csv")):
+        continue
     st = newest(os.path.join(SRC, f"stats_{w}", "*", "*kernel_stats.csv"))
     shutil.copy(st, os.path.join(DST, f"{R}_{w}_kernel_stats.csv"))
     log = open(os.path.join(SRC, f"stats_{w}.log")).read().strip().splitlines()
@@ -58,10 +60,11 @@ for w in ("c2", "c3", "c4"):
     ks = [r for r in ks if "pg::" in r["Kernel_Name"]]
     # the last step: from the last kernel that begins a step (c2: the pre-pass or the emit launch; c3: the launch that plans,
     # inverts and writes the variable table; c4: the plan kernel)
-    first_of = {"c2": ("batch_invert", "emit_kernel"), "c3": ("scalar_mix_vars",), "c4": ("plan_kernel",)}[w]
+    first_of = {"c2": ("batch_invert", "emit_kernel"), "c3": ("scalar_mix_vars",), "c4": ("plan_kernel",),
+                "c2_values": ("batch_invert", "emit_kernel")}[w]
     firsts = [i for i, r in enumerate(ks) if any(k in r["Kernel_Name"] for k in first_of)]
     start = firsts[-1]
-    if w == "c2" and len(firsts) > 1 and firsts[-2] == start - 1:  # pre-pass and emit launch of the same step
+    if w in ("c2", "c2_values") and len(firsts) > 1 and firsts[-2] == start - 1:  # pre-pass and emit launch of the same step
         start = firsts[-2]
     step = ks[start:]
     t0 = int(step[0]["Start_Timestamp"])
