@@ -329,25 +329,26 @@ def measure(wl: Workload, steps: int, warmup: int, sync_all):
     stream = torch.cuda.current_stream(wl.dev)
 
     def step(events=None):
+        # ONE event per launch boundary (launch i runs from boundary i to boundary i + 1): an event record is a packet of its own
+        # on the stream -- with a pair around every launch, consecutive launches stood two records apart, ~15 us per C3 step
         for c in range(wl.n_chunks):
-            if events is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
             wl.launch(c)
             if events is not None:
-                e1.record(stream)
-                events.append((e0, e1))
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(stream)
+                events.append(e)
 
     for _ in range(warmup):
         step()
     sync_all()
-    events = []
+    events = [torch.cuda.Event(enable_timing=True)]
     t0 = time.perf_counter()
+    events[0].record(stream)
     for _ in range(steps):
         step(events)
     sync_all()
     elapsed = time.perf_counter() - t0
-    kernel_ms = [a.elapsed_time(b) for a, b in events]
+    kernel_ms = [a.elapsed_time(b) for a, b in zip(events[:-1], events[1:])]
     return elapsed, kernel_ms
 
 

@@ -159,6 +159,55 @@ def run_c3(log2_chunk=20, rounds=4):
                           "gbps_median": nbytes / ts[len(ts) // 2] / 1e6}))
 
 
+def run_c3_b2b(log2_chunk=20, steps=40, rounds=5):
+    """the C3 step issued back to back, no synchronisation and no events between the calls (what a caller's loop does): ms per
+    step over `steps` calls -- the difference to run_c3's per-call figure is what the step's launches cost each other"""
+    import numpy as np
+    import torch
+    from plonk_gadgets_amd import _lib
+    import plonk_gadgets_amd as pg
+    import bench
+    dev = torch.device("cuda", 0)
+    chunk = 1 << log2_chunk
+    ins = [torch.from_numpy(np.ascontiguousarray(x).view(np.int64)).to(dev) for x in bench.mix_inputs(chunk)]
+    roff = torch.empty((chunk + 1,), dtype=torch.int64, device=dev)
+    voff = torch.empty((chunk + 1,), dtype=torch.int64, device=dev)
+    res = torch.empty((chunk, 2), dtype=torch.int64, device=dev)
+    cols = pg.Columns.allocate(10 * chunk, 15 * chunk, dev)
+    cc = cols.as_c()
+    stream = torch.cuda.current_stream(dev)
+    sp = C.c_void_p(stream.cuda_stream)
+    libs = {}
+    for name in VARIANTS:
+        path = os.path.join(VDIR, f"lib_{name}.so")
+        if not os.path.exists(path):
+            continue
+        lib = C.CDLL(path)
+        for fn, (r, a) in _lib.SIGNATURES.items():
+            if hasattr(lib, fn):
+                f = getattr(lib, fn)
+                f.restype, f.argtypes = r, a
+        h = C.c_void_p()
+        assert lib.pg_engine_create(0, C.byref(h)) == 0
+        libs[name] = (lib, h)
+    times = {n: [] for n in libs}
+    for r in range(rounds + 1):
+        for name, (lib, h) in libs.items():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record(stream)
+            for _ in range(steps):
+                assert lib.pg_scalar_mix_planned_batch(h, *[t.data_ptr() for t in ins], chunk, roff.data_ptr(), voff.data_ptr(), None,
+                                                       3, 5, 0, C.byref(cc), res.data_ptr(), sp) == 0
+            e1.record(stream)
+            torch.cuda.synchronize()
+            if r:
+                times[name].append(e0.elapsed_time(e1) / steps)
+    for name, ts in times.items():
+        ts = sorted(ts)
+        print(json.dumps({"variant": name, "ms_per_step_back_to_back": ts[len(ts) // 2], "min": ts[0]}))
+
+
 def run_c4(log2_chunk=19, rounds=4):
     """ragged max_bound (BASELINE config C4 shape): plan once, time invert pre-pass + emit"""
     import numpy as np
@@ -321,6 +370,8 @@ if __name__ == "__main__":
         run_c3(*(int(x) for x in sys.argv[2:]))
     elif sys.argv[1] == "run_c4":
         run_c4(*(int(x) for x in sys.argv[2:]))
+    elif sys.argv[1] == "run_c3_b2b":
+        run_c3_b2b(*(int(x) for x in sys.argv[2:]))
     elif sys.argv[1] == "run_values":
         run_values(*(int(x) for x in sys.argv[2:]))
     else:
