@@ -30,6 +30,9 @@ VARIANTS = {
     "rows_prio1": ["-DPG_ROWS_SETPRIO=1"],
     # round 4 experiments on the mix
     "sbit": ["-DPG_EXP_SBIT"],
+    "diag_coal": ["-DPG_MIX_STAMPS", "-DPG_DIAG_FWD_COALESCED"],  # timing only: the forward pass's loads as three contiguous KiB
+    "diag_3ld": ["-DPG_MIX_STAMPS", "-DPG_DIAG_FWD_3LOADS"],      # timing only: without the v side's second fetch of v
+    "diag_split": ["-DPG_MIX_STAMPS", "-DPG_DIAG_FWD_SPLIT"],     # stamps inside the forward loop (they disturb it: vmcnt(0) waits)
     "var_single": ["-DPG_VAR_SWEEP_SINGLE"],        # the variable sweep one scalar per lane everywhere (before round 4)
     "var_pairs_always": ["-DPG_VAR_SWEEP_PAIRS_ALWAYS"],  # the paired sweep in the full emission too
     "side_normal": ["-DPG_SIDE_STREAM_NORMAL_PRIORITY"],
@@ -73,6 +76,8 @@ PATCHES = {  # builds that are NOT in the sources: a patch (tools/patches/) appl
     "ablate_amul": "ablations_wrong_output.patch",
     # round 4's rejected schedules of the fused mix (profiles/NOTES_r04.md): apply to the sources of commit "round 4: values" --
     # kept as a record of what was measured, it may no longer apply cleanly
+    "diag_coal": "r04_fwd_load_shape_diagnostic.patch", "diag_3ld": "r04_fwd_load_shape_diagnostic.patch",
+    "diag_split": "r04_fwd_load_shape_diagnostic.patch",
     "f1": "r04_mix_experiments.patch", "f3": "r04_mix_experiments.patch", "p1": "r04_mix_experiments.patch", "g8": "r04_mix_experiments.patch",
     "p1g8": "r04_mix_experiments.patch", "iplenv": "r04_mix_experiments.patch", "iplenv_stamps": "r04_mix_experiments.patch",
     "f1_stamps": "r04_mix_experiments.patch", "f2a_stamps": "r04_mix_experiments.patch", "f2b_stamps": "r04_mix_experiments.patch",

@@ -40,7 +40,11 @@ for rep in range(6):
     torch.cuda.synchronize()
     assert lib.pg_debug_mix_phases(out) == 0
     if rep:
-        if any(out[k] for k in range(4, 8)):  # a staggered build (PG_EXP_STAGGER_TICKS): even / odd workgroups apart
+        if os.environ.get("FWD_SPLIT"):  # tools/patches/r04_fwd_load_shape_diagnostic.patch with -DPG_DIAG_FWD_SPLIT
+            w = 2048
+            print("forward us per wave: first fetches + wait %.1f | steps 0-3 %.1f | 4-7 %.1f | 8-11 %.1f | 12-15 %.1f ; inversion %.1f backward %.1f" % (
+                out[4] / w / 100, out[5] / w / 100, out[6] / w / 100, out[7] / w / 100, out[0] / w / 100, out[2] / w / 100, out[3] / w / 100))
+        elif any(out[k] for k in range(4, 8)):  # a staggered build (PG_EXP_STAGGER_TICKS): even / odd workgroups apart
             for g, name in ((0, "even"), (4, "odd ")):
                 print("us per wave (%s workgroups): forward %.1f  look-back %.1f  inversion %.1f  backward %.1f" % ((name,) + tuple(out[g + k] / 1024 / 100.0 for k in range(4))))
         else:
