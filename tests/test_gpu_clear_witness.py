@@ -262,3 +262,43 @@ def test_clear_witness_argument_checks(engine):
     dev.clear_witness()  # nothing built yet
     assert dev.refresh_stats() == (0, 0, False) and (dev.circuit_size(), dev.num_variables()) == (3, 5)
     assert dev.check() == -1
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 101, 102])
+def test_fuzz_programs_rebuilt_on_other_witnesses(engine, seed):
+    """tests/test_gpu_composer.py's random programs of 30 operations -- every single call and every batched append -- built,
+    then clear_witness and the SAME program (same public structure: operations, sizes, bounds, selectors, Variables referred to)
+    on other witnesses, three builds in all, the last one cut short and followed by ANOTHER program: after every build the
+    composer == a fresh oracle composer of that build, its first unsatisfied row and its sigma too.  (Appends on device arrays
+    are emitted again, signed ones found in place, the fused mix in place only when no item fails; a witness-dependent shape
+    that differs -- other items with v = 0 -- ends the refresh and everything after it is emitted in full.)"""
+    from oracle import pyoracle as po
+    import test_gpu_composer as tc
+    dev = pg.StandardComposer(engine, 1 << 14, 1 << 14)
+    dev.auto_grow()
+    kept_total = 0
+    for build, (wit_seed, steps, prog) in enumerate([(1000 + seed, 30, seed), (2000 + seed, 30, seed), (3000 + seed, 17, seed),
+                                                     (4000 + seed, 30, seed + 50)]):
+        if build:
+            dev.clear_witness()
+        ora = po.Composer()
+        log = tc.run_fuzz_program(dev, ora, prog, wit_seed, steps)
+        kept, rewritten, refreshing = dev.refresh_stats()
+        kept_total += kept
+        try:
+            same(dev, ora)
+            assert dev.check() == ora.check()
+            n = dev.circuit_size()
+            padded = 1 << (n - 1).bit_length()
+            assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded))
+        except AssertionError as e:
+            raise AssertionError(f"seed {seed}, build {build} (kept {kept}, rewritten {rewritten}, refreshing {refreshing}), program {log}: {e}")
+        if build == 0:
+            assert kept == 0
+            first_log = log
+    # the refresh ends at the first signed append that differs, and in these programs only a fused mix can (its random v hold
+    # zeros: a shape that depends on the witnesses): whatever signed append comes before the first mix must have been found in place
+    ops = [op for op, _ in first_log]
+    before_mix = ops[:ops.index("mix")] if "mix" in ops else ops
+    if any(op in ("rc", "mb", "bool", "ctc") for op in before_mix):
+        assert kept_total > 0, f"seed {seed}: signed appends {before_mix} before the first mix, yet no row was found in place"

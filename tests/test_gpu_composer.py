@@ -711,28 +711,27 @@ def test_empty_batches_and_minimal_composer(engine):
         assert np.array_equal(dev.permutation(8).cpu().numpy().view(np.uint64), ora.sigma(8))
 
 
-@pytest.mark.parametrize("seed", list(range(1, 11)) + [101, 102, 103])
-def test_fuzz_composer_programs(engine, seed):
-    """random programs of 30 composer operations -- single calls and every batched append, on random earlier Variables,
-    random bounds and batch sizes -- replayed on the oracle call for call: same columns, same first unsatisfied row,
-    same sigma.  (Segments of every shape, gaps between them, references across segments, hot Variables.)"""
+def run_fuzz_program(dev, ora, seed, wit_seed=None, steps=30):
+    """a random program of `steps` composer operations -- single calls and every batched append, on random earlier Variables,
+    random bounds and batch sizes -- on the device composer and, call for call, on the oracle's.  Everything PUBLIC (operations,
+    batch sizes, bounds, selectors, constants, which earlier Variables a call refers to) comes from `seed`; the WITNESS scalars
+    from `wit_seed` (default: the same stream, as before the two were told apart).  Returns the log of (operation, size)."""
     from oracle import pyoracle as po
     import ctypes as C
     import random
     rng = random.Random(seed)
-    dev, ora = pg.StandardComposer(engine, 1 << 14, 1 << 14), po.Composer()
-    dev.auto_grow()
+    wrng = rng if wit_seed is None else random.Random(wit_seed)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:0")
     tv = lambda xs: torch.tensor(xs, dtype=torch.int64, device="cuda:0")
     F = lambda x: po.fr(synth.mont(x))
     nb = C.c_uint64()
 
     def rand_scalars(k):
-        return synth.scalars_from_ints([rng.choice([0, 1, rng.randrange(1 << 16), rng.randrange(po_Q)]) for _ in range(k)])
+        return synth.scalars_from_ints([wrng.choice([0, 1, wrng.randrange(1 << 16), wrng.randrange(po_Q)]) for _ in range(k)])
 
     po_Q = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
     log = []
-    for step in range(30):
+    for step in range(steps):
         nv = dev.num_variables()
         assert nv == ora.num_vars
         op = rng.choice(["add_input", "rc", "rc_alloc", "mb", "mb_alloc", "mb_ragged", "dec", "sel0", "sel1", "meq", "inz", "mix",
@@ -744,7 +743,7 @@ def test_fuzz_composer_programs(engine, seed):
         old2 = [rng.randrange(nv) for _ in range(k)]
         log.append((op, k))
         if op == "add_input":
-            x = rng.randrange(po_Q)
+            x = wrng.randrange(po_Q)
             assert dev.add_input(S(x)) == ora.add_input(synth.mont(x))
         elif op == "alloc_batch":
             w = rand_scalars(k)
@@ -846,6 +845,17 @@ def test_fuzz_composer_programs(engine, seed):
             x = rng.randrange(po_Q)
             dev.constrain_to_constant(old[0], S(x), None)
             ora.L.composer_constrain_to_constant(ora.c, old[0], F(x), None)
+    return log
+
+
+@pytest.mark.parametrize("seed", list(range(1, 11)) + [101, 102, 103])
+def test_fuzz_composer_programs(engine, seed):
+    """random programs of 30 composer operations (run_fuzz_program) replayed on the oracle call for call: same columns, same
+    first unsatisfied row, same sigma.  (Segments of every shape, gaps between them, references across segments, hot Variables.)"""
+    from oracle import pyoracle as po
+    dev, ora = pg.StandardComposer(engine, 1 << 14, 1 << 14), po.Composer()
+    dev.auto_grow()
+    log = run_fuzz_program(dev, ora, seed)
     try:
         same(dev, ora)
         assert dev.check() == ora.check()
