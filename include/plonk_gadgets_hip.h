@@ -338,10 +338,12 @@ pg_status pg_composer_queue_stats(const pg_composer *c, uint64_t *pending, uint6
  * they are: an append that repeats, at the same place in the call sequence, what the build before it did there (the same
  * call with the same public parameters, landing on the same first row, first Variable and zero_var) finds its rows in the
  * columns and writes only its assignments (32 B per variable instead of 184 B per row on top; pg_*_values_batch).  That
- * holds for every single composer gate call, single pg_range_check / pg_max_bound calls, and the batched appends on witness
- * scalars (pg_composer_range_check_batch, _max_bound_batch, _scalar_mix_batch when no item fails); appends whose rows depend
- * on device arrays of Variables or bounds are simply emitted again.  The first append that differs from the previous build
- * ends the refresh: from there on everything is emitted in full, so another circuit is built correctly too -- only slower. */
+ * holds for every append: single composer gate calls and single gadget calls, the batched appends on witness scalars, and the
+ * batched appends whose rows depend on device arrays (Variables, per-item bounds), which are signed by a 128-bit digest of
+ * those arrays taken in the pass that validates them.  The two gadgets whose SHAPE depends on witness values --
+ * is_non_zero and the fused mix, which stop at a zero (src/scalar.rs:79) -- are found in place only when no item fails, in
+ * either build.  The first append that differs from the previous build ends the refresh: from there on everything is emitted
+ * in full, so another circuit is built correctly too -- only slower. */
 pg_status pg_composer_clear_witness(pg_composer *c);
 /* since the last pg_composer_clear_witness: rows found in place, rows written again, still matching (any pointer may be NULL) */
 pg_status pg_composer_refresh_stats(const pg_composer *c, uint64_t *rows_in_place, uint64_t *rows_rewritten, int *refreshing);

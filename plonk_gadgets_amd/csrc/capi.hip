@@ -310,11 +310,9 @@ pg_status launch_mix(pg_engine *e, const pg::ScalarMixArgs &A, const pg_columns 
     return PG_OK;
 }
 
-// gadgets whose witness refresh (EMIT_VALUES: the variable assignments alone) is exported
-template <class GD> struct ValuesMode { static constexpr bool ok = false; };
-template <> struct ValuesMode<pg::RangeCheckGD> { static constexpr bool ok = true; };
-template <> struct ValuesMode<pg::MaxBoundGD<false>> { static constexpr bool ok = true; };
-template <> struct ValuesMode<pg::MaxBoundGD<true>> { static constexpr bool ok = true; };
+// the witness refresh (EMIT_VALUES: the variable assignments alone) exists for every gadget of the one-launch emitter; the split
+// gadget (the fused mix) has its own: the launch that writes its variable table, alone (launch_mix)
+template <class GD> struct ValuesMode { static constexpr bool ok = !pg::Split<GD>::ok; };
 
 template <class GD>
 pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, uint64_t batch, uint64_t gate_base,
@@ -694,9 +692,9 @@ pg_status pg_scalar_decomposition_layout(uint64_t num_bits, uint64_t batch, pg_l
     return PG_OK;
 }
 
-pg_status pg_scalar_decomposition_batch(pg_engine *e, uint64_t num_bits, const pg_variable *d_witness_var,
-                                        const pg_scalar *d_witness, uint64_t batch, uint64_t gate_base, uint64_t var_base,
-                                        const pg_columns *out, pg_variable *d_result_vars, void *stream) {
+static pg_status decomposition_common(pg_engine *e, uint64_t num_bits, const pg_variable *d_witness_var,
+                                      const pg_scalar *d_witness, uint64_t batch, uint64_t gate_base, uint64_t var_base,
+                                      const pg_columns *out, pg_variable *d_result_vars, void *stream, bool values_only) {
     if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
     pg_layout lay;
     PG_TRY(pg_scalar_decomposition_layout(num_bits, batch, &lay));
@@ -711,7 +709,13 @@ pg_status pg_scalar_decomposition_batch(pg_engine *e, uint64_t num_bits, const p
     A.witness_vars = d_witness_var;
     A.result_vars = d_result_vars;
     A.pow2 = e->d_pow2;
-    return launch<pg::DecompositionGD>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream);
+    return launch<pg::DecompositionGD>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream, nullptr, values_only);
+}
+
+pg_status pg_scalar_decomposition_batch(pg_engine *e, uint64_t num_bits, const pg_variable *d_witness_var,
+                                        const pg_scalar *d_witness, uint64_t batch, uint64_t gate_base, uint64_t var_base,
+                                        const pg_columns *out, pg_variable *d_result_vars, void *stream) {
+    return decomposition_common(e, num_bits, d_witness_var, d_witness, batch, gate_base, var_base, out, d_result_vars, stream, false);
 }
 
 /* ---- max_bound ------------------------------------------------------------ */
@@ -854,39 +858,44 @@ pg_status pg_max_bound_ragged_values_batch(pg_engine *e, const pg_scalar *d_max_
 }
 
 /* ---- scalar gadgets ------------------------------------------------------- */
+}  // extern "C"
+
+// the three gadgets on two existing Variables each; values_only: a witness refresh (pg_composer_clear_witness)
+template <class GD>
+static pg_status two_input_common(pg_engine *e, const pg_variable *d_a_var, const pg_scalar *d_a_val, const pg_variable *d_b_var,
+                                  const pg_scalar *d_b_val, uint64_t batch, uint64_t gate_base, uint64_t var_base,
+                                  const pg_columns *out, pg_variable *d_result_vars, void *stream, bool values_only) {
+    if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
+    if (batch == 0) return PG_OK;
+    pg::ScalarArgs A;
+    PG_TRY(scalar_args(d_a_var, d_a_val, d_b_var, d_b_val, d_result_vars, &A));
+    PG_TRY(check_columns(out));
+    return launch<GD>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream, nullptr, values_only);
+}
+
+extern "C" {
+
 pg_status pg_conditionally_select_zero_batch(pg_engine *e, const pg_variable *d_x_var, const pg_scalar *d_x_val,
                                              const pg_variable *d_select_var, const pg_scalar *d_select_val, uint64_t batch,
                                              uint64_t gate_base, uint64_t var_base, const pg_columns *out,
                                              pg_variable *d_result_vars, void *stream) {
-    if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
-    if (batch == 0) return PG_OK;
-    pg::ScalarArgs A;
-    PG_TRY(scalar_args(d_x_var, d_x_val, d_select_var, d_select_val, d_result_vars, &A));
-    PG_TRY(check_columns(out));
-    return launch<pg::SelectZeroGD>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream);
+    return two_input_common<pg::SelectZeroGD>(e, d_x_var, d_x_val, d_select_var, d_select_val, batch, gate_base, var_base, out,
+                                              d_result_vars, stream, false);
 }
 
 pg_status pg_conditionally_select_one_batch(pg_engine *e, const pg_variable *d_y_var, const pg_scalar *d_y_val,
                                             const pg_variable *d_selector_var, const pg_scalar *d_selector_val,
                                             uint64_t batch, uint64_t gate_base, uint64_t var_base, const pg_columns *out,
                                             pg_variable *d_result_vars, void *stream) {
-    if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
-    if (batch == 0) return PG_OK;
-    pg::ScalarArgs A;
-    PG_TRY(scalar_args(d_y_var, d_y_val, d_selector_var, d_selector_val, d_result_vars, &A));
-    PG_TRY(check_columns(out));
-    return launch<pg::SelectOneGD>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream);
+    return two_input_common<pg::SelectOneGD>(e, d_y_var, d_y_val, d_selector_var, d_selector_val, batch, gate_base, var_base, out,
+                                             d_result_vars, stream, false);
 }
 
 pg_status pg_maybe_equal_batch(pg_engine *e, const pg_variable *d_a_var, const pg_scalar *d_a_val, const pg_variable *d_b_var,
                                const pg_scalar *d_b_val, uint64_t batch, uint64_t gate_base, uint64_t var_base,
                                const pg_columns *out, pg_variable *d_result_vars, void *stream) {
-    if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
-    if (batch == 0) return PG_OK;
-    pg::ScalarArgs A;
-    PG_TRY(scalar_args(d_a_var, d_a_val, d_b_var, d_b_val, d_result_vars, &A));
-    PG_TRY(check_columns(out));
-    return launch<pg::MaybeEqualGD>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream);
+    return two_input_common<pg::MaybeEqualGD>(e, d_a_var, d_a_val, d_b_var, d_b_val, batch, gate_base, var_base, out, d_result_vars,
+                                              stream, false);
 }
 
 pg_status pg_is_non_zero_plan(pg_engine *e, const pg_scalar *d_value_assigned, uint64_t batch, uint64_t *d_row_off,
@@ -896,9 +905,9 @@ pg_status pg_is_non_zero_plan(pg_engine *e, const pg_scalar *d_value_assigned, u
                       err_count, stream);
 }
 
-pg_status pg_is_non_zero_batch(pg_engine *e, const pg_variable *d_var, const pg_scalar *d_value_assigned, uint64_t batch,
-                               const uint64_t *d_row_off, const uint64_t *d_var_off, uint64_t gate_base, uint64_t var_base,
-                               pg_variable zero_var, const pg_columns *out, void *stream) {
+static pg_status is_non_zero_common(pg_engine *e, const pg_variable *d_var, const pg_scalar *d_value_assigned, uint64_t batch,
+                                    const uint64_t *d_row_off, const uint64_t *d_var_off, uint64_t gate_base, uint64_t var_base,
+                                    pg_variable zero_var, const pg_columns *out, void *stream, bool values_only) {
     if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
     if (batch == 0) return PG_OK;
     PG_TRY(check_u64s(d_var, "d_var"));
@@ -909,7 +918,13 @@ pg_status pg_is_non_zero_batch(pg_engine *e, const pg_variable *d_var, const pg_
     pg::ScalarArgs A{};
     A.a_var = d_var;
     A.b_val = reinterpret_cast<const uint4 *>(d_value_assigned);
-    return launch<pg::IsNonZeroGD>(e, A, out, batch, gate_base, var_base, zero_var, d_row_off, d_var_off, stream);
+    return launch<pg::IsNonZeroGD>(e, A, out, batch, gate_base, var_base, zero_var, d_row_off, d_var_off, stream, nullptr, values_only);
+}
+
+pg_status pg_is_non_zero_batch(pg_engine *e, const pg_variable *d_var, const pg_scalar *d_value_assigned, uint64_t batch,
+                               const uint64_t *d_row_off, const uint64_t *d_var_off, uint64_t gate_base, uint64_t var_base,
+                               pg_variable zero_var, const pg_columns *out, void *stream) {
+    return is_non_zero_common(e, d_var, d_value_assigned, batch, d_row_off, d_var_off, gate_base, var_base, zero_var, out, stream, false);
 }
 
 pg_status pg_scalar_mix_plan(pg_engine *e, const pg_scalar *d_v, uint64_t batch, uint64_t *d_row_off, uint64_t *d_var_off,

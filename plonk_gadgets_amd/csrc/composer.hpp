@@ -141,7 +141,10 @@ struct GateBatch {
     uint64_t *out_vars;  // OP_ADD / OP_MUL: the new Variables (may be NULL)
     Fr q_m, q_l, q_r, q_o, q_c;
 };
-__global__ __launch_bounds__(kThreads) void gate_batch_kernel(const GateBatch B, const ComposerCols C) {
+__global__ __launch_bounds__(kThreads) void gate_batch_kernel(const GateBatch B_in, const ComposerCols C) {
+    GateBatch B = B_in;
+    const bool in_place = (B.op & OP_ROW_IN_PLACE) != 0;  // a witness refresh: the rows are in the columns already
+    B.op &= ~OP_ROW_IN_PLACE;
     FrVec q[5];
     q[0].f = B.q_m; q[1].f = B.q_l; q[2].f = B.q_r; q[3].f = B.q_o; q[4].f = B.q_c;
     for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < B.batch; i += (uint64_t)gridDim.x * kThreads) {
@@ -155,6 +158,7 @@ __global__ __launch_bounds__(kThreads) void gate_batch_kernel(const GateBatch B,
             put_fr(C.vars, out, v);
             if (B.out_vars) B.out_vars[i] = out;
         }
+        if (in_place) continue;
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             C.q[k][2 * g] = q[k].v[0];
@@ -166,17 +170,36 @@ __global__ __launch_bounds__(kThreads) void gate_batch_kernel(const GateBatch B,
     }
 }
 
-// largest entry of a device array of Variables -> *out (atomicMax; *out starts at 0): the batched appends check it
-// against the composer's variable count before anything is appended (the reference panics on an unknown Variable)
-__global__ __launch_bounds__(kThreads) void max_variable_kernel(const uint64_t *a, uint64_t n, unsigned long long *out) {
-    unsigned long long m = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kThreads) m = a[i] > m ? a[i] : m;
+// largest entry of a device array of Variables -> out[0] (atomicMax; starts at 0): the batched appends check it against the
+// composer's variable count before anything is appended (the reference panics on an unknown Variable).  In the same pass a
+// 128-bit digest of the array -> out[1], out[2] (sums of two position-salted 64-bit mixes: order of summation does not matter,
+// order of the entries does): an append whose rows depend on the array is signed with it (pg_composer_clear_witness).
+__device__ __forceinline__ unsigned long long digest_mix(unsigned long long x) {
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(kThreads) void max_variable_kernel(const uint64_t *a, uint64_t n, unsigned long long *out,
+                                                               unsigned long long salt) {
+    unsigned long long m = 0, h1 = 0, h2 = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kThreads) {
+        const unsigned long long v = a[i];
+        m = v > m ? v : m;
+        h1 += digest_mix(v + digest_mix(i + salt));
+        h2 += digest_mix((v ^ 0x9e3779b97f4a7c15ull) * 0xff51afd7ed558ccdull + i * 0xc4ceb9fe1a85ec53ull + salt);
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         const unsigned long long o = __shfl_xor(m, d, 64);
         m = o > m ? o : m;
+        h1 += __shfl_xor(h1, d, 64);
+        h2 += __shfl_xor(h2, d, 64);
     }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0) {
+        if (m) atomicMax(out, m);
+        atomicAdd(out + 1, h1);
+        atomicAdd(out + 2, h2);
+    }
 }
 
 // small host blob -> device staging buffer (inputs of single-gadget calls: scalars, Variables, offsets)

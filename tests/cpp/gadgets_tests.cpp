@@ -233,7 +233,7 @@ static void test_conditionally_select_0(Engine &e) {
     CHECK(prover.check() >= 0);
     CHECK(same_structure(download(prover), download(verifier)));
     const auto st = prover.refresh_stats();
-    CHECK(st.refreshing && st.rows_in_place == 1 && st.rows_rewritten == 0);  // constrain_to_constant's row (the select is emitted)
+    CHECK(st.refreshing && st.rows_in_place == 2 && st.rows_rewritten == 0);  // the select's row and constrain_to_constant's
     prover.clear_witness();
     circuit(prover, random_scalar(), BlsScalar::zero());
     CHECK(prover.check() == -1);

@@ -52,7 +52,7 @@ def F(x):
 
 def program(dev, ora, ws, bounds=(50_000, 250_000), extra_rows=0):
     """the reference's loop (allocate, range_check, constrain the outcome) over `ws`, then single composer calls with and
-    without public inputs, a max_bound, a select (a call on existing Variables: always emitted in full); on the device
+    without public inputs, a max_bound, a select (a call on existing Variables); on the device
     composer and on the oracle's.  Returns the outcomes' Variables."""
     from oracle import pyoracle as po
     mn, mx = bounds
@@ -108,8 +108,8 @@ def test_prove_twice_flow(engine):
     ora_b = po.Composer()
     res = program(dev, ora_b, wb)
     kept, rewritten, refreshing = dev.refresh_stats()
-    # everything but the select's row (a call on existing Variables: emitted in full, unsigned) was found in place
-    assert refreshing and rewritten == 0 and kept == n_rows - 3 - 1, (kept, rewritten, n_rows)
+    # every row after StandardComposer::new()'s three was found in place
+    assert refreshing and rewritten == 0 and kept == n_rows - 3, (kept, rewritten, n_rows)
     got = dev.export()
     assert got["q_l"][40, 1] == np.uint64(keep[0] ^ 0x55), "a row found in place was written again"
     cols = dev.device_columns()
@@ -149,7 +149,7 @@ def test_another_circuit_after_clear_witness_is_emitted_in_full(engine):
     program_prefix(dev, ora3, [70_000, 1], (50_000, 250_000))
     program(dev, ora3, [2**63, 2**65], bounds=(0, 2**64), extra_rows=2)
     kept3, rewritten3, refreshing3 = dev.refresh_stats()
-    assert refreshing3 and rewritten3 == 0 and kept3 == dev.circuit_size() - 3 - 1
+    assert refreshing3 and rewritten3 == 0 and kept3 == dev.circuit_size() - 3
     same(dev, ora3)
     assert dev.check() == -1 and first and rest
 
@@ -248,7 +248,7 @@ def test_growing_during_a_refresh_keeps_the_rows_in_place(engine):
     dev.reserve(5000, 9000)  # new buffers while only the initial rows are live: the first build's rows must come along
     ora = po.Composer()
     program(dev, ora, [1, 2, 100_000])
-    assert dev.refresh_stats() == (n1 - 3 - 1, 0, True)
+    assert dev.refresh_stats() == (n1 - 3, 0, True)
     same(dev, ora)
     assert dev.check() == -1
 
@@ -269,9 +269,10 @@ def test_fuzz_programs_rebuilt_on_other_witnesses(engine, seed):
     """tests/test_gpu_composer.py's random programs of 30 operations -- every single call and every batched append -- built,
     then clear_witness and the SAME program (same public structure: operations, sizes, bounds, selectors, Variables referred to)
     on other witnesses, three builds in all, the last one cut short and followed by ANOTHER program: after every build the
-    composer == a fresh oracle composer of that build, its first unsatisfied row and its sigma too.  (Appends on device arrays
-    are emitted again, signed ones found in place, the fused mix in place only when no item fails; a witness-dependent shape
-    that differs -- other items with v = 0 -- ends the refresh and everything after it is emitted in full.)"""
+    composer == a fresh oracle composer of that build, its first unsatisfied row and its sigma too.  (Every append is signed --
+    those on device arrays of Variables or bounds by a digest of the arrays -- and found in place; the fused mix and
+    is_non_zero only when no item fails: a witness-dependent shape ends the refresh and everything after it is emitted in
+    full.)"""
     from oracle import pyoracle as po
     import test_gpu_composer as tc
     dev = pg.StandardComposer(engine, 1 << 14, 1 << 14)
@@ -296,9 +297,88 @@ def test_fuzz_programs_rebuilt_on_other_witnesses(engine, seed):
         if build == 0:
             assert kept == 0
             first_log = log
-    # the refresh ends at the first signed append that differs, and in these programs only a fused mix can (its random v hold
-    # zeros: a shape that depends on the witnesses): whatever signed append comes before the first mix must have been found in place
+    # the refresh ends at the first append whose rows differ, and in these programs only a fused mix or an is_non_zero batch can
+    # (random values hold zeros: a shape that depends on the witnesses): whatever appends rows before the first of them must have
+    # been found in place
     ops = [op for op, _ in first_log]
-    before_mix = ops[:ops.index("mix")] if "mix" in ops else ops
-    if any(op in ("rc", "mb", "bool", "ctc") for op in before_mix):
-        assert kept_total > 0, f"seed {seed}: signed appends {before_mix} before the first mix, yet no row was found in place"
+    cut = min([ops.index(o) for o in ("mix", "inz") if o in ops] or [len(ops)])
+    if any(op not in ("add_input", "alloc_batch") for op in ops[:cut]):
+        assert kept_total > 0, f"seed {seed}: appends {ops[:cut]} before the first witness-dependent shape, yet no row was found in place"
+
+
+def test_appends_on_device_arrays_are_signed_by_their_contents(engine):
+    """batched appends whose rows depend on device arrays -- Variables (maybe_equal, select, gate batches, gadgets on allocated
+    witnesses) and per-item bounds (ragged max_bound): rebuilt with the SAME arrays they are found in place (a bent limb in
+    their rows survives); with ONE entry of one array changed, that append and everything after it is written again and the
+    composer equals the oracle's for the new circuit"""
+    from oracle import pyoracle as po
+    tv = lambda xs: torch.tensor(xs, dtype=torch.int64, device="cuda:0")
+    bounds = [200, 2**40 + 1, 3, 2**100, 77, 2**64]
+
+    def build(dev, ora, seed, b_idx, bnds):
+        w = synth.random_scalars(40, seed)
+        first = dev.add_input_batch(t(w))
+        assert first == int(ora.allocate(w[0]).var)
+        for x in w[1:]:
+            ora.allocate(x)
+        a_idx = [first + i for i in range(0, 20)]
+        r = dev.maybe_equal_batch(tv(a_idx), tv(b_idx))
+        o = [ora.L.maybe_equal(ora.c, po.AllocatedScalar(a, ora.L.composer_value(ora.c, a)),
+                               po.AllocatedScalar(b, ora.L.composer_value(ora.c, b))) for a, b in zip(a_idx, b_idx)]
+        assert r.cpu().numpy().view(np.uint64).tolist() == [int(x) for x in o]
+        r = dev.add_batch(S(3), tv(a_idx), S(Q - 1), tv(b_idx), S(9))
+        o = [ora.L.composer_add(ora.c, F(3), a, F(Q - 1), b, F(9), None) for a, b in zip(a_idx, b_idx)]
+        assert r.cpu().numpy().view(np.uint64).tolist() == [int(x) for x in o]
+        vals = [ora.L.composer_value(ora.c, v) for v in a_idx]
+        wv = np.array([[x.l[i] for i in range(4)] for x in vals], dtype=np.uint64)
+        r = dev.range_check_allocated_batch(S(5), S(2**30), tv(a_idx), t(wv))
+        o = [ora.L.range_check(ora.c, F(5), F(2**30), po.AllocatedScalar(v, x)) for v, x in zip(a_idx, vals)]
+        assert r.cpu().numpy().view(np.uint64).tolist() == [int(x) for x in o]
+        wr = synth.scalars_from_ints([int(v) % (2**70) for v in synth.splitmix64(len(bnds), seed + 5)])
+        nb = C.c_uint64()
+        r, _ = dev.max_bound_ragged_batch(t(synth.scalars_from_ints(bnds)), t(wr))
+        o = [ora.L.max_bound(ora.c, F(b), ora.allocate(x), C.byref(nb)) for b, x in zip(bnds, wr)]
+        assert r.cpu().numpy().view(np.uint64).tolist() == [int(x) for x in o]
+        dev.boolean_gate_batch(tv(a_idx[:7]))
+        for a in a_idx[:7]:
+            ora.L.composer_boolean_gate(ora.c, a)
+        return first
+
+    dev = pg.StandardComposer(engine, 1 << 14, 1 << 15)
+    ora = po.Composer()
+    first = build(dev, ora, 1, [5 + 20 + i for i in range(20)], bounds)
+    same(dev, ora)
+    n1 = dev.circuit_size()
+    cols = dev.device_columns()
+    cols.q_m[3 + 1, 2] ^= 0x77  # a row of the maybe_equal batch (rows 3 .. 62)
+    torch.cuda.synchronize()
+    dev.clear_witness()
+    ora = po.Composer()
+    build(dev, ora, 2, [first + 20 + i for i in range(20)], bounds)
+    assert dev.refresh_stats() == (n1 - 3, 0, True)
+    got = dev.export()
+    assert not np.array_equal(got["q_m"][4], ora.export()["q_m"][4]), "a row found in place was written again"
+    cols = dev.device_columns()
+    cols.q_m[3 + 1, 2] ^= 0x77  # still bent: nothing rewrote the row; straighten it
+    torch.cuda.synchronize()
+    same(dev, ora)
+    assert dev.check() == ora.check()
+    # one entry of the second Variable array differs: the maybe_equal batch and all that follows are emitted again
+    dev.clear_witness()
+    ora = po.Composer()
+    other = [first + 20 + i for i in range(20)]
+    other[13] = first + 3
+    build(dev, ora, 3, other, bounds)
+    kept, rewritten, refreshing = dev.refresh_stats()
+    assert not refreshing and kept == 0 and rewritten == n1 - 3
+    same(dev, ora)
+    # ... and one bound of the ragged batch: everything before it stays
+    dev.clear_witness()
+    ora = po.Composer()
+    b2 = list(bounds)
+    b2[4] = 78
+    build(dev, ora, 4, other, b2)
+    kept, rewritten, refreshing = dev.refresh_stats()
+    assert not refreshing and kept == 60 + 20 + 20 * (4 * 31 + 11) and rewritten > 0, (kept, rewritten)
+    same(dev, ora)
+    assert dev.check() == ora.check()
