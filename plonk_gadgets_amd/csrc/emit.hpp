@@ -214,6 +214,16 @@ template <class GD>
 struct PairVars<GD, std::void_t<decltype(GD::kPairVars)>> {
     static constexpr bool ok = GD::kPairVars;
 };
+// kRegionVars (optional, gadgets made of ladder blocks): in a witness refresh the variable sweep goes by REGION -- a wave-pass
+// is the 256 bit variables or the n + 1 accumulators of one block of one item, four consecutive ones per lane -- see the sweep
+template <class GD, class = void>
+struct RegionVars {
+    static constexpr bool ok = false;
+};
+template <class GD>
+struct RegionVars<GD, std::void_t<decltype(GD::kRegionVars)>> {
+    static constexpr bool ok = GD::kRegionVars;
+};
 template <class GD, int MODE>
 struct EmitShape {
     using Rec = typename GD::ItemRec;
@@ -229,6 +239,7 @@ struct EmitShape<GD, EMIT_ROWS> {
 // inv of is_non_zero) are written, at their final slots, by the inversion pre-pass (invert.hpp), which runs
 // concurrently on the engine's side stream; the variable sweep here skips exactly those slots (GD::is_inv_slot).
 template <class GD, int MODE = EMIT_ALL>
+// (a witness refresh is a store stream with little arithmetic left: it wants four waves per SIMD, i.e. at most 128 registers)
 __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(const typename GD::Args A, const EmitOut O) {
     static_assert(MODE != EMIT_STRUCTURE || !(GD::kRagged || GD::kRecInRows), "rows of this gadget depend on its inputs");
     constexpr bool kVars = MODE == EMIT_ALL || MODE == EMIT_VALUES;  // item arithmetic and the variable sweep
@@ -415,106 +426,96 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
             const uint32_t smis = (uint32_t)((reinterpret_cast<uintptr_t>(O.vars + var0 * 2) >> 5) & 3u);
 #endif
 #if !defined(PG_VAR_SWEEP_SINGLE)
-#if defined(PG_VAR_SWEEP_PAIRS_ALWAYS)  // A/B build: the paired sweep in the full emission too (130 registers there: three waves per SIMD instead of four)
-            if constexpr (PairVars<GD>::ok) {
-#else
-            if constexpr (PairVars<GD>::ok && MODE == EMIT_VALUES) {
-#endif
-                // R = 2 consecutive variables per lane.  Half of a ladder block's variables are accumulators, one Montgomery
-                // multiplication each when computed alone (A_i = mont(T mod 2^i)): with rows to write that hides behind the
-                // store stream, a launch that writes ONLY variables (EMIT_VALUES) was bound by it and by its half-line stores
-                // (0.54 of the HBM peak).  A variable that follows one of the same item costs a modular addition where
-                // GD::var_next has a shortcut, and a lane's R scalars leave through a wave-private LDS buffer, two per round,
-                // so that with R = 2 every wave store is one contiguous KiB (7.3 against 8.0 ms per 2^20 witnesses).  R = 4
-                // (two rounds, each writing the 64-byte halves of 64 lines) executes fewer multiplications still but stands at
-                // its stores: 9.9 ms -- what a wave-instruction costs is decided per WAVE, a pass that holds one accumulator
-                // pays the multiplication for all 64 lanes, and the store shape weighs more (profiles/NOTES_r04.md).
-                constexpr int R = 2;
-                static_assert(R == 2 || R == 4, "two scalars per lane and round");
-                __shared__ uint4 s_pair[4 * 272];  // per wave 256 units of 16 bytes, one unit of padding after every 16
-                __shared__ uint8_t s_pflag[kThreads * 2];
+            if constexpr (RegionVars<GD>::ok && MODE == EMIT_VALUES) {
+                // A launch that writes ONLY variables is bound by instruction issue, not by HBM, when it sweeps them as the full
+                // emission does (one scalar per lane, slot by slot: 0.54 of peak): half of a block's variables are accumulators,
+                // A_i = mont(T mod 2^i), one Montgomery multiplication each, and a wave-instruction is paid per WAVE -- a pass
+                // that holds one accumulator runs the multiplication for all 64 lanes.  So the sweep goes by region: a
+                // wave-pass is the 256 bit variables, or the n + 1 accumulators, of ONE block of ONE item; a lane takes four
+                // consecutive ones, the first accumulator by the multiplication, the next three by the reference's own
+                // update A_{i+1} = A_i + b_i mont(2^i) (range.rs:152: a modular addition of a table entry; values fully reduced,
+                // so the limbs are those of the closed form).  One multiplication per 256 accumulators instead of four; a pass
+                // over bits runs none.  A lane's four scalars are 128 contiguous bytes; the wave's 8 KiB leave in two halves
+                // through a wave-private LDS buffer as stores of one contiguous KiB that start on a line.  The few variables
+                // outside those runs (x, T, U, y, R) are written by a loop of their own.
+                __shared__ uint4 s_reg[4 * 288];  // per wave: 256 units of 16 bytes, one unit of padding after every 8
                 const uint32_t wave = tid >> 6, lane = tid & 63;
-                uint4 *wp = s_pair + wave * 272;
-                uint8_t *wf = s_pflag + wave * 128;
-                const uint32_t span = total_vars + smis;  // slots counted from the line before the tile's first variable
-                // (item, variable) of the lane's first slot that holds a variable; uniform items: advanced per pass
-                uint32_t it0 = 0, k0 = 0;
-                if constexpr (!GD::kRagged) {
-                    const uint32_t first = wave * 64 * R + R * lane;
-                    const uint32_t s = first >= smis ? first - smis : 0;
-                    it0 = s / V;
-                    k0 = s - it0 * V;
-                }
-                for (uint32_t base = wave * 64 * R; base < span; base += R * kThreads) {
-                    const uint32_t p0 = base + R * lane;
-                    uint32_t vcount = V;
-                    if constexpr (GD::kRagged) {
-                        if (p0 + (R - 1) >= smis && p0 < span) {
-                            const uint32_t s = p0 >= smis ? p0 - smis : 0;
-                            it0 = find_item<W >= 64, kUniV>(s_voff, Wt, s, it0, uni_vars);
-                            k0 = uni_vars ? s - it0 * kUniV : s - s_voff[it0];
-                            vcount = uni_vars ? kUniV : s_voff[it0 + 1] - s_voff[it0];
-                        }
-                    }
-                    FrVec v[R];
-                    bool st[R];
-                    {
-                        uint32_t it = it0, k = k0;
-                        bool have_prev = false;
-                        Fr prev = fr_zero();
+                uint4 *wp = s_reg + wave * 288;
+                constexpr uint32_t B2 = 2 * GD::kBlocks;
+                const uint32_t units = Wt * B2;
+                for (uint32_t q = wave; q < units; q += kThreads / 64) {
+                    const uint32_t it = q / B2, r = q - it * B2, b = r >> 1;
+                    const uint32_t kind = (r + (GD::kBlocks == 2 ? it : it >> 1)) & 1;  // bits / accumulators alternate per wave
+                    const Rec &R = s_item[it];
+                    const auto &Bk = GD::region_block(R, b);  // (a BoundRec: its canonical T is what the run is made from)
+                    const uint32_t n = GD::region_n(A, R);
+                    const uint32_t count = kind ? (n + 1 < 256 ? n + 1 : 256) : 256;
+                    uint32_t vfirst;  // the run's first variable, relative to the tile
+                    if constexpr (GD::kRagged) vfirst = uni_vars ? it * kUniV : s_voff[it];
+                    else vfirst = it * V;
+                    vfirst += GD::region_k(A, R, b, kind ? 257 : 1);
+                    FrVec v[4];
+                    const uint32_t i0 = 4 * lane;
+                    if (kind == 0) {  // range.rs:128-131
 #pragma unroll
-                        for (int t = 0; t < R; t++) {
-                            const uint32_t slot = p0 + t;
-                            st[t] = false;
-                            v[t].f = fr_zero();
-                            if (slot >= smis && slot < span) {
-                                st[t] = !GD::is_inv_slot(A, s_item[it], k);
-                                if (st[t]) {
-                                    if (!(have_prev && GD::var_next(A, s_item[it], s_table, k, prev, v[t].f)))
-                                        v[t].f = GD::var_value(A, s_item[it], s_table, k);
-                                    prev = v[t].f;
-                                }
-                                have_prev = st[t];
-                                if (++k >= vcount) {  // the next slot opens the next item
-                                    k = 0;
-                                    it++;
-                                    have_prev = false;
-                                    if constexpr (GD::kRagged) {
-                                        if (slot + 1 < span) vcount = uni_vars ? kUniV : s_voff[it + 1] - s_voff[it];
-                                    }
-                                }
+                        for (int t = 0; t < 4; t++) v[t].f = raw_bit(Bk.Tc, i0 + t) ? fr_one() : fr_zero();
+                    } else {
+                        v[0].f = fr_zero();
+                        if (i0 && i0 < count) v[0].f = fr_to_mont(raw_low_bits(Bk.Tc, i0));
+#pragma unroll
+                        for (int t = 1; t < 4; t++) {
+                            v[t].f = v[t - 1].f;
+                            if (i0 + t < count && raw_bit(Bk.Tc, i0 + t - 1)) {
+                                FrVec p;
+                                p.v[0] = s_table[2 * (T_POW + i0 + t - 1)];
+                                p.v[1] = s_table[2 * (T_POW + i0 + t - 1) + 1];
+                                v[t].f = fr_add(v[t - 1].f, p.f);
                             }
                         }
                     }
-                    // global 16-byte unit, relative to the wave's chunk, that lane l stores with store j of round r:
-                    // 32 R j + 2 R (l / 4) + 4 r + (l & 3)  [LDS unit 64 j + l = lane 16 j + l / 4's scalar (l / 2) & 1 of the round]
-                    uint4 *dst = O.vars + ((int64_t)(var0 + base) - (int64_t)smis) * 2 + 2 * R * (lane >> 2) + (lane & 3);
 #pragma unroll
-                    for (int r = 0; r < R / 2; r++) {
-                        // unit u of the round's 4 KiB lives at wp[u + u / 16]: the lanes of a 16-lane group then write 16
-                        // different 16-byte columns of the LDS (64 bytes apart unpadded, four of them would share each)
-                        const uint32_t u0 = 4 * lane, w0i = u0 + (u0 >> 4);
-                        wp[w0i + 0] = v[2 * r].v[0];
-                        wp[w0i + 1] = v[2 * r].v[1];
-                        wp[w0i + 2] = v[2 * r + 1].v[0];
-                        wp[w0i + 3] = v[2 * r + 1].v[1];
-                        wf[2 * lane] = st[2 * r] ? 1 : 0;
-                        wf[2 * lane + 1] = st[2 * r + 1] ? 1 : 0;
-                        // (wave-private, and the LDS runs a wave's instructions in order: the reads below see the other lanes' writes
-                        // above, the next round's writes come after these reads -- no wait, the compiler must only keep the order)
+                    for (int h = 0; h < 2; h++) {
+                        // unit u of the half's 4 KiB lives at wp[u + u / 8]: the lanes of a 16-lane group, 128 bytes apart, then
+                        // write 16 different 16-byte columns of the LDS
+                        if ((lane >> 5) == (uint32_t)h) {
+                            const uint32_t u0 = 8 * (lane & 31), w0 = u0 + (u0 >> 3);
+#pragma unroll
+                            for (int t = 0; t < 4; t++) {
+                                wp[w0 + 2 * t] = v[t].v[0];
+                                wp[w0 + 2 * t + 1] = v[t].v[1];
+                            }
+                        }
+                        // (wave-private, and the LDS runs a wave's instructions in order: the reads below see the other lanes'
+                        // writes, the next half's writes come after these reads -- the compiler must only keep the order)
                         asm volatile("" ::: "memory");
+                        const uint32_t done = 128 * h;
+                        const uint32_t valid = count > done ? 2 * (count - done < 128 ? count - done : 128) : 0;  // units of this half
+                        uint4 *dst = O.vars + ((uint64_t)var0 + vfirst + done) * 2;
+                        const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(dst) >> 4) & 7u);  // units into its line
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const uint32_t u = 64 * j + lane;
-                            const uint4 val = wp[u + (u >> 4)];
-                            if (wf[u >> 1]) store16(dst + 32 * R * j + 4 * r, val);
+                        for (int j = 0; j < 5; j++) {
+                            const uint32_t g = 64 * j + lane - mis;  // (wraps below zero for the lanes before the first unit)
+                            if (g < valid) store16(dst + g, wp[g + (g >> 3)]);
                         }
                         asm volatile("" ::: "memory");
                     }
-                    if constexpr (!GD::kRagged) {
-                        // (a lane whose first slots lay before the tile's first variable stood at variable 0 of item 0)
-                        k0 += p0 >= smis ? R * kThreads : R * kThreads - (smis - p0);
-                        while (k0 >= V) { k0 -= V; it0++; }
+                    // the item's variables outside the runs, a share of them with every run of the item: they lie in the lines
+                    // the runs' first and last stores leave incomplete, and a line completed within microseconds is still in
+                    // the L2 -- written once the tile's runs are through (a loop of its own, ~150 us later) they cost 1 ms of
+                    // the 8: partial lines written to HBM twice
+                    {
+                        const uint32_t nloose = GD::loose_count(A);
+                        const uint32_t l0 = r * nloose / B2, l1 = (r + 1) * nloose / B2;
+                        if (lane < l1 - l0) {
+                            const uint32_t k = GD::loose_k(A, R, l0 + lane);
+                            if (!GD::is_inv_slot(A, R, k)) {
+                                FrVec val;
+                                val.f = GD::var_value(A, R, s_table, k);
+                                uint4 *dst = O.vars + ((uint64_t)var0 + (vfirst - GD::region_k(A, R, b, kind ? 257 : 1)) + k) * 2;
+                                store16(dst, val.v[0]);
+                                store16(dst + 1, val.v[1]);
+                            }
+                        }
                     }
                 }
             } else

@@ -269,6 +269,22 @@ struct RangeCheckGD {
         if (kk >= VB) { kk -= VB; blk = 1; }
         return bound_var_next(R.b[blk], kk, n, table, prev, out);
     }
+    // the region sweep of a witness refresh (emit.hpp): blocks, where their variables lie in the item, and the few variables
+    // outside the blocks' bit and accumulator runs ([x] | T U y | T U y | R; z is the pre-pass's)
+    static constexpr bool kRegionVars = true;
+    static constexpr uint32_t kBlocks = 2;
+    __device__ static uint32_t region_n(const Args &A, const ItemRec &) { return A.n; }
+    __device__ static const BoundRec &region_block(const ItemRec &R, uint32_t b) { return R.b[b]; }
+    __device__ static uint32_t region_k(const Args &A, const ItemRec &, uint32_t b, uint32_t kk) { return xo(A) + b * (A.n + 261) + kk; }
+    __device__ static uint32_t loose_count(const Args &A) { return xo(A) + 7; }
+    __device__ static uint32_t loose_k(const Args &A, const ItemRec &, uint32_t j) {
+        const uint32_t x0 = xo(A), n = A.n, VB = n + 261;
+        if (j < x0) return 0;
+        j -= x0;
+        if (j == 6) return x0 + 2 * VB;
+        const uint32_t b = j / 3, w = j - 3 * b;
+        return x0 + b * VB + (w == 0 ? 0 : (w == 1 ? 258 + n : 260 + n));
+    }
 };
 
 // ---- max_bound: one public bound for the whole batch, or one bound per item ----
@@ -411,6 +427,18 @@ struct MaxBoundGD {
         }
         return bound_var_next(R.b, k, RAGGED ? R.n : A.n, table, prev, out);
     }
+    static constexpr bool kRegionVars = true;
+    static constexpr uint32_t kBlocks = 1;
+    __device__ static uint32_t region_n(const Args &A, const ItemRec &R) { return RAGGED ? R.n : A.n; }
+    __device__ static const BoundRec &region_block(const ItemRec &R, uint32_t) { return R.b; }
+    __device__ static uint32_t region_k(const Args &A, const ItemRec &, uint32_t, uint32_t kk) { return xo(A) + kk; }
+    __device__ static uint32_t loose_count(const Args &A) { return xo(A) + 3; }
+    __device__ static uint32_t loose_k(const Args &A, const ItemRec &R, uint32_t j) {
+        const uint32_t x0 = xo(A), n = RAGGED ? R.n : A.n;
+        if (j < x0) return 0;
+        j -= x0;
+        return x0 + (j == 0 ? 0 : (j == 1 ? 258 + n : 260 + n));
+    }
 };
 
 // ---- scalar_decomposition_gadget alone (range.rs:119-158): the bound block without its add row ------------------
@@ -483,6 +511,16 @@ struct DecompositionGD {
     static constexpr bool kPairVars = true;
     __device__ static bool var_next(const Args &A, const ItemRec &R, const uint4 *table, uint32_t k, const Fr &prev, Fr &out) {
         return bound_var_next(R.b, k + 1, A.n, table, prev, out);
+    }
+    static constexpr bool kRegionVars = true;
+    static constexpr uint32_t kBlocks = 1;
+    __device__ static uint32_t region_n(const Args &A, const ItemRec &) { return A.n; }
+    __device__ static const BoundRec &region_block(const ItemRec &R, uint32_t) { return R.b; }
+    __device__ static uint32_t region_k(const Args &, const ItemRec &, uint32_t, uint32_t kk) { return kk - 1; }  // (no T: the block starts at its bits)
+    // (num_bits may be 256 here, range.rs:134: 257 accumulators, one more than a wave-pass of four per lane holds -- the last is loose)
+    __device__ static uint32_t loose_count(const Args &A) { return A.n == 256 ? 3 : 2; }
+    __device__ static uint32_t loose_k(const Args &A, const ItemRec &, uint32_t j) {
+        return (j == 0 ? 258 + A.n : (j == 1 ? 260 + A.n : 257 + 256)) - 1;
     }
 };
 

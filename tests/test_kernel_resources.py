@@ -54,5 +54,5 @@ def test_no_kernel_uses_scratch_and_residency_assumptions_hold(tmp_path):
         assert k["vgpr"] <= 72
     for k in one("gate_queue_kernel"):
         assert k["vgpr"] <= 128
-    emit = [k for n, k in ks.items() if "emit_kernel" in n and "RangeCheckGD" in n]
+    emit = [k for n, k in ks.items() if "emit_kernel" in n and "RangeCheckGDELi0E" in n]  # the full emission (EMIT_ALL): four waves per SIMD
     assert emit and all(k["vgpr"] <= 128 for k in emit)
