@@ -221,6 +221,9 @@ pg::EmitOut make_out(const pg_columns *c, uint64_t batch, int W, uint64_t gate_b
     O.var_off = var_off;
     O.batch = batch;
     O.tiles = (uint32_t)((batch + W - 1) / W);
+    O.inv_dense = nullptr;
+    O.inv_elems = 0;
+    O.inv_in_place = 1;
     return O;
 }
 
@@ -349,6 +352,11 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
                 PG_HIP_TRY(hipEventRecord(e->ev_fork, st));  // the pre-pass reads the call's inputs: order it after the stream
                 PG_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
                 inv_st = e->side;
+            }
+            if constexpr (pg::InvDense<GD>::ok) {
+                O.inv_dense = e->d_prefix;
+                O.inv_elems = elems;
+                O.inv_in_place = side;  // else the pre-pass is through before the emitter starts: it leaves the inverses where it computed them
             }
             hipLaunchKernelGGL((pg::batch_invert_kernel<GD, GRP>), dim3(blocks), dim3(pg::kThreads), 0, inv_st, A, O, elems,
                                (uint32_t)groups, e->d_prefix);

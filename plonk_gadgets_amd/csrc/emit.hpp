@@ -44,6 +44,16 @@ struct EmitOut {
     const uint64_t *var_off;
     uint64_t batch;
     uint32_t tiles;
+    // The inverses of the call (invert.hpp).  inv_in_place: the pre-pass runs BESIDE the emitter and writes every inverse at
+    // its final slot, which the emitter skips -- a 32-byte hole in a 128-byte line, i.e. two partial line writes to HBM: at
+    // 2^20 x range_check that alone is 0.6 ms of a witness refresh's 7.4.  Big calls (and tiny ones) run the pre-pass to
+    // completion BEFORE the emitter on the same stream, and it leaves the inverses in the engine's scratch array: two planes of
+    // 16-byte halves, element s = e * batch + item at inv_dense[s] and inv_dense[inv_elems + s]; the emitter (GD::kInvDense
+    // gadgets) fetches them with its items' inputs and writes the variable itself, with its neighbours.  (inv_dense is
+    // readable either way for those gadgets -- what is read beside a running pre-pass is not used.)
+    const uint4 *inv_dense;
+    uint64_t inv_elems;
+    uint32_t inv_in_place;
 };
 
 // constant-table slots every gadget shares
@@ -224,6 +234,14 @@ template <class GD>
 struct RegionVars<GD, std::void_t<decltype(GD::kRegionVars)>> {
     static constexpr bool ok = GD::kRegionVars;
 };
+template <class GD, class = void>
+struct InvDense {
+    static constexpr bool ok = false;
+};
+template <class GD>
+struct InvDense<GD, std::void_t<decltype(GD::kInvDense)>> {
+    static constexpr bool ok = GD::kInvDense;
+};
 template <class GD, int MODE>
 struct EmitShape {
     using Rec = typename GD::ItemRec;
@@ -235,11 +253,14 @@ struct EmitShape<GD, EMIT_ROWS> {
     static constexpr int W = GD::kRowsW;
 };
 
+// the region sweep's stage (emit_kernel<GD, EMIT_VALUES>), per wave, in units of 16 bytes: 8 units of neighbours, the half's
+// 256, 8 more, one unit of padding after every 8
+constexpr uint32_t kRegionLead = 8, kRegionStage = (kRegionLead + 256 + 8) / 8 * 9;
+
 // Nothing an EMIT_ALL launch writes depends on a field inversion: the variables that hold inverses (z of maybe_equal,
 // inv of is_non_zero) are written, at their final slots, by the inversion pre-pass (invert.hpp), which runs
 // concurrently on the engine's side stream; the variable sweep here skips exactly those slots (GD::is_inv_slot).
 template <class GD, int MODE = EMIT_ALL>
-// (a witness refresh is a store stream with little arithmetic left: it wants four waves per SIMD, i.e. at most 128 registers)
 __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(const typename GD::Args A, const EmitOut O) {
     static_assert(MODE != EMIT_STRUCTURE || !(GD::kRagged || GD::kRecInRows), "rows of this gadget depend on its inputs");
     constexpr bool kVars = MODE == EMIT_ALL || MODE == EMIT_VALUES;  // item arithmetic and the variable sweep
@@ -418,6 +439,7 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
 
         // ---- variable sweep: one scalar (2 x 16 B) per lane ----------------
         if constexpr (kVars) {
+            const bool inv_here = InvDense<GD>::ok && !O.inv_in_place;  // the inverses are in the records: written here
             // slots are counted from the 128-byte line before the tile's first one (see the selector sweep): a wave's two
             // stores then cover whole lines between them
 #if defined(PG_UNALIGNED_SWEEPS)
@@ -436,11 +458,10 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                 // update A_{i+1} = A_i + b_i mont(2^i) (range.rs:152: a modular addition of a table entry; values fully reduced,
                 // so the limbs are those of the closed form).  One multiplication per 256 accumulators instead of four; a pass
                 // over bits runs none.  A lane's four scalars are 128 contiguous bytes; the wave's 8 KiB leave in two halves
-                // through a wave-private LDS buffer as stores of one contiguous KiB that start on a line.  The few variables
-                // outside those runs (x, T, U, y, R) are written by a loop of their own.
-                __shared__ uint4 s_reg[4 * 288];  // per wave: 256 units of 16 bytes, one unit of padding after every 8
+                // through a wave-private LDS buffer as stores of one contiguous KiB that start on a line.
+                __shared__ uint4 s_reg[4 * kRegionStage];
                 const uint32_t wave = tid >> 6, lane = tid & 63;
-                uint4 *wp = s_reg + wave * 288;
+                uint4 *wp = s_reg + wave * kRegionStage;
                 constexpr uint32_t B2 = 2 * GD::kBlocks;
                 const uint32_t units = Wt * B2;
                 for (uint32_t q = wave; q < units; q += kThreads / 64) {
@@ -450,10 +471,28 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                     const auto &Bk = GD::region_block(R, b);  // (a BoundRec: its canonical T is what the run is made from)
                     const uint32_t n = GD::region_n(A, R);
                     const uint32_t count = kind ? (n + 1 < 256 ? n + 1 : 256) : 256;
-                    uint32_t vfirst;  // the run's first variable, relative to the tile
-                    if constexpr (GD::kRagged) vfirst = uni_vars ? it * kUniV : s_voff[it];
-                    else vfirst = it * V;
-                    vfirst += GD::region_k(A, R, b, kind ? 257 : 1);
+                    uint32_t vitem, vend;  // the item's first variable and the one after its last, relative to the tile
+                    if constexpr (GD::kRagged) {
+                        vitem = uni_vars ? it * kUniV : s_voff[it];
+                        vend = uni_vars ? vitem + kUniV : s_voff[it + 1];
+                    } else {
+                        vitem = it * V;
+                        vend = vitem + V;
+                    }
+                    const uint32_t kfirst = GD::region_k(A, R, b, kind ? 257 : 1);  // the run's first variable, in the item
+                    // The variables outside the runs (x, T, U, y, R, A_256) lie in the lines a run's first and last store
+                    // leave incomplete.  Written by a loop of their own once the tile's runs are through (~150 us later) they
+                    // cost 1 ms of 8: partial lines go to HBM twice.  So a pass takes its neighbours along, in the same
+                    // store instructions: what precedes the item's first run, what follows an accumulator run
+                    const uint32_t pre = (kind == 0 && b == 0) ? kfirst : 0;
+                    uint32_t post = 0;
+                    if (kind) post = (b + 1 < GD::kBlocks ? GD::region_k(A, R, b + 1, 1) : vend - vitem) - (kfirst + count);
+                    if (post > kRegionLead / 2) post = kRegionLead / 2;  // (never: U z y and at most one of T, R, A_256 -- the stage's room)
+                    const uint32_t h_end = (count - 1) >> 7;  // the half that holds the run's end
+                    uint32_t hole = ~0u;                      // the neighbour the pre-pass has written in place (z), if any
+                    if (!inv_here)
+                        for (uint32_t j = 0; j < post; j++)
+                            if (GD::is_inv_slot(A, R, kfirst + count + j)) hole = j;
                     FrVec v[4];
                     const uint32_t i0 = 4 * lane;
                     if (kind == 0) {  // range.rs:128-131
@@ -473,49 +512,50 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                             }
                         }
                     }
+                    // the neighbours' values: lanes 0 .. pre + post - 1 (records in the LDS; arithmetic only for A_256)
+                    FrVec nb;
+                    uint32_t nb_at = ~0u;  // where the lane's neighbour goes in the stage (units; ~0: the lane has none)
+                    if (lane < pre + post) {
+                        const uint32_t k = lane < pre ? lane : kfirst + count + (lane - pre);
+                        nb.f = GD::var_value(A, R, s_table, k);
+                        nb_at = lane < pre ? kRegionLead - 2 * pre + 2 * lane
+                                           : kRegionLead + 2 * (count - 128 * h_end) + 2 * (lane - pre);
+                    }
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
-                        // unit u of the half's 4 KiB lives at wp[u + u / 8]: the lanes of a 16-lane group, 128 bytes apart, then
-                        // write 16 different 16-byte columns of the LDS
+                        // the stage holds the half's 256 units of 16 bytes from unit kRegionLead on, the neighbours before and
+                        // after them; unit u lives at wp[u + u / 8]: the lanes of a 16-lane group, 128 bytes apart, then write 16
+                        // different 16-byte columns of the LDS
                         if ((lane >> 5) == (uint32_t)h) {
-                            const uint32_t u0 = 8 * (lane & 31), w0 = u0 + (u0 >> 3);
+                            const uint32_t u0 = kRegionLead + 8 * (lane & 31), w0 = u0 + (u0 >> 3);
 #pragma unroll
                             for (int t = 0; t < 4; t++) {
                                 wp[w0 + 2 * t] = v[t].v[0];
                                 wp[w0 + 2 * t + 1] = v[t].v[1];
                             }
                         }
+                        const uint32_t pre_u = h == 0 ? 2 * pre : 0, post_u = (uint32_t)h == h_end ? 2 * post : 0;
+                        if (nb_at != ~0u && (lane < pre ? h == 0 : (uint32_t)h == h_end)) {
+                            wp[nb_at + (nb_at >> 3)] = nb.v[0];
+                            wp[nb_at + 1 + ((nb_at + 1) >> 3)] = nb.v[1];
+                        }
                         // (wave-private, and the LDS runs a wave's instructions in order: the reads below see the other lanes'
                         // writes, the next half's writes come after these reads -- the compiler must only keep the order)
                         asm volatile("" ::: "memory");
                         const uint32_t done = 128 * h;
-                        const uint32_t valid = count > done ? 2 * (count - done < 128 ? count - done : 128) : 0;  // units of this half
-                        uint4 *dst = O.vars + ((uint64_t)var0 + vfirst + done) * 2;
+                        const uint32_t valid = count > done ? 2 * (count - done < 128 ? count - done : 128) : 0;  // the run's units in this half
+                        const uint32_t total = valid ? pre_u + valid + post_u : 0;
+                        const uint32_t holev = ((uint32_t)h == h_end && hole != ~0u) ? (pre_u + valid) / 2 + hole : ~0u;
+                        uint4 *dst = O.vars + ((uint64_t)var0 + vitem + kfirst + done) * 2 - pre_u;
                         const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(dst) >> 4) & 7u);  // units into its line
+                        const uint32_t lead = kRegionLead - pre_u;
 #pragma unroll
                         for (int j = 0; j < 5; j++) {
                             const uint32_t g = 64 * j + lane - mis;  // (wraps below zero for the lanes before the first unit)
-                            if (g < valid) store16(dst + g, wp[g + (g >> 3)]);
+                            const uint32_t u = g + lead;
+                            if (g < total && (g >> 1) != holev) store16(dst + g, wp[u + (u >> 3)]);
                         }
                         asm volatile("" ::: "memory");
-                    }
-                    // the item's variables outside the runs, a share of them with every run of the item: they lie in the lines
-                    // the runs' first and last stores leave incomplete, and a line completed within microseconds is still in
-                    // the L2 -- written once the tile's runs are through (a loop of its own, ~150 us later) they cost 1 ms of
-                    // the 8: partial lines written to HBM twice
-                    {
-                        const uint32_t nloose = GD::loose_count(A);
-                        const uint32_t l0 = r * nloose / B2, l1 = (r + 1) * nloose / B2;
-                        if (lane < l1 - l0) {
-                            const uint32_t k = GD::loose_k(A, R, l0 + lane);
-                            if (!GD::is_inv_slot(A, R, k)) {
-                                FrVec val;
-                                val.f = GD::var_value(A, R, s_table, k);
-                                uint4 *dst = O.vars + ((uint64_t)var0 + (vfirst - GD::region_k(A, R, b, kind ? 257 : 1)) + k) * 2;
-                                store16(dst, val.v[0]);
-                                store16(dst + 1, val.v[1]);
-                            }
-                        }
                     }
                 }
             } else
@@ -531,7 +571,7 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                         k = uni_vars ? s - it * kUniV : s - s_voff[it];
                     }
                     uint4 *dst = O.vars + (var0 + s) * 2;
-                    if (!GD::is_inv_slot(A, s_item[it], k)) {  // the pre-pass's, written in place
+                    if (inv_here || !GD::is_inv_slot(A, s_item[it], k)) {  // (the pre-pass's, written in place)
                         FrVec val;
                         val.f = GD::var_value(A, s_item[it], s_table, k);
                         store16(dst, val.v[0]);

@@ -6,10 +6,13 @@
 // coalesce), multiplies them up, inverts ONE product, and unwinds:
 //     inv(x_k) = inv(x_0..x_k) * (x_0..x_{k-1}),   inv(x_0..x_{k-1}) = inv(x_0..x_k) * x_k
 // 3 multiplications per element + one inversion per lane.  Zero elements are skipped and come out as zero (the
-// reference's unwrap_or(zero) at scalar.rs:122).  Each inverse goes straight to its final slot in the call's variable
-// table (GD::inv_slot; NULL when the item has no such variable -- an is_non_zero item that stopped at its error),
-// which the emit kernel leaves alone: the two kernels write disjoint bytes, so they run concurrently on two streams
-// and the call joins them at the end.
+// reference's unwrap_or(zero) at scalar.rs:122).  Where the inverses go depends on the call's size (EmitOut::inv_in_place):
+// a call of a few thousand elements runs the pre-pass BESIDE the emitter, and each inverse goes straight to its final
+// slot in the call's variable table (GD::inv_slot; NULL when the item has no such variable -- an is_non_zero item that
+// stopped at its error), which the emit kernel leaves alone: the two kernels write disjoint bytes, so they run
+// concurrently on two streams and the call joins them at the end.  A big call runs it FIRST and leaves the inverses
+// in the scratch array, dense; the emitter reads them with its items' inputs and writes them as it writes every other
+// variable (no 32-byte holes in its lines, no scattered 32-byte stores here).
 //
 // What the kernel is built around is MEMORY LATENCY, not arithmetic: it runs beside a writer that saturates HBM, so a
 // load takes several microseconds, and a lane's chain is strictly sequential.  Round 1 loaded one element per step
@@ -150,6 +153,14 @@ __global__ __launch_bounds__(kThreads) void batch_invert_kernel(const typename G
             uint64_t item;
             uint32_t e;
             inv_locate<GD::kInv>(s, batch, item, e);
+            if (!O.inv_in_place) {
+                // over x's planes (this lane's own element, already in registers): a wave's store is one contiguous KiB, and
+                // the emitter writes the variable with the rest of its line
+                uint4 *dst = scratch + s;
+                dst[0] = o.v[0];
+                dst[n_elems] = o.v[1];
+                continue;
+            }
             uint4 *slot = GD::inv_slot(A, O, item, e);
             if (slot) {
                 slot[0] = o.v[0];

@@ -30,8 +30,16 @@ namespace pg {
 struct alignas(16) BoundRec {
     Fr Tm;  // T in Montgomery form (the block's first variable)
     Fr Tc;  // canonical integer of T
-    Fr U;   // A_n - T   (its inverse z is written by the pre-pass, invert.hpp)
+    Fr UZ[2];  // u = A_n - T, and its inverse z -- the pre-pass's (invert.hpp): held here when it has left the call's inverses
+               // in the scratch array (!EmitOut::inv_in_place), else not used
 };
+
+// z of element s of the call, from the pre-pass's dense output (unconditionally: beside a running pre-pass the bytes are not used)
+__device__ __forceinline__ void bound_fetch_z(const EmitOut &O, uint64_t s, BoundRec &b) {
+    uint4 *z = reinterpret_cast<uint4 *>(&b.UZ[1]);  // (16-byte halves straight into the record: a copy through an Fr temporary
+    z[0] = O.inv_dense[s];                           // goes through private memory here)
+    z[1] = O.inv_dense[O.inv_elems + s];
+}
 
 // u = accumulator - witness (scalar.rs:121) of a bound block: A_n - T with A_n = mont(T mod 2^n); 0 when T fits n bits
 __device__ __forceinline__ Fr bound_u(const Fr &Tm, const Fr &Tc, uint32_t n) {
@@ -44,8 +52,9 @@ __device__ __forceinline__ uint32_t bound_item(const Fr &Tm, uint32_t n, BoundRe
     const Fr Tc = fr_from_mont(Tm);  // scalar_to_bits -> to_bytes, range.rs:163
     b.Tm = Tm;
     b.Tc = Tc;
-    b.U = bound_u(Tm, Tc, n);
-    return fr_is_zero(b.U) ? 1u : 0u;  // y = 1 - u z
+    const Fr u = bound_u(Tm, Tc, n);
+    b.UZ[0] = u;
+    return fr_is_zero(u) ? 1u : 0u;  // y = 1 - u z
 }
 
 // offset of z inside a bound block's variables
@@ -112,8 +121,13 @@ __device__ __forceinline__ Fr bound_var_value(const BoundRec &B, uint32_t y, uin
         const uint32_t i = kk - 257;
         return i ? fr_to_mont(raw_low_bits(B.Tc, i)) : fr_zero();
     }
-    if (kk == 258 + n) return B.U;
-    // kk == 259 + n is z: written by the pre-pass, never asked for here
+    if (kk <= 259 + n) {  // u, z (z is asked for only when the record holds it: !EmitOut::inv_in_place)
+        const uint4 *p = reinterpret_cast<const uint4 *>(B.UZ) + 2 * (kk - (258 + n));
+        FrVec v;
+        v.v[0] = p[0];
+        v.v[1] = p[1];
+        return v.f;
+    }
     return y ? fr_one() : fr_zero();  // scalar.rs:126
 }
 
@@ -152,6 +166,7 @@ struct RangeCheckGD {
         const uint4 *pow2;
     };
     static constexpr int kInv = 2;
+    static constexpr bool kInvDense = true;  // item() fetches the inverses when the pre-pass has left them dense
     static constexpr int kInvGroup = 4;  // elements a lane of the pre-pass fetches per round trip (inv_combine is register-hungry here)
     // element e of item: u of the max block (e = 0) / min block (e = 1)
     __device__ static void inv_operands(const Args &A, const EmitOut &, uint64_t item, uint32_t, FrVec &p, FrVec &q, uint32_t &) {
@@ -210,6 +225,8 @@ struct RangeCheckGD {
         x.v[1] = A.witness[item * 2 + 1];
         R.x = x.f;
         // T = (max-1) - x  (range.rs:102)   |   T = x - min  (range.rs:69)
+        bound_fetch_z(O, item, R.b[0]);  // (elements are numbered e-major, invert.hpp)
+        bound_fetch_z(O, O.batch + item, R.b[1]);
         R.y[0] = bound_item(fr_sub(lds_fr(table, T_QC_A), x.f), A.n, R.b[0]);
         R.y[1] = bound_item(fr_add(x.f, lds_fr(table, T_QC_B)), A.n, R.b[1]);
         const uint64_t V = vars_per_item(A);
@@ -269,22 +286,13 @@ struct RangeCheckGD {
         if (kk >= VB) { kk -= VB; blk = 1; }
         return bound_var_next(R.b[blk], kk, n, table, prev, out);
     }
-    // the region sweep of a witness refresh (emit.hpp): blocks, where their variables lie in the item, and the few variables
-    // outside the blocks' bit and accumulator runs ([x] | T U y | T U y | R; z is the pre-pass's)
+    // the region sweep of a witness refresh (emit.hpp): blocks, and where their variables lie in the item
+    // ([x] | T bits accumulators U z y | T bits accumulators U z y | R; z is the pre-pass's)
     static constexpr bool kRegionVars = true;
     static constexpr uint32_t kBlocks = 2;
     __device__ static uint32_t region_n(const Args &A, const ItemRec &) { return A.n; }
     __device__ static const BoundRec &region_block(const ItemRec &R, uint32_t b) { return R.b[b]; }
     __device__ static uint32_t region_k(const Args &A, const ItemRec &, uint32_t b, uint32_t kk) { return xo(A) + b * (A.n + 261) + kk; }
-    __device__ static uint32_t loose_count(const Args &A) { return xo(A) + 7; }
-    __device__ static uint32_t loose_k(const Args &A, const ItemRec &, uint32_t j) {
-        const uint32_t x0 = xo(A), n = A.n, VB = n + 261;
-        if (j < x0) return 0;
-        j -= x0;
-        if (j == 6) return x0 + 2 * VB;
-        const uint32_t b = j / 3, w = j - 3 * b;
-        return x0 + b * VB + (w == 0 ? 0 : (w == 1 ? 258 + n : 260 + n));
-    }
 };
 
 // ---- max_bound: one public bound for the whole batch, or one bound per item ----
@@ -301,6 +309,7 @@ struct MaxBoundGD {
         const uint4 *pow2;
     };
     static constexpr int kInv = 1;
+    static constexpr bool kInvDense = true;
     static constexpr int kInvGroup = 4;  // elements a lane of the pre-pass fetches per round trip (inv_combine is register-hungry here)
     __device__ static uint4 *inv_slot(const Args &A, const EmitOut &O, uint64_t item, uint32_t) {
         const uint32_t n = RAGGED ? A.num_bits_v[item] : A.n;
@@ -370,6 +379,7 @@ struct MaxBoundGD {
         x.v[0] = A.witness[item * 2];
         x.v[1] = A.witness[item * 2 + 1];
         R.x = x.f;
+        bound_fetch_z(O, item, R.b);
         uint32_t n = A.n;
         Fr qc;
         if constexpr (RAGGED) {  // R.qc / R.n are item_rows' (same lane, earlier): read, never rewritten
@@ -432,13 +442,6 @@ struct MaxBoundGD {
     __device__ static uint32_t region_n(const Args &A, const ItemRec &R) { return RAGGED ? R.n : A.n; }
     __device__ static const BoundRec &region_block(const ItemRec &R, uint32_t) { return R.b; }
     __device__ static uint32_t region_k(const Args &A, const ItemRec &, uint32_t, uint32_t kk) { return xo(A) + kk; }
-    __device__ static uint32_t loose_count(const Args &A) { return xo(A) + 3; }
-    __device__ static uint32_t loose_k(const Args &A, const ItemRec &R, uint32_t j) {
-        const uint32_t x0 = xo(A), n = RAGGED ? R.n : A.n;
-        if (j < x0) return 0;
-        j -= x0;
-        return x0 + (j == 0 ? 0 : (j == 1 ? 258 + n : 260 + n));
-    }
 };
 
 // ---- scalar_decomposition_gadget alone (range.rs:119-158): the bound block without its add row ------------------
@@ -455,6 +458,7 @@ struct DecompositionGD {
         const uint4 *pow2;
     };
     static constexpr int kInv = 1;
+    static constexpr bool kInvDense = true;
     static constexpr int kInvGroup = 4;  // elements a lane of the pre-pass fetches per round trip (inv_combine is register-hungry here)
     __device__ static void inv_operands(const Args &A, const EmitOut &, uint64_t item, uint32_t, FrVec &p, FrVec &q, uint32_t &) {
         p.v[0] = A.witness[item * 2];
@@ -487,6 +491,7 @@ struct DecompositionGD {
         FrVec x;
         x.v[0] = A.witness[item * 2];
         x.v[1] = A.witness[item * 2 + 1];
+        bound_fetch_z(O, item, R.b);
         R.y = bound_item(x.f, A.n, R.b);
         const uint64_t V = vars_per_item(A);
         if (A.result_vars) A.result_vars[item] = O.var_base + item * V + (V - 1);
@@ -517,11 +522,7 @@ struct DecompositionGD {
     __device__ static uint32_t region_n(const Args &A, const ItemRec &) { return A.n; }
     __device__ static const BoundRec &region_block(const ItemRec &R, uint32_t) { return R.b; }
     __device__ static uint32_t region_k(const Args &, const ItemRec &, uint32_t, uint32_t kk) { return kk - 1; }  // (no T: the block starts at its bits)
-    // (num_bits may be 256 here, range.rs:134: 257 accumulators, one more than a wave-pass of four per lane holds -- the last is loose)
-    __device__ static uint32_t loose_count(const Args &A) { return A.n == 256 ? 3 : 2; }
-    __device__ static uint32_t loose_k(const Args &A, const ItemRec &, uint32_t j) {
-        return (j == 0 ? 258 + A.n : (j == 1 ? 260 + A.n : 257 + 256)) - 1;
-    }
+    // (num_bits may be 256 here, range.rs:134: 257 accumulators, one more than a wave-pass of four per lane holds -- the last goes with U z y)
 };
 
 // plan of a ragged max_bound batch: ladder bits and row/variable counts per item (range.rs:87-90)
