@@ -253,9 +253,10 @@ struct EmitShape<GD, EMIT_ROWS> {
     static constexpr int W = GD::kRowsW;
 };
 
-// the region sweep's stage (emit_kernel<GD, EMIT_VALUES>), per wave, in units of 16 bytes: 8 units of neighbours, the half's
-// 256, 8 more, one unit of padding after every 8
-constexpr uint32_t kRegionLead = 8, kRegionStage = (kRegionLead + 256 + 8) / 8 * 9;
+// the region sweep's stage (emit_kernel<GD, EMIT_VALUES>), per wave, in units of 16 bytes: 8 units for what precedes the run in
+// the pass's first line (at most three variables), the half's 256, 16 for what follows it (U z y, one of T / R / A_256, at most
+// three variables of the next run); one unit of padding after every 8
+constexpr uint32_t kRegionLead = 8, kRegionStage = (kRegionLead + 256 + 16) / 8 * 9;
 
 // Nothing an EMIT_ALL launch writes depends on a field inversion: the variables that hold inverses (z of maybe_equal,
 // inv of is_non_zero) are written, at their final slots, by the inversion pre-pass (invert.hpp), which runs
@@ -464,6 +465,7 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                 uint4 *wp = s_reg + wave * kRegionStage;
                 constexpr uint32_t B2 = 2 * GD::kBlocks;
                 const uint32_t units = Wt * B2;
+                const uint32_t tile_mis = (uint32_t)((reinterpret_cast<uintptr_t>(O.vars + var0 * 2) >> 5) & 3u);  // variables into its line
                 for (uint32_t q = wave; q < units; q += kThreads / 64) {
                     const uint32_t it = q / B2, r = q - it * B2, b = r >> 1;
                     const uint32_t kind = (r + (GD::kBlocks == 2 ? it : it >> 1)) & 1;  // bits / accumulators alternate per wave
@@ -480,19 +482,32 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                         vend = vitem + V;
                     }
                     const uint32_t kfirst = GD::region_k(A, R, b, kind ? 257 : 1);  // the run's first variable, in the item
-                    // The variables outside the runs (x, T, U, y, R, A_256) lie in the lines a run's first and last store
-                    // leave incomplete.  Written by a loop of their own once the tile's runs are through (~150 us later) they
-                    // cost 1 ms of 8: partial lines go to HBM twice.  So a pass takes its neighbours along, in the same
-                    // store instructions: what precedes the item's first run, what follows an accumulator run
-                    const uint32_t pre = (kind == 0 && b == 0) ? kfirst : 0;
-                    uint32_t post = 0;
-                    if (kind) post = (b + 1 < GD::kBlocks ? GD::region_k(A, R, b + 1, 1) : vend - vitem) - (kfirst + count);
-                    if (post > kRegionLead / 2) post = kRegionLead / 2;  // (never: U z y and at most one of T, R, A_256 -- the stage's room)
+                    // WHO WRITES WHICH LINE.  A 128-byte line (four variables) that reaches HBM in two pieces costs far more than
+                    // its share -- the pre-pass's 32-byte z alone, written in place, was 0.6 ms of 7.4 -- so every line of the
+                    // tile is written by ONE pass, in one store instruction.  The variables outside the runs (x, T, U, z, y, R,
+                    // A_256) go with a neighbouring run: what precedes the item's first run with that run, what follows an
+                    // accumulator run with it.  The lines two passes would share belong to the ACCUMULATOR pass on both sides: it
+                    // starts at the line that holds its first variable (up to three bits of its own block before it) and ends
+                    // with the line that holds its last (up to three variables of the next run: bits of the next block, or x, T,
+                    // bits of the next item); a bit pass keeps to the whole lines in between.  Only the tile's first and last line
+                    // are shared, with other workgroups.
+                    const uint32_t mis0 = (tile_mis + vitem) & 3u;  // the item's first variable, in variables into its line
+                    uint32_t ks, ke;                                // the variables the pass writes: [ks, ke) of the item
+                    if (kind == 0) {
+                        ks = b == 0 ? 0 : kfirst;
+                        if (it != 0 || b != 0) ks += (4u - ((mis0 + ks) & 3u)) & 3u;  // (the tile's first line: from where the tile starts)
+                        ke = kfirst + 256;
+                        ke -= (mis0 + ke) & 3u;
+                    } else {
+                        ks = kfirst - ((mis0 + kfirst) & 3u);
+                        ke = b + 1 < GD::kBlocks ? GD::region_k(A, R, b + 1, 1) : vend - vitem;
+                        if (it + 1 != Wt || b + 1 < GD::kBlocks) ke += (4u - ((mis0 + ke) & 3u)) & 3u;  // (the tile's last: to where it ends)
+                    }
                     const uint32_t h_end = (count - 1) >> 7;  // the half that holds the run's end
-                    uint32_t hole = ~0u;                      // the neighbour the pre-pass has written in place (z), if any
+                    uint32_t hole = ~0u;                      // the variable the pre-pass has written in place (z), if any
                     if (!inv_here)
-                        for (uint32_t j = 0; j < post; j++)
-                            if (GD::is_inv_slot(A, R, kfirst + count + j)) hole = j;
+                        for (uint32_t k = kfirst + count; k < ke && k < vend - vitem; k++)
+                            if (GD::is_inv_slot(A, R, k)) hole = k;
                     FrVec v[4];
                     const uint32_t i0 = 4 * lane;
                     if (kind == 0) {  // range.rs:128-131
@@ -512,20 +527,22 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                             }
                         }
                     }
-                    // the neighbours' values: lanes 0 .. pre + post - 1 (records in the LDS; arithmetic only for A_256)
+                    // the variables of the pass outside its run: lanes 0 .. npre + npost - 1 (records in the LDS; no arithmetic
+                    // but for A_256)
+                    const uint32_t npre = ks < kfirst ? kfirst - ks : 0, npost = ke > kfirst + count ? ke - (kfirst + count) : 0;
                     FrVec nb;
-                    uint32_t nb_at = ~0u;  // where the lane's neighbour goes in the stage (units; ~0: the lane has none)
-                    if (lane < pre + post) {
-                        const uint32_t k = lane < pre ? lane : kfirst + count + (lane - pre);
-                        nb.f = GD::var_value(A, R, s_table, k);
-                        nb_at = lane < pre ? kRegionLead - 2 * pre + 2 * lane
-                                           : kRegionLead + 2 * (count - 128 * h_end) + 2 * (lane - pre);
+                    uint32_t nb_at = ~0u;  // where the lane's goes in the stage (units; ~0: the lane has none)
+                    if (lane < npre + npost) {
+                        const uint32_t k = lane < npre ? ks + lane : kfirst + count + (lane - npre);
+                        const uint32_t vitem_n = vend - vitem;  // past the item's last variable: the next item's first ones
+                        nb.f = k < vitem_n ? GD::var_value(A, R, s_table, k) : GD::var_value(A, s_item[it + 1], s_table, k - vitem_n);
+                        nb_at = kRegionLead + 2 * (k - kfirst) - (lane < npre ? 0 : 256 * h_end);
                     }
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
-                        // the stage holds the half's 256 units of 16 bytes from unit kRegionLead on, the neighbours before and
-                        // after them; unit u lives at wp[u + u / 8]: the lanes of a 16-lane group, 128 bytes apart, then write 16
-                        // different 16-byte columns of the LDS
+                        // the stage holds the half's 256 units of 16 bytes from unit kRegionLead on, the other variables before
+                        // and after them; unit u lives at wp[u + u / 8]: the lanes of a 16-lane group, 128 bytes apart, then write
+                        // 16 different 16-byte columns of the LDS
                         if ((lane >> 5) == (uint32_t)h) {
                             const uint32_t u0 = kRegionLead + 8 * (lane & 31), w0 = u0 + (u0 >> 3);
 #pragma unroll
@@ -534,26 +551,32 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
                                 wp[w0 + 2 * t + 1] = v[t].v[1];
                             }
                         }
-                        const uint32_t pre_u = h == 0 ? 2 * pre : 0, post_u = (uint32_t)h == h_end ? 2 * post : 0;
-                        if (nb_at != ~0u && (lane < pre ? h == 0 : (uint32_t)h == h_end)) {
+                        if (h == 1 && lane == 31) {  // the first half's last line is completed by the second: its tail, before the lead
+#pragma unroll
+                            for (int t = 0; t < 4; t++) {
+                                wp[kRegionLead - 8 + 2 * t] = v[t].v[0];
+                                wp[kRegionLead - 8 + 2 * t + 1] = v[t].v[1];
+                            }
+                        }
+                        if (nb_at != ~0u && (lane < npre ? h == 0 : (uint32_t)h == h_end)) {
                             wp[nb_at + (nb_at >> 3)] = nb.v[0];
                             wp[nb_at + 1 + ((nb_at + 1) >> 3)] = nb.v[1];
                         }
                         // (wave-private, and the LDS runs a wave's instructions in order: the reads below see the other lanes'
                         // writes, the next half's writes come after these reads -- the compiler must only keep the order)
                         asm volatile("" ::: "memory");
-                        const uint32_t done = 128 * h;
-                        const uint32_t valid = count > done ? 2 * (count - done < 128 ? count - done : 128) : 0;  // the run's units in this half
-                        const uint32_t total = valid ? pre_u + valid + post_u : 0;
-                        const uint32_t holev = ((uint32_t)h == h_end && hole != ~0u) ? (pre_u + valid) / 2 + hole : ~0u;
-                        uint4 *dst = O.vars + ((uint64_t)var0 + vitem + kfirst + done) * 2 - pre_u;
+                        // the half's variables [lo, hi) of the item
+                        const uint32_t mid = kfirst + 128 - ((mis0 + kfirst + 128) & 3u);  // (the halves meet on a line boundary)
+                        const uint32_t lo = h == 0 ? ks : mid, hi = (uint32_t)h == h_end ? ke : (h == 0 ? mid : lo);
+                        const uint32_t total = hi > lo ? 2 * (hi - lo) : 0;
+                        uint4 *dst = O.vars + ((uint64_t)var0 + vitem + lo) * 2;
                         const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(dst) >> 4) & 7u);  // units into its line
-                        const uint32_t lead = kRegionLead - pre_u;
+                        const uint32_t lead = kRegionLead + 2 * (lo - kfirst) - 256 * h;  // (lo < kfirst: below the lead, never below 0)
 #pragma unroll
                         for (int j = 0; j < 5; j++) {
                             const uint32_t g = 64 * j + lane - mis;  // (wraps below zero for the lanes before the first unit)
                             const uint32_t u = g + lead;
-                            if (g < total && (g >> 1) != holev) store16(dst + g, wp[u + (u >> 3)]);
+                            if (g < total && lo + (g >> 1) != hole) store16(dst + g, wp[u + (u >> 3)]);
                         }
                         asm volatile("" ::: "memory");
                     }
