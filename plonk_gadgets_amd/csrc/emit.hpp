@@ -56,6 +56,15 @@ struct EmitOut {
     uint32_t inv_in_place;
 };
 
+// the inverse of element s of the call, from the pre-pass's dense output into an item record (16-byte halves straight into
+// the record: a copy through an Fr temporary goes through private memory).  Unconditional -- beside a running pre-pass
+// (inv_in_place) the bytes are readable and not used
+__device__ __forceinline__ void fetch_inverse(const EmitOut &O, uint64_t s, void *rec_fr) {
+    uint4 *z = reinterpret_cast<uint4 *>(rec_fr);
+    z[0] = O.inv_dense[s];
+    z[1] = O.inv_dense[O.inv_elems + s];
+}
+
 // constant-table slots every gadget shares
 enum : uint32_t { T_ZERO = 0, T_ONE = 1, T_NEG1 = 2, T_QC_A = 3, T_QC_B = 4, T_POW = 8 };
 constexpr int kTableEntries = 8 + 256;
@@ -151,7 +160,13 @@ __device__ __forceinline__ uint32_t find_item(const uint32_t *off, uint32_t Wt, 
 //   void selectors(A, rec, j, table, h, uint4 out[5])
 //   void wires(A, O, rec, item, item_var_base, j, uint64_t out[3])
 //   Fr   var_value(A, rec, table, k)
-//   bool is_inv_slot(A, rec, k)          item-variable k holds an inverse (written by the pre-pass, not here)
+//   bool is_inv_slot(A, rec, k)          item-variable k holds an inverse: the pre-pass's, written in place and skipped here,
+//                                        unless the call's inverses are in the records (kInvDense and !O.inv_in_place)
+//   kInvDense                            optional: item() fetches the item's inverses from the pre-pass's dense output
+//                                        (EmitOut::inv_dense) and var_value returns them
+//   kRegionVars / kBlocks / region_n / region_block / region_k
+//                                        optional: the item's variables as runs of bits and accumulators of bound blocks --
+//                                        the witness refresh sweeps them by region (emit_kernel<GD, EMIT_VALUES>)
 //   kSplit / RowRec / kRowsW             optional: the rows are written by launches of their own (EmitMode, below)
 //   kPeriodic                            optional: the rows of full-shape tiles by rows_periodic_kernel (below)
 //   int  kInv; inv_operands / inv_combine / inv_slot                        the pre-pass's view (invert.hpp)
@@ -213,17 +228,6 @@ template <class GD>
 struct Split<GD, std::void_t<decltype(GD::kSplit)>> {
     static constexpr bool ok = GD::kSplit;
 };
-// kPairVars (optional, gadgets with a ladder): the variable sweep gives every lane TWO consecutive variables, the second
-// derived from the first where GD::var_next knows a shortcut (the accumulators: one modular addition instead of a Montgomery
-// multiplication), and goes through a wave-private LDS transpose so that every wave store is one contiguous KiB
-template <class GD, class = void>
-struct PairVars {
-    static constexpr bool ok = false;
-};
-template <class GD>
-struct PairVars<GD, std::void_t<decltype(GD::kPairVars)>> {
-    static constexpr bool ok = GD::kPairVars;
-};
 // kRegionVars (optional, gadgets made of ladder blocks): in a witness refresh the variable sweep goes by REGION -- a wave-pass
 // is the 256 bit variables or the n + 1 accumulators of one block of one item, four consecutive ones per lane -- see the sweep
 template <class GD, class = void>
@@ -234,6 +238,7 @@ template <class GD>
 struct RegionVars<GD, std::void_t<decltype(GD::kRegionVars)>> {
     static constexpr bool ok = GD::kRegionVars;
 };
+// kInvDense (optional): the gadget's item phase can take the call's inverses from the pre-pass's dense output (EmitOut::inv_dense)
 template <class GD, class = void>
 struct InvDense {
     static constexpr bool ok = false;
@@ -260,7 +265,8 @@ constexpr uint32_t kRegionLead = 8, kRegionStage = (kRegionLead + 256 + 16) / 8 
 
 // Nothing an EMIT_ALL launch writes depends on a field inversion: the variables that hold inverses (z of maybe_equal,
 // inv of is_non_zero) are written, at their final slots, by the inversion pre-pass (invert.hpp), which runs
-// concurrently on the engine's side stream; the variable sweep here skips exactly those slots (GD::is_inv_slot).
+// concurrently on the engine's side stream; the variable sweep here skips exactly those slots (GD::is_inv_slot) -- or,
+// in a big call, ahead of this launch, which then writes them itself (EmitOut::inv_in_place).
 template <class GD, int MODE = EMIT_ALL>
 __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(const typename GD::Args A, const EmitOut O) {
     static_assert(MODE != EMIT_STRUCTURE || !(GD::kRagged || GD::kRecInRows), "rows of this gadget depend on its inputs");

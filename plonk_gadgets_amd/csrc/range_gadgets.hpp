@@ -34,12 +34,8 @@ struct alignas(16) BoundRec {
                // in the scratch array (!EmitOut::inv_in_place), else not used
 };
 
-// z of element s of the call, from the pre-pass's dense output (unconditionally: beside a running pre-pass the bytes are not used)
-__device__ __forceinline__ void bound_fetch_z(const EmitOut &O, uint64_t s, BoundRec &b) {
-    uint4 *z = reinterpret_cast<uint4 *>(&b.UZ[1]);  // (16-byte halves straight into the record: a copy through an Fr temporary
-    z[0] = O.inv_dense[s];                           // goes through private memory here)
-    z[1] = O.inv_dense[O.inv_elems + s];
-}
+// z of element s of the call, from the pre-pass's dense output
+__device__ __forceinline__ void bound_fetch_z(const EmitOut &O, uint64_t s, BoundRec &b) { fetch_inverse(O, s, &b.UZ[1]); }
 
 // u = accumulator - witness (scalar.rs:121) of a bound block: A_n - T with A_n = mont(T mod 2^n); 0 when T fits n bits
 __device__ __forceinline__ Fr bound_u(const Fr &Tm, const Fr &Tc, uint32_t n) {
@@ -129,24 +125,6 @@ __device__ __forceinline__ Fr bound_var_value(const BoundRec &B, uint32_t y, uin
         return v.f;
     }
     return y ? fr_one() : fr_zero();  // scalar.rs:126
-}
-
-// block variable kk from block variable kk - 1, when that is cheaper than bound_var_value: the ladder's accumulators differ by
-// one term, A_{i+1} = A_i + b_i mont(2^i) (exactly the reference's own update, range.rs:152; every value fully reduced, so
-// the limbs equal mont(T mod 2^(i+1)) computed from scratch) -- a modular addition of a table entry instead of a Montgomery
-// multiplication.  false: no shortcut for this kk.
-__device__ __forceinline__ bool bound_var_next(const BoundRec &B, uint32_t kk, uint32_t n, const uint4 *table, const Fr &prev, Fr &out) {
-    if (kk < 258 || kk > 257 + n) return false;
-    const uint32_t i = kk - 258;  // prev = A_i
-    if (raw_bit(B.Tc, i)) {
-        FrVec p;
-        p.v[0] = table[2 * (T_POW + i)];
-        p.v[1] = table[2 * (T_POW + i) + 1];
-        out = fr_add(prev, p.f);
-    } else {
-        out = prev;
-    }
-    return true;
 }
 
 __device__ __forceinline__ void ids_to_values(const uint32_t id[5], const uint4 *table, uint32_t h, uint4 out[5]) {
@@ -272,19 +250,6 @@ struct RangeCheckGD {
         uint32_t kk = k, blk = 0;
         if (kk >= VB) { kk -= VB; blk = 1; }
         return bound_var_value(R.b[blk], R.y[blk], kk, n);
-    }
-    // the paired variable sweep (emit.hpp): variable k of the item from variable k - 1
-    static constexpr bool kPairVars = true;
-    __device__ static bool var_next(const Args &A, const ItemRec &R, const uint4 *table, uint32_t k, const Fr &prev, Fr &out) {
-        const uint32_t n = A.n, VB = n + 261;
-        if (!A.witness_vars) {
-            if (k == 0) return false;
-            k -= 1;
-        }
-        if (k >= 2 * VB) return false;
-        uint32_t kk = k, blk = 0;
-        if (kk >= VB) { kk -= VB; blk = 1; }
-        return bound_var_next(R.b[blk], kk, n, table, prev, out);
     }
     // the region sweep of a witness refresh (emit.hpp): blocks, and where their variables lie in the item
     // ([x] | T bits accumulators U z y | T bits accumulators U z y | R; z is the pre-pass's)
@@ -429,14 +394,6 @@ struct MaxBoundGD {
         }
         return bound_var_value(R.b, R.y, k, RAGGED ? R.n : A.n);
     }
-    static constexpr bool kPairVars = true;
-    __device__ static bool var_next(const Args &A, const ItemRec &R, const uint4 *table, uint32_t k, const Fr &prev, Fr &out) {
-        if (xo(A)) {
-            if (k == 0) return false;
-            k -= 1;
-        }
-        return bound_var_next(R.b, k, RAGGED ? R.n : A.n, table, prev, out);
-    }
     static constexpr bool kRegionVars = true;
     static constexpr uint32_t kBlocks = 1;
     __device__ static uint32_t region_n(const Args &A, const ItemRec &R) { return RAGGED ? R.n : A.n; }
@@ -512,10 +469,6 @@ struct DecompositionGD {
     __device__ static bool is_inv_slot(const Args &A, const ItemRec &, uint32_t k) { return k + 1 == bound_z_offset(A.n); }
     __device__ static Fr var_value(const Args &A, const ItemRec &R, const uint4 *, uint32_t k) {
         return bound_var_value(R.b, R.y, k + 1, A.n);
-    }
-    static constexpr bool kPairVars = true;
-    __device__ static bool var_next(const Args &A, const ItemRec &R, const uint4 *table, uint32_t k, const Fr &prev, Fr &out) {
-        return bound_var_next(R.b, k + 1, A.n, table, prev, out);
     }
     static constexpr bool kRegionVars = true;
     static constexpr uint32_t kBlocks = 1;

@@ -153,9 +153,10 @@ struct SelectOneGD {
 // ---- maybe_equal ----------------------------------------------------------------
 struct MaybeEqualGD {
     using Args = ScalarArgs;
-    struct alignas(16) ItemRec { Fr u; };
+    struct alignas(16) ItemRec { Fr u, z; };  // (z: when the pre-pass has left the call's inverses dense, EmitOut::inv_in_place)
     static constexpr int W = 256;
     static constexpr int kInv = 1;
+    static constexpr bool kInvDense = true;
     static constexpr int kInvGroup = PG_INV_GRP;
     __device__ static void inv_operands(const Args &A, const EmitOut &, uint64_t item, uint32_t, FrVec &p, FrVec &q, uint32_t &) {
         p.f = load_fr(A.a_val, item);
@@ -170,6 +171,7 @@ struct MaybeEqualGD {
     __device__ static uint32_t vars_per_item(const Args &) { return 3; }
     __device__ static void fill_table(const Args &, uint4 *, uint32_t) {}
     __device__ static void item(const Args &A, const EmitOut &O, uint64_t item, const uint4 *, ItemRec &R) {
+        fetch_inverse(O, item, &R.z);
         R.u = fr_sub(load_fr(A.a_val, item), load_fr(A.b_val, item));
         if (A.result_vars) A.result_vars[item] = O.var_base + item * 3 + 2;
     }
@@ -186,16 +188,18 @@ struct MaybeEqualGD {
     }
     __device__ static Fr var_value(const Args &, const ItemRec &R, const uint4 *, uint32_t k) {
         if (k == 0) return R.u;
-        return fr_is_zero(R.u) ? fr_one() : fr_zero();  // k == 2 (k == 1 is z: the pre-pass's)
+        if (k == 1) return R.z;                         // (asked for only when the record holds it)
+        return fr_is_zero(R.u) ? fr_one() : fr_zero();  // scalar.rs:126
     }
 };
 
 // ---- is_non_zero (ragged: an item whose value is 0 stops after 1 row / 1 variable) ----------
 struct IsNonZeroGD {
     using Args = ScalarArgs;
-    struct alignas(16) ItemRec { Fr value; };
+    struct alignas(16) ItemRec { Fr value, inv; };  // (inv: when the pre-pass has left the call's inverses dense)
     static constexpr int W = 256;
     static constexpr int kInv = 1;
+    static constexpr bool kInvDense = true;
     static constexpr int kInvGroup = PG_INV_GRP;
     __device__ static void inv_operands(const Args &A, const EmitOut &, uint64_t item, uint32_t, FrVec &p, FrVec &q, uint32_t &) {
         p.f = load_fr(A.b_val, item);  // scalar.rs:73
@@ -212,7 +216,8 @@ struct IsNonZeroGD {
     static constexpr uint32_t kUniformRows = 3, kUniformVars = 3;  // an item whose value is not 0
     __device__ static void fill_table(const Args &, uint4 *, uint32_t) {}
     __device__ static void item_rows(const Args &, const EmitOut &, uint64_t, const uint4 *, ItemRec &) {}
-    __device__ static void item(const Args &A, const EmitOut &, uint64_t item, const uint4 *, ItemRec &R) {
+    __device__ static void item(const Args &A, const EmitOut &O, uint64_t item, const uint4 *, ItemRec &R) {
+        fetch_inverse(O, item, &R.inv);
         R.value = load_fr(A.b_val, item);
     }
     __device__ static void selectors(const Args &, const ItemRec &, uint32_t j, const uint4 *table, uint32_t h, uint4 out[5]) {
@@ -228,7 +233,8 @@ struct IsNonZeroGD {
     }
     __device__ static Fr var_value(const Args &, const ItemRec &R, const uint4 *, uint32_t k) {
         if (k == 0) return R.value;
-        return fr_one();  // k == 2 (k == 1 is inv: the pre-pass's)
+        if (k == 1) return R.inv;  // (asked for only when the record holds it)
+        return fr_one();
     }
 };
 

@@ -368,6 +368,56 @@ def run_values(log2_chunk=20, rounds=6):
                           "gbps_median": nbytes / ts[len(ts) // 2] / 1e6}))
 
 
+def run_maybe_equal(log2_chunk=22, rounds=6):
+    """pg_maybe_equal_batch: 3 rows + 3 variables per item (648 B), one inverse per item"""
+    import numpy as np
+    import torch
+    from plonk_gadgets_amd import _lib, synth
+    import plonk_gadgets_amd as pg
+    dev = torch.device("cuda", 0)
+    chunk = 1 << log2_chunk
+    a = torch.from_numpy(synth.random_scalars(chunk, seed=1).view(np.int64)).to(dev)
+    b = torch.from_numpy(synth.random_scalars(chunk, seed=2).view(np.int64)).to(dev)
+    av = torch.arange(chunk, dtype=torch.int64, device=dev)
+    bv = av + chunk
+    cols = pg.Columns.allocate(chunk * 3, chunk * 3, dev)
+    res = torch.empty((chunk,), dtype=torch.int64, device=dev)
+    cc = cols.as_c()
+    stream = torch.cuda.current_stream(dev)
+    libs = {}
+    for name in VARIANTS:
+        path = os.path.join(VDIR, f"lib_{name}.so")
+        if not os.path.exists(path):
+            continue
+        lib = C.CDLL(path)
+        for fn, (r, ar) in _lib.SIGNATURES.items():
+            if hasattr(lib, fn):
+                f = getattr(lib, fn)
+                f.restype, f.argtypes = r, ar
+        h = C.c_void_p()
+        assert lib.pg_engine_create(0, C.byref(h)) == 0
+        libs[name] = (lib, h)
+    times = {n: [] for n in libs}
+    nbytes = chunk * 3 * (184 + 32)
+    for r in range(rounds + 1):
+        order = list(libs.items())
+        order = order[r % len(order):] + order[:r % len(order)]
+        for name, (lib, h) in order:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            st = lib.pg_maybe_equal_batch(h, av.data_ptr(), a.data_ptr(), bv.data_ptr(), b.data_ptr(), chunk, 3, 5, C.byref(cc),
+                                          res.data_ptr(), C.c_void_p(stream.cuda_stream))
+            assert st == 0
+            e1.record(stream)
+            torch.cuda.synchronize()
+            if r:
+                times[name].append(e0.elapsed_time(e1))
+    for name, ts in times.items():
+        ts = sorted(ts)
+        print(json.dumps({"variant": name, "flags": VARIANTS[name], "median_ms": ts[len(ts) // 2], "min_ms": ts[0],
+                          "gbps_median": nbytes / ts[len(ts) // 2] / 1e6}))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build(sys.argv[2:])
@@ -377,6 +427,8 @@ if __name__ == "__main__":
         run_c4(*(int(x) for x in sys.argv[2:]))
     elif sys.argv[1] == "run_c3_b2b":
         run_c3_b2b(*(int(x) for x in sys.argv[2:]))
+    elif sys.argv[1] == "run_maybe_equal":
+        run_maybe_equal(*(int(x) for x in sys.argv[2:]))
     elif sys.argv[1] == "run_values":
         run_values(*(int(x) for x in sys.argv[2:]))
     else:
