@@ -322,11 +322,57 @@ class Workload:
         self.launch = self.cols = self.res = None
 
 
+def hip_runtime():
+    """the HIP runtime this process already has (torch's, which the library binds to as well: the loader returns the loaded
+    object for the soname)"""
+    import ctypes as C
+    import torch  # noqa: F401
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+    hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+    hip.hipEventSynchronize.argtypes = [C.c_void_p]
+    hip.hipEventDestroy.argtypes = [C.c_void_p]
+    return hip
+
+
+class TimingEvent:
+    """a HIP event that only measures time: hipEventDisableSystemFence (hip_runtime_api.h: "for events that are only being used
+    to measure timing ... avoiding the cost of cache writeback and invalidation, and the performance impact of those actions on
+    the execution of following work").  After every call of the short C3 step a default event (torch.cuda.Event) costs 4.8 us,
+    this one 3.8 (tools/event_cost.py); the timed region itself is bracketed by device synchronisation, not by events."""
+    DISABLE_SYSTEM_FENCE = 0x20000000
+
+    def __init__(self, hip):
+        import ctypes as C
+        self.hip, self.h = hip, C.c_void_p()
+        if hip.hipEventCreateWithFlags(C.byref(self.h), self.DISABLE_SYSTEM_FENCE) != 0:
+            raise RuntimeError("hipEventCreateWithFlags failed")
+
+    def record(self, stream_handle):
+        if self.hip.hipEventRecord(self.h, stream_handle) != 0:
+            raise RuntimeError("hipEventRecord failed")
+        return self
+
+    def elapsed_ms(self, later):
+        import ctypes as C
+        ms = C.c_float()
+        if self.hip.hipEventElapsedTime(C.byref(ms), self.h, later.h) != 0:
+            raise RuntimeError("hipEventElapsedTime failed")
+        return ms.value
+
+    def __del__(self):
+        if self.h:
+            self.hip.hipEventDestroy(self.h)
+
+
 def measure(wl: Workload, steps: int, warmup: int, sync_all):
     """W untimed steps, then exactly K timed steps bracketed by sync_all() (barrier + device synchronise); HIP events on
     the launch stream around every launch give the per-launch duration the roofline is computed from"""
+    import ctypes as C
     import torch
-    stream = torch.cuda.current_stream(wl.dev)
+    stream = C.c_void_p(torch.cuda.current_stream(wl.dev).cuda_stream)
+    hip = hip_runtime()
 
     def step(events=None):
         # ONE event per launch boundary (launch i runs from boundary i to boundary i + 1): an event record is a packet of its own
@@ -334,21 +380,19 @@ def measure(wl: Workload, steps: int, warmup: int, sync_all):
         for c in range(wl.n_chunks):
             wl.launch(c)
             if events is not None:
-                e = torch.cuda.Event(enable_timing=True)
-                e.record(stream)
-                events.append(e)
+                events.append(TimingEvent(hip).record(stream))
 
     for _ in range(warmup):
         step()
     sync_all()
-    events = [torch.cuda.Event(enable_timing=True)]
+    events = [TimingEvent(hip)]
     t0 = time.perf_counter()
     events[0].record(stream)
     for _ in range(steps):
         step(events)
     sync_all()
     elapsed = time.perf_counter() - t0
-    kernel_ms = [a.elapsed_time(b) for a, b in zip(events[:-1], events[1:])]
+    kernel_ms = [a.elapsed_ms(b) for a, b in zip(events[:-1], events[1:])]
     return elapsed, kernel_ms
 
 

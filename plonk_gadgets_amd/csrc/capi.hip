@@ -238,6 +238,11 @@ pg_status ensure_inv_scratch(pg_engine *e, uint64_t elems) {
     return PG_OK;
 }
 
+// the engine's events order streams of ONE device against each other and are never waited for by the host: without the
+// system-scope fence a default event performs when it completes (cache write-back and invalidation: microseconds on the
+// stream, after every call)
+constexpr unsigned kOrderingEvent = hipEventDisableTiming | hipEventDisableSystemFence;
+
 // The engine's scratch (plan counts, pre-pass products, the pinned plan result) is shared by consecutive calls and is
 // ordered only by the stream they are issued on.  A caller that moves to ANOTHER stream is made to wait for everything
 // the engine still has in flight on the previous one (and on the side stream, which joins it): every call records, when
@@ -490,9 +495,9 @@ pg_status pg_engine_create(int device, pg_engine **out) {
     prio_hi = 0;
 #endif
     if (hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_inv, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_switch, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&e->ev_fork, kOrderingEvent) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_inv, kOrderingEvent) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_switch, kOrderingEvent) != hipSuccess) {
         pg_engine_destroy(e);
         return fail(PG_ERR_HIP, "creating the engine's side stream / events failed");
     }
