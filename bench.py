@@ -278,7 +278,11 @@ class Workload:
             lay, nerr = eng.scalar_mix_plan(ins[0][:chunk], roff, voff)
             assert nerr == 0 and (lay.n_gates, lay.n_vars) == (10 * chunk, 15 * chunk)
             self.rows_per_launch, self.vars_per_launch = lay.n_gates, lay.n_vars
-            cols = pg.Columns.allocate(lay.n_gates, lay.n_vars, dev)
+            # a circuit of 2.4 GB: its five selector columns, written in lock step, go 26 GiB apart in one slab (where nine
+            # allocations in a row happen to land decides 0.51 ... 0.59 ms per step otherwise: DESIGN.md section 2,
+            # tools/c3_instances.py, tools/placement_sweep.py); PG_BENCH_SPREAD_GIB=0 allocates them one after the other
+            self.spread_gib = float(os.environ.get("PG_BENCH_SPREAD_GIB", "26"))
+            cols = pg.Columns.allocate(lay.n_gates, lay.n_vars, dev, spread_gib=self.spread_gib)
             res = torch.empty((chunk, 2), dtype=torch.int64, device=dev)
             self.read_bytes = chunk * 160
 
@@ -587,6 +591,8 @@ def main():
     config = {"workload": wl.desc, "items_per_gpu": wl.batch, "items_per_launch": wl.chunk,
               "launches_per_step": wl.n_chunks,
               "sharding": "contiguous witness ranges per rank at global numbering, no data-path collective"}
+    if getattr(wl, "spread_gib", 0):
+        config["column_layout"] = "one slab, selector columns %g GiB apart" % wl.spread_gib
     wit = getattr(wl, "wit", None)
     mn, mx = getattr(wl, "mn", None), getattr(wl, "mx", None)
     wl.release()
@@ -604,7 +610,9 @@ def main():
                                              "constraints whose witnesses are refreshed /sec (range_check 256-bit, values only)",
                                    "value": w2.rows_per_launch * w2.n_chunks * args.steps / el2, "unit": "constraints/s",
                                    "ms_per_step": el2 / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
-                                   "config": {"workload": w2.desc, "items_per_gpu": w2.batch, "items_per_launch": w2.chunk},
+                                   "config": {"workload": w2.desc, "items_per_gpu": w2.batch, "items_per_launch": w2.chunk,
+                                              **({"column_layout": "one slab, selector columns %g GiB apart" % w2.spread_gib}
+                                                 if getattr(w2, "spread_gib", 0) else {})},
                                    "roofline": roofline_of(w2, ms2)}
                 w2.release()
                 del w2

@@ -38,11 +38,15 @@ def main(instances=6, steps=8, slab=0):
             sizes = [G * 32] * 5 + [G * 8] * 3 + [V * 32]
             al = 2 << 20
             sizes_al = [(x + al - 1) // al * al for x in sizes]
-            buf = torch.empty((sum(sizes_al),), dtype=torch.uint8, device=dev)
-            ptrs, off = [], 0
-            for x in sizes_al:
-                ptrs.append(buf.data_ptr() + off)
-                off += x
+            total = sum(sizes_al) if slab == 1 else slab << 30  # slab > 1: a slab of that many GiB, the arrays spread evenly over it
+            gap = (total - sum(sizes_al)) // 8 // al * al
+            # order: the five lock-step selector streams alternate with the wires and the variable table
+            order = [0, 5, 1, 6, 2, 7, 3, 8, 4] if slab > 1 else list(range(9))
+            buf = torch.empty((total,), dtype=torch.uint8, device=dev)
+            ptrs, off = [0] * 9, (-buf.data_ptr()) % al
+            for k in order:
+                ptrs[k] = buf.data_ptr() + off
+                off += sizes_al[k] + gap
             cc = _lib.ColumnsC(*ptrs)
             keep = buf
         else:
