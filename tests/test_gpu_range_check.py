@@ -187,6 +187,36 @@ def test_misaligned_wire_columns(engine):
     assert int(big.w_r[0]) == -1 and int(big.w_r[1]) == -1
 
 
+def test_columns_in_one_spread_slab(engine):
+    """Columns.allocate(spread_gib=...): nine views of ONE allocation, the selector columns a stride apart -- disjoint, inside
+    the slab, 16-byte aligned; a call that writes into them == the oracle, and the slab between the arrays keeps its fill"""
+    import plonk_gadgets_amd as pg
+    from oracle import pyoracle as po
+    mn, mx = 0, 2**64
+    wit = mixed_witnesses(mn, mx, 21, seed=91)
+    ora = po.range_check_batch(synth.mont(mn), synth.mont(mx), wit)
+    lay = engine.range_check_layout(pg.BlsScalar.from_int(mn), pg.BlsScalar.from_int(mx), len(wit))
+    cols = pg.Columns.allocate(lay.n_gates, lay.n_vars, "cuda:0", spread_gib=0.03)
+    names = SCALAR_COLS[:5] + WIRE_COLS + ("var_values",)
+    lo, hi = cols.slab.data_ptr(), cols.slab.data_ptr() + cols.slab.numel() * 8
+    iv = sorted((getattr(cols, n).data_ptr(), getattr(cols, n).data_ptr() + getattr(cols, n).numel() * 8) for n in names)
+    assert iv[0][0] >= lo and iv[-1][1] <= hi and all(a1 <= b0 for (_, a1), (b0, _) in zip(iv, iv[1:]))
+    assert all(getattr(cols, n).data_ptr() % 16 == 0 for n in names)
+    sel = sorted(getattr(cols, n).data_ptr() for n in SCALAR_COLS[:5])
+    assert all(b - a >= int(0.03 * 2**30) - (2 << 20) for a, b in zip(sel, sel[1:]))
+    cols.slab.fill_(0x5A5A5A5A5A5A5A5A)
+    w = torch.from_numpy(wit.view(np.int64)).to("cuda:0")
+    engine.range_check_batch(pg.BlsScalar.from_int(mn), pg.BlsScalar.from_int(mx), w, 3, 5, out=cols)
+    torch.cuda.synchronize()
+    got = cols.to_numpy()
+    for k in SCALAR_COLS + WIRE_COLS:
+        assert np.array_equal(got[k], ora[k]), k
+    mask = torch.ones_like(cols.slab, dtype=torch.bool)
+    for a, b in iv:
+        mask[(a - lo) // 8:(b - lo) // 8] = False
+    assert bool((cols.slab[mask] == 0x5A5A5A5A5A5A5A5A).all())
+
+
 def test_config_c1_exact(engine):
     """BASELINE config 1: 1 000 x range_check(v, "64-bit") -- min = 0, max = 2^64 (n = 65, 271 rows per witness),
     witnesses uniform in [0, 2^64 + 2^60) (about 6 % out of range): every limb vs the CPU oracle."""
