@@ -278,10 +278,10 @@ class Workload:
             lay, nerr = eng.scalar_mix_plan(ins[0][:chunk], roff, voff)
             assert nerr == 0 and (lay.n_gates, lay.n_vars) == (10 * chunk, 15 * chunk)
             self.rows_per_launch, self.vars_per_launch = lay.n_gates, lay.n_vars
-            # a circuit of 2.4 GB: its five selector columns, written in lock step, go 26 GiB apart in one slab (where nine
+            # a circuit of 2.4 GB: its five selector columns, written in lock step, go 24 GiB apart in one slab (where nine
             # allocations in a row happen to land decides 0.51 ... 0.59 ms per step otherwise: DESIGN.md section 2,
             # tools/c3_instances.py, tools/placement_sweep.py); PG_BENCH_SPREAD_GIB=0 allocates them one after the other
-            self.spread_gib = float(os.environ.get("PG_BENCH_SPREAD_GIB", "26"))
+            self.spread_gib = float(os.environ.get("PG_BENCH_SPREAD_GIB", "24"))
             cols = pg.Columns.allocate(lay.n_gates, lay.n_vars, dev, spread_gib=self.spread_gib)
             res = torch.empty((chunk, 2), dtype=torch.int64, device=dev)
             self.read_bytes = chunk * 160

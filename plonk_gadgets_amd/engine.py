@@ -54,11 +54,11 @@ class Columns:
     @staticmethod
     def allocate(n_gates: int, n_vars: int, device, gate_base: int = 0, var_base: int = 0, spread_gib: float = 0) -> "Columns":
         """spread_gib = 0: nine allocations, one after the other.
-        spread_gib > 0: ONE allocation, the five selector columns spread_gib GiB apart with a wire column or the variable
-        table half way between each two.  The emitters write the same row of all five selector columns at once; on MI355X five such streams
+        spread_gib > 0: ONE allocation, the five selector columns spread_gib GiB apart, the wire columns and the variable
+        table behind the last.  The emitters write the same row of all five selector columns at once; on MI355X five such streams
         inside one stretch of a few GiB of physical memory run 10-15 % slower than five streams tens of GiB apart (the 12-high
         stacks' ranks lie one after the other in the address space: streams in one rank share its banks).  A circuit of a few
-        GB therefore does better in a slab that spans much of the card (C3: 0.575 -> 0.50 ms per step with the columns 24 GiB
+        GB therefore does better in a slab that spans much of the card (C3: 0.575 -> 0.50 ms per step with the columns 16 GiB
         and more apart, tools/placement_sweep.py); columns of tens of GB each lie that far apart anyway.  The memory between the
         arrays belongs to the slab: the caller's to use for whatever else it streams (Columns.slab), or the price of the layout."""
         if spread_gib <= 0:
@@ -69,14 +69,15 @@ class Columns:
         align = 2 << 20
         up = lambda x: (x + align - 1) // align * align
         ssz, wsz, vsz = up(n_gates * 32), up(n_gates * 8), up(n_vars * 32)
-        # order in the slab, half a stride apart: q_m w_l q_l w_r q_r w_o q_o var_values q_c
-        half = max(up(int(spread_gib * (1 << 30))) // 2 // align * align, ssz, wsz, vsz)
-        slab = torch.empty(((8 * half + ssz + align) // 8,), dtype=torch.int64, device=device)
+        # q_m q_l q_r q_o q_c a stride apart, then w_l w_r w_o var_values back to back behind q_c (of the layouts measured --
+        # the others between the selector columns, before them, a stride apart themselves -- the best: tools/placement_policy.py)
+        stride = max(up(int(spread_gib * (1 << 30))), ssz)
+        slab = torch.empty(((4 * stride + ssz + 3 * wsz + vsz + align) // 8,), dtype=torch.int64, device=device)
         first = ((-slab.data_ptr()) % align) // 8
-        at = [first + k * half // 8 for k in range(9)]
-        sel = [slab[at[2 * c]:at[2 * c] + n_gates * 4].view(n_gates, 4) for c in range(5)]
-        wc = [slab[at[2 * c + 1]:at[2 * c + 1] + n_gates] for c in range(3)]
-        vv = slab[at[7]:at[7] + n_vars * 4].view(n_vars, 4)
+        sel = [slab[first + c * stride // 8:first + c * stride // 8 + n_gates * 4].view(n_gates, 4) for c in range(5)]
+        tail = first + (4 * stride + ssz) // 8
+        wc = [slab[tail + c * wsz // 8:tail + c * wsz // 8 + n_gates] for c in range(3)]
+        vv = slab[tail + 3 * wsz // 8:tail + 3 * wsz // 8 + n_vars * 4].view(n_vars, 4)
         cols = Columns(*sel, *wc, vv, gate_base, var_base)
         cols.slab = slab
         return cols

@@ -60,15 +60,35 @@ def main(trials=4, steps=10):
         torch.cuda.empty_cache()
         return pg.Columns(*arrs)
 
-    out = {"A separate": [], "B slab 20 GiB stride": [], "B slab 26 GiB stride": [], "B slab 32 GiB stride": [], "B slab 44 GiB stride": []}
+    def slab_layout(slots_gib):
+        """nine arrays in one slab at the given GiB offsets (q_m q_l q_r q_o q_c w_l w_r w_o var_values)"""
+        sizes = [G * 32] * 5 + [G * 8] * 3 + [V * 32]
+        al = 2 << 20
+        total = int(max(o * GiB + n for o, n in zip(slots_gib, sizes))) + 2 * al
+        slab = torch.empty((total // 8,), dtype=torch.int64, device=dev)
+        first = ((-slab.data_ptr()) % al) // 8
+        at = [first + int(o * GiB) // al * al // 8 for o in slots_gib]
+        iv = sorted((a, a + n // 8) for a, n in zip(at, sizes))
+        assert all(a1 <= b0 for (_, a1), (b0, _) in zip(iv, iv[1:])) and iv[-1][1] <= slab.numel()
+        sel = [slab[at[c]:at[c] + G * 4].view(G, 4) for c in range(5)]
+        wc = [slab[at[5 + c]:at[5 + c] + G] for c in range(3)]
+        vv = slab[at[8]:at[8] + V * 4].view(V, 4)
+        cols = pg.Columns(*sel, *wc, vv)
+        cols.slab = slab
+        return cols
+
+    L = {
+        "A separate": None,
+        "B Columns.allocate(spread_gib=26)": "B",
+        "selectors 24 apart, then wires 24 apart, var_values": [0, 24, 48, 72, 96, 120, 144, 168, 176],
+        "selectors 24 apart, wires + var_values right after the last": [0, 24, 48, 72, 96, 97, 98, 99, 100],
+        "selectors 16 apart, wires 16 apart after them": [0, 16, 32, 48, 64, 80, 96, 112, 120],
+        "selectors 24 apart, wires + var_values before the first": [4, 28, 52, 76, 100, 0, 1, 2, 3],
+    }
+    out = {k: [] for k in L}
     for _ in range(trials):
-        for name in out:
-            if name.startswith("A"):
-                cols = pg.Columns.allocate(G, V, dev)
-            elif name.startswith("B"):
-                cols = pg.Columns.allocate(G, V, dev, spread_gib=int(name.split()[2]))
-            else:
-                cols = policy_c(24 if "24" in name else 12)
+        for name, spec in L.items():
+            cols = pg.Columns.allocate(G, V, dev) if spec is None else (pg.Columns.allocate(G, V, dev, spread_gib=26) if spec == "B" else slab_layout(spec))
             out[name].append(timed(cols))
             del cols
             torch.cuda.empty_cache()

@@ -58,7 +58,7 @@ def main(slab_gib=200, steps=10):
     slab = torch.empty((slab_gib * GiB,), dtype=torch.uint8, device=dev)
     base = slab.data_ptr() + (-slab.data_ptr()) % (2 * MiB)
     out = {}
-    for d in (0.33, 0.5, 1, 1.5, 2, 3, 4, 6, 8, 12, 16, 24, 32, 40):
+    for d in (() if os.environ.get("LAYOUTS_ONLY") else (0.33, 0.5, 1, 1.5, 2, 3, 4, 6, 8, 12, 16, 24, 32, 40)):
         D = int(d * GiB) // (2 * MiB) * (2 * MiB)
         if 4 * D + size > (slab_gib - 1) * GiB:
             break
@@ -67,7 +67,7 @@ def main(slab_gib=200, steps=10):
     # all seventeen arrays in the slab (inputs copied in)
     out = {}
     sizes = [chunk * 32] * 5 + [(chunk + 1) * 8] * 2 + [chunk * 16] + [size] * 5 + [10 * chunk * 8] * 3 + [15 * chunk * 32]
-    for d in (0.5, 1, 2, 3, 4, 6, 8, 11):
+    for d in (() if os.environ.get("LAYOUTS_ONLY") else (0.5, 1, 2, 3, 4, 6, 8, 11)):
         D = int(d * GiB) // (2 * MiB) * (2 * MiB)
         if 16 * D + sizes[-1] > (slab_gib - 1) * GiB or D < max(sizes):
             continue
@@ -94,6 +94,7 @@ def main(slab_gib=200, steps=10):
         "inputs apart too": [1, 4, 7, 10, 13] + near(0, 3, 0.1) + [3, 6, 9, 12, 15] + [18, 21, 23] + [22],
         "inputs 32 apart, outputs together": [0, 4, 8, 12, 16] + near(20, 12),
         "thirds: columns round robin over slots 0, 11, 22": near(0, 8, 0.05) + [0.5, 11, 22, 1, 11.5] + [22.5, 1.5, 12] + [23],
+        "selectors apart, inputs apart, rest together": [1, 5, 9, 13, 17] + near(0, 3, 0.1) + [4, 8, 12, 16, 20] + near(21, 3) + [23],
     }
     out = {k: layout(v) for k, v in L.items()}
     print(json.dumps({"layouts_ms_per_step": out}), flush=True)
