@@ -294,6 +294,11 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
         // (bijective for any tile count; speed only, nothing depends on the placement)
         const uint32_t q8 = O.tiles >> 3, r8 = O.tiles & 7, x = t & 7, k = t >> 3;
         const uint32_t tile = x * q8 + (x < r8 ? x : r8) + k;
+#elif defined(PG_TILE_SPREAD)
+        // A/B build: consecutive workgroups take tiles 1 / PG_TILE_SPREAD of the call apart (the resident workgroups then write all
+        // over the arrays instead of inside one moving window)
+        const uint32_t qs = O.tiles / PG_TILE_SPREAD, rs = O.tiles % PG_TILE_SPREAD, x = t % PG_TILE_SPREAD, k = t / PG_TILE_SPREAD;
+        const uint32_t tile = x * qs + (x < rs ? x : rs) + k;
 #else
         const uint32_t tile = t;
 #endif

@@ -13,6 +13,7 @@
      defined(PG_UNALIGNED_SWEEPS) || defined(PG_ROWS_WAVES_PER_SIMD) || defined(PG_ROWS_SETPRIO) || defined(PG_INVERT_FERMAT) || \
      defined(PG_INV_GRP) || defined(PG_RC_W) || defined(PG_MB_W) || defined(PG_MIX_VARS_VGPRS) || defined(PG_MIX_STAMPS) ||     \
      defined(PG_QUEUE_MAX) || defined(PG_PERM_LDS_PAD) || defined(PG_GRID_BLOCKS_PER_CU) || defined(PG_PLAN_TWO_LAUNCHES) ||    \
-     defined(PG_INV_LANES_PER_CU) || defined(PG_INV_MAX_PER_LANE) || defined(PG_SIDE_STREAM_NORMAL_PRIORITY) || defined(PG_VAR_SWEEP_SINGLE))
+     defined(PG_INV_LANES_PER_CU) || defined(PG_INV_MAX_PER_LANE) || defined(PG_SIDE_STREAM_NORMAL_PRIORITY) || defined(PG_VAR_SWEEP_SINGLE) || \
+     defined(PG_TILE_SPREAD))
 #error "a PG_... build option is defined without -DPG_EXPERIMENT: the shipped library is built with none of them (csrc/experiment.hpp)"
 #endif

@@ -33,6 +33,7 @@ VARIANTS = {
     "diag_coal": ["-DPG_MIX_STAMPS", "-DPG_DIAG_FWD_COALESCED"],  # timing only: the forward pass's loads as three contiguous KiB
     "diag_3ld": ["-DPG_MIX_STAMPS", "-DPG_DIAG_FWD_3LOADS"],      # timing only: without the v side's second fetch of v
     "diag_split": ["-DPG_MIX_STAMPS", "-DPG_DIAG_FWD_SPLIT"],     # stamps inside the forward loop (they disturb it: vmcnt(0) waits)
+    "spread64": ["-DPG_TILE_SPREAD=64"], "spread1024": ["-DPG_TILE_SPREAD=1024"], "spread4096": ["-DPG_TILE_SPREAD=4096"],  # tile order: consecutive workgroups far apart
     "var_single": ["-DPG_VAR_SWEEP_SINGLE"],        # the variable sweep one scalar per lane everywhere (before round 4)
     "var_pairs_always": ["-DPG_VAR_SWEEP_PAIRS_ALWAYS"],  # the paired sweep in the full emission too
     "side_normal": ["-DPG_SIDE_STREAM_NORMAL_PRIORITY"],
