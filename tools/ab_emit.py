@@ -34,6 +34,7 @@ VARIANTS = {
     "diag_3ld": ["-DPG_MIX_STAMPS", "-DPG_DIAG_FWD_3LOADS"],      # timing only: without the v side's second fetch of v
     "diag_split": ["-DPG_MIX_STAMPS", "-DPG_DIAG_FWD_SPLIT"],     # stamps inside the forward loop (they disturb it: vmcnt(0) waits)
     "spread64": ["-DPG_TILE_SPREAD=64"], "spread1024": ["-DPG_TILE_SPREAD=1024"], "spread4096": ["-DPG_TILE_SPREAD=4096"],  # tile order: consecutive workgroups far apart
+    "rc_w4": ["-DPG_RC_W=4"], "rc_w8": ["-DPG_RC_W=8"], "rc_w64": ["-DPG_RC_W=64"],  # items per tile of range_check (rc_w16 below)
     "var_single": ["-DPG_VAR_SWEEP_SINGLE"],        # the variable sweep one scalar per lane everywhere (before round 4)
     "var_pairs_always": ["-DPG_VAR_SWEEP_PAIRS_ALWAYS"],  # the paired sweep in the full emission too
     "side_normal": ["-DPG_SIDE_STREAM_NORMAL_PRIORITY"],
@@ -323,8 +324,9 @@ def run(log2_chunk=18, rounds=4, mn_int=0, mx_int=2**254):
                           "gbps_median": nbytes / ts[len(ts) // 2] / 1e6, "gbps_best": nbytes / ts[0] / 1e6}))
 
 
-def run_values(log2_chunk=20, rounds=6):
-    """the witness refresh of C2's circuit (pg_range_check_values_batch: 1034 variables per witness, no rows)"""
+def run_values(log2_chunk=20, rounds=6, tables=1):
+    """the witness refresh of C2's circuit (pg_range_check_values_batch: 1034 variables per witness, no rows); tables > 1: that many
+    tables alive together, every variant timed on each (where a table lies decides 5.6 ... 6.8 ms: NOTES_r04 section 7)"""
     import numpy as np
     import torch
     from plonk_gadgets_amd import _lib, synth
@@ -333,7 +335,7 @@ def run_values(log2_chunk=20, rounds=6):
     chunk = 1 << log2_chunk
     wit = torch.from_numpy(synth.random_scalars(chunk).view(np.int64)).to(dev)
     mn, mx = pg.BlsScalar.from_int(0), pg.BlsScalar.from_int(2**254)
-    table = torch.empty((chunk * 1034, 4), dtype=torch.int64, device=dev)
+    T = [torch.empty((chunk * 1034, 4), dtype=torch.int64, device=dev) for _ in range(tables)]
     stream = torch.cuda.current_stream(dev)
     libs = {}
     for name in VARIANTS:
@@ -348,25 +350,26 @@ def run_values(log2_chunk=20, rounds=6):
         h = C.c_void_p()
         assert lib.pg_engine_create(0, C.byref(h)) == 0
         libs[name] = (lib, h)
-    times = {n: [] for n in libs}
+    times = {n: [[] for _ in T] for n in libs}
     nbytes = chunk * 1034 * 32
     for r in range(rounds + 1):
         order = list(libs.items())
         order = order[r % len(order):] + order[:r % len(order)]
         for name, (lib, h) in order:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            st = lib.pg_range_check_values_batch(h, C.byref(mn.c), C.byref(mx.c), wit.data_ptr(), chunk, table.data_ptr(),
-                                                 C.c_void_p(stream.cuda_stream))
-            assert st == 0
-            e1.record(stream)
-            torch.cuda.synchronize()
-            if r:
-                times[name].append(e0.elapsed_time(e1))
-    for name, ts in times.items():
-        ts = sorted(ts)
-        print(json.dumps({"variant": name, "flags": VARIANTS[name], "median_ms": ts[len(ts) // 2], "min_ms": ts[0],
-                          "gbps_median": nbytes / ts[len(ts) // 2] / 1e6}))
+            for k, table in enumerate(T):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                st = lib.pg_range_check_values_batch(h, C.byref(mn.c), C.byref(mx.c), wit.data_ptr(), chunk, table.data_ptr(),
+                                                     C.c_void_p(stream.cuda_stream))
+                assert st == 0
+                e1.record(stream)
+                torch.cuda.synchronize()
+                if r:
+                    times[name][k].append(e0.elapsed_time(e1))
+    for name, per in times.items():
+        med = [sorted(ts)[len(ts) // 2] for ts in per]
+        print(json.dumps({"variant": name, "flags": VARIANTS[name], "median_ms": med[0] if tables == 1 else [round(m, 3) for m in med],
+                          "min_ms": min(per[0]), "gbps_median": nbytes / med[0] / 1e6}))
 
 
 def run_maybe_equal(log2_chunk=22, rounds=6):

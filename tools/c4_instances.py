@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/c4_instances.py [instances] [steps] [slab] -- the C4 step (2^20 ragged max_bound items, 115.8 GB) on output arrays
 allocated anew `instances` times in one process: ms per step of every instance.  slab = 1: the nine arrays carved out of ONE
-allocation instead of nine."""
+allocation instead of nine; slab = N > 1: spread evenly over a slab of N GiB; slab = -S: Columns.allocate(spread_gib=S)."""
 import ctypes as C
 import json
 import os
@@ -34,7 +34,11 @@ def main(instances=6, steps=8, slab=0):
     assert lib.pg_max_bound_ragged_plan(eng._h, mr.data_ptr(), chunk, nb.data_ptr(), roff.data_ptr(), voff.data_ptr(), C.byref(lay), sp) == 0
     G, V = int(lay.n_gates), int(lay.n_vars)
     for inst in range(instances):
-        if slab:
+        if slab < 0:  # Columns.allocate(spread_gib=-slab): selector columns that far apart, the rest behind the last
+            cols = pg.Columns.allocate(G, V, dev, spread_gib=-slab)
+            cc = cols.as_c()
+            keep = cols
+        elif slab:
             sizes = [G * 32] * 5 + [G * 8] * 3 + [V * 32]
             al = 2 << 20
             sizes_al = [(x + al - 1) // al * al for x in sizes]
@@ -69,6 +73,7 @@ def main(instances=6, steps=8, slab=0):
         print(json.dumps({"instance": inst, "slab": slab, "ms_per_step": round(ms, 3), "frac_of_8TBps": round((G * 184 + V * 32) / ms / 1e6 / 8000, 4),
                           "q_m": hex(cc.q_m or 0), "vars": hex(cc.var_values or 0)}), flush=True)
         del keep, cc
+        buf = cols = None
         torch.cuda.empty_cache()
 
 
