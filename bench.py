@@ -282,7 +282,11 @@ class Workload:
             # allocations in a row happen to land decides 0.51 ... 0.59 ms per step otherwise: DESIGN.md section 2,
             # tools/c3_instances.py, tools/placement_sweep.py); PG_BENCH_SPREAD_GIB=0 allocates them one after the other
             self.spread_gib = float(os.environ.get("PG_BENCH_SPREAD_GIB", "24"))
-            cols = pg.Columns.allocate(lay.n_gates, lay.n_vars, dev, spread_gib=self.spread_gib)
+            try:
+                cols = pg.Columns.allocate(lay.n_gates, lay.n_vars, dev, spread_gib=self.spread_gib)
+            except torch.OutOfMemoryError:  # a card that does not have the room: nine allocations, and the line says so
+                self.spread_gib = 0.0
+                cols = pg.Columns.allocate(lay.n_gates, lay.n_vars, dev)
             res = torch.empty((chunk, 2), dtype=torch.int64, device=dev)
             self.read_bytes = chunk * 160
 
