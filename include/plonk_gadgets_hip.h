@@ -597,6 +597,18 @@ pg_status pg_max_bound_ragged_sharded_batch(pg_comm *c, const pg_scalar *d_max_r
                                             uint64_t gate_base, uint64_t var_base, const pg_columns *out,
                                             pg_variable *d_result_vars /* may be NULL */, pg_shard *shard, void *stream);
 
+/* ---- where to put the columns ---------------------------------------------
+ * pg_columns is nine device pointers and the library writes where it is told; on MI355X it matters where.  The emitters write
+ * the same row of the five selector columns at once, and five such streams inside a few GiB of physical memory run 10-18 %
+ * slower than five streams tens of GiB apart.  Columns of tens of GB each lie that far apart by
+ * themselves; for a smaller circuit, allocate ONE block of *total_bytes and put the arrays at the offsets this call returns:
+ * q_m, q_l, q_r, q_o, q_c `stride_bytes` apart (rounded up to 2 MiB; at least a column's own size), then w_l, w_r, w_o and the
+ * variable table back to back behind q_c -- of the layouts measured the best (profiles/NOTES_r04.md section 7).  offsets[] in
+ * the order of pg_columns' fields, every one a multiple of 2 MiB; the block itself should start on a 2-MiB boundary too (any
+ * large hipMalloc does).  24 GiB is what bench.py's fused-mix configuration uses.  Host arithmetic only. */
+pg_status pg_columns_slab_layout(uint64_t n_gates, uint64_t n_vars, uint64_t stride_bytes, uint64_t offsets[9],
+                                 uint64_t *total_bytes);
+
 /* ---- diagnostics ----------------------------------------------------------
  * pg_fill_bytes: a bare streaming fill (16 B per lane, same store form as the emitters) that bench.py times on the same
  * box as a comparison point.  streams = 1..16: the buffer is written as that many equal parts

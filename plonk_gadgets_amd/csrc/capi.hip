@@ -1036,6 +1036,22 @@ extern "C" int pg_debug_mix_phases(unsigned long long out[8]) {
 }
 #endif
 
+pg_status pg_columns_slab_layout(uint64_t n_gates, uint64_t n_vars, uint64_t stride_bytes, uint64_t offsets[9], uint64_t *total_bytes) {
+    if (!offsets || !total_bytes) return fail(PG_ERR_INVALID_ARGUMENT, "offsets / total_bytes is NULL");
+    if (n_gates > (1ull << 40) || n_vars > (1ull << 40) || stride_bytes > (1ull << 44))
+        return fail(PG_ERR_INVALID_ARGUMENT, "circuit or stride too large");
+    constexpr uint64_t al = 2ull << 20;
+    auto up = [](uint64_t x) { return (x + al - 1) / al * al; };
+    const uint64_t ssz = up(n_gates * 32), wsz = up(n_gates * 8), vsz = up(n_vars * 32);
+    const uint64_t stride = up(stride_bytes) > ssz ? up(stride_bytes) : ssz;
+    for (int c = 0; c < 5; c++) offsets[c] = (uint64_t)c * stride;
+    const uint64_t tail = 4 * stride + ssz;
+    for (int c = 0; c < 3; c++) offsets[5 + c] = tail + (uint64_t)c * wsz;
+    offsets[8] = tail + 3 * wsz;
+    *total_bytes = tail + 3 * wsz + vsz;
+    return PG_OK;
+}
+
 pg_status pg_fill_bytes(pg_engine *e, void *d_dst, uint64_t bytes, uint32_t streams, uint64_t pattern, void *stream) {
     if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
     if (!d_dst || !aligned(d_dst, 16) || (bytes & 15)) return fail(PG_ERR_INVALID_ARGUMENT, "dst/bytes not 16-byte aligned");

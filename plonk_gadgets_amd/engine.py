@@ -66,18 +66,21 @@ class Columns:
             wc = [torch.empty((n_gates,), dtype=torch.int64, device=device) for _ in range(3)]
             vv = torch.empty((n_vars, 4), dtype=torch.int64, device=device)
             return Columns(*sc, *wc, vv, gate_base, var_base)
-        align = 2 << 20
-        up = lambda x: (x + align - 1) // align * align
-        ssz, wsz, vsz = up(n_gates * 32), up(n_gates * 8), up(n_vars * 32)
         # q_m q_l q_r q_o q_c a stride apart, then w_l w_r w_o var_values back to back behind q_c (of the layouts measured --
-        # the others between the selector columns, before them, a stride apart themselves -- the best: tools/placement_policy.py)
-        stride = max(up(int(spread_gib * (1 << 30))), ssz)
-        slab = torch.empty(((4 * stride + ssz + 3 * wsz + vsz + align) // 8,), dtype=torch.int64, device=device)
+        # the others between the selector columns, before them, a stride apart themselves -- the best: tools/placement_policy.py);
+        # the arithmetic is the library's (pg_columns_slab_layout: what a caller of the C ABI uses for its own block)
+        off = (C.c_uint64 * 9)()
+        total = C.c_uint64()
+        st = _lib.load().pg_columns_slab_layout(n_gates, n_vars, int(spread_gib * (1 << 30)), off, C.byref(total))
+        if st != 0:
+            raise PgError(st, "pg_columns_slab_layout")
+        align = 2 << 20
+        slab = torch.empty(((total.value + align) // 8,), dtype=torch.int64, device=device)
         first = ((-slab.data_ptr()) % align) // 8
-        sel = [slab[first + c * stride // 8:first + c * stride // 8 + n_gates * 4].view(n_gates, 4) for c in range(5)]
-        tail = first + (4 * stride + ssz) // 8
-        wc = [slab[tail + c * wsz // 8:tail + c * wsz // 8 + n_gates] for c in range(3)]
-        vv = slab[tail + 3 * wsz // 8:tail + 3 * wsz // 8 + n_vars * 4].view(n_vars, 4)
+        at = [first + o // 8 for o in off]
+        sel = [slab[at[c]:at[c] + n_gates * 4].view(n_gates, 4) for c in range(5)]
+        wc = [slab[at[5 + c]:at[5 + c] + n_gates] for c in range(3)]
+        vv = slab[at[8]:at[8] + n_vars * 4].view(n_vars, 4)
         cols = Columns(*sel, *wc, vv, gate_base, var_base)
         cols.slab = slab
         return cols

@@ -53,6 +53,29 @@ def test_host_scalar_helpers_and_layouts():
     assert b"reduced" in lib.pg_last_error()
 
 
+def test_columns_slab_layout():
+    """pg_columns_slab_layout (host arithmetic): the nine arrays of a circuit in one block -- disjoint, inside it, on 2-MiB
+    boundaries, the five selector columns a stride apart (at least their own size), the rest behind the last"""
+    from plonk_gadgets_amd import _lib
+    lib = _lib.load()
+    MiB2 = 2 << 20
+    for n_gates, n_vars, stride in ((10 << 20, 15 << 20, 24 << 30), (1000, 1500, 0), (1000, 1500, 5 << 20), (1 << 27, 1 << 27, 1 << 30),
+                                    (0, 0, 0), (1, 1, 1)):
+        off = (C.c_uint64 * 9)()
+        total = C.c_uint64()
+        assert lib.pg_columns_slab_layout(n_gates, n_vars, stride, off, C.byref(total)) == 0
+        off = list(off)
+        sizes = [n_gates * 32] * 5 + [n_gates * 8] * 3 + [n_vars * 32]
+        assert all(o % MiB2 == 0 for o in off) and off[0] == 0
+        iv = sorted(zip(off, sizes))
+        assert all(a + n <= b for (a, n), (b, _) in zip(iv, iv[1:])) and iv[-1][0] + iv[-1][1] <= total.value
+        want = max((stride + MiB2 - 1) // MiB2 * MiB2, (n_gates * 32 + MiB2 - 1) // MiB2 * MiB2)
+        assert [b - a for a, b in zip(off[:5], off[1:5])] == [want] * 4
+        assert off[5] >= off[4] + n_gates * 32 and off[5] < off[6] < off[7] < off[8] or n_gates == 0
+    assert lib.pg_columns_slab_layout(1, 1, 0, None, C.byref(total)) == 2
+    assert lib.pg_columns_slab_layout(1 << 41, 1, 0, off if False else (C.c_uint64 * 9)(), C.byref(total)) == 2
+
+
 def test_engine_fails_loudly_without_gpu():
     import pytest
     import torch
