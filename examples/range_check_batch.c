@@ -37,11 +37,16 @@ int main(void) {
     pg_columns cols;
     pg_scalar *d_witness;
     pg_variable *d_result;
-    HK(hipMalloc((void **)&cols.q_m, lay.n_gates * 32)); HK(hipMalloc((void **)&cols.q_l, lay.n_gates * 32));
-    HK(hipMalloc((void **)&cols.q_r, lay.n_gates * 32)); HK(hipMalloc((void **)&cols.q_o, lay.n_gates * 32));
-    HK(hipMalloc((void **)&cols.q_c, lay.n_gates * 32)); HK(hipMalloc((void **)&cols.w_l, lay.n_gates * 8));
-    HK(hipMalloc((void **)&cols.w_r, lay.n_gates * 8));  HK(hipMalloc((void **)&cols.w_o, lay.n_gates * 8));
-    HK(hipMalloc((void **)&cols.var_values, lay.n_vars * 32));
+    /* the nine arrays in ONE block, where the library says they should lie relative to each other (a stride of 0: back to
+     * back on 2-MiB boundaries; a circuit of GBs on an MI355X would ask for 24 GiB between the selector columns) */
+    uint64_t off[9], block_bytes;
+    unsigned char *block;
+    CK(pg_columns_slab_layout(lay.n_gates, lay.n_vars, 0, off, &block_bytes));
+    HK(hipMalloc((void **)&block, block_bytes));
+    cols.q_m = (pg_scalar *)(block + off[0]); cols.q_l = (pg_scalar *)(block + off[1]); cols.q_r = (pg_scalar *)(block + off[2]);
+    cols.q_o = (pg_scalar *)(block + off[3]); cols.q_c = (pg_scalar *)(block + off[4]);
+    cols.w_l = (pg_variable *)(block + off[5]); cols.w_r = (pg_variable *)(block + off[6]); cols.w_o = (pg_variable *)(block + off[7]);
+    cols.var_values = (pg_scalar *)(block + off[8]);
     HK(hipMalloc((void **)&d_witness, sizeof witness));
     HK(hipMalloc((void **)&d_result, BATCH * sizeof(pg_variable)));
     HK(hipMemcpy(d_witness, witness, sizeof witness, hipMemcpyHostToDevice));
