@@ -370,8 +370,11 @@ class TimingEvent:
         return ms.value
 
     def __del__(self):
-        if self.h:
-            self.hip.hipEventDestroy(self.h)
+        try:
+            if self.h:
+                self.hip.hipEventDestroy(self.h)
+        except Exception:  # (interpreter shutdown: the runtime may be gone already)
+            pass
 
 
 def measure(wl: Workload, steps: int, warmup: int, sync_all):
