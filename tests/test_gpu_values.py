@@ -139,6 +139,32 @@ def test_max_bound_ragged_values(engine):
     assert engine.check_rows(cols, 5, 0) == -1
 
 
+@pytest.mark.parametrize("shift", [0, 1, 2, 3])
+def test_max_bound_ragged_values_every_ladder_length_every_alignment(engine, shift):
+    """the region sweep writes every 128-byte line in one piece and hands the lines between runs, items and tiles to one pass
+    each: ladders of 1 ... 254 bits side by side (runs shorter than a half, than a line), the table starting 0 / 32 / 64 / 96
+    bytes into a line, canaries on both sides"""
+    from oracle import pyoracle as po
+    batch = 333
+    bits = [1 + int(x) % 254 for x in synth.splitmix64(batch, 77 + shift)]
+    bounds = [max(1, int(x) % (1 << b)) for x, b in zip(synth.splitmix64(batch, 78), bits)]
+    bounds[:6] = [1, 2, 3, 4, 5, (1 << 254) - 1]
+    mr_np = synth.scalars_from_ints(bounds)
+    wit = synth.random_scalars(batch, 79)
+    wit[::2] = synth.scalars_from_ints([int(x) % b for x, b in zip(synth.splitmix64(batch, 80)[::2], bounds[::2])])
+    mr = dev(mr_np)
+    nb, roff, voff = engine.ragged_buffers(batch)
+    lay = engine.max_bound_ragged_plan(mr, nb, roff, voff)
+    ora = po.max_bound_batch(mr_np, wit)
+    assert ora["n_vars"] == lay.n_vars
+    buf = torch.full((lay.n_vars + 128 + shift, 4), CANARY, dtype=torch.int64, device="cuda:0")
+    table = buf[64 + shift:64 + shift + lay.n_vars]
+    engine.max_bound_ragged_values(mr, dev(wit), nb, roff, voff, table)
+    torch.cuda.synchronize()
+    assert bool((buf[:64 + shift] == CANARY).all()) and bool((buf[64 + shift + lay.n_vars:] == CANARY).all())
+    assert np.array_equal(u64(table), ora["var_values"])
+
+
 @pytest.mark.parametrize("batch,zeros", [(1, ()), (129, (0, 127, 128)), (5003, (0, 63, 64, 255, 256, 257, 1023, 1024, 4095, 4096, 4992, 5002))])
 def test_scalar_mix_values(engine, batch, zeros):
     """the fused mix's refresh plans again (an item's shape depends on its witness): prefix sums, error mask and totals == the
