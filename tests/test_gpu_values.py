@@ -80,6 +80,24 @@ def test_range_check_values(engine, mn, mx, n):
     assert torch.equal(full.var_values, table)
 
 
+@pytest.mark.parametrize("shift", [1, 2, 3])
+@pytest.mark.parametrize("mn,mx,n", [(50_000, 250_000, 70), (0, 2**254, 41), (0, 2, 67)])
+def test_range_check_values_at_every_line_alignment(engine, mn, mx, n, shift):
+    """the same refresh into a table that starts 32 / 64 / 96 bytes into a 128-byte line (a composer appending behind other
+    variables): several tiles, canaries on both sides"""
+    import plonk_gadgets_amd as pg
+    from oracle import pyoracle as po
+    w = mixed(mn, mx, n, 29 + shift)
+    ora = po.range_check_batch(synth.mont(mn), synth.mont(mx), w)
+    nv = ora["n_vars"]
+    buf = torch.full((nv + 128 + shift, 4), CANARY, dtype=torch.int64, device="cuda:0")
+    table = buf[64 + shift:64 + shift + nv]
+    engine.range_check_values_batch(pg.BlsScalar.from_int(mn), pg.BlsScalar.from_int(mx), dev(w), table)
+    torch.cuda.synchronize()
+    assert bool((buf[:64 + shift] == CANARY).all()) and bool((buf[64 + shift + nv:] == CANARY).all())
+    assert np.array_equal(u64(table), ora["var_values"])
+
+
 def test_values_calls_touch_no_row_pointer(engine):
     """the C entry point takes no row columns at all; through it, 5000 items at tile edges (32-item tiles: 4999, 5000, 5001)"""
     import plonk_gadgets_amd as pg
