@@ -335,7 +335,23 @@ def hip_runtime():
     object for the soname)"""
     import ctypes as C
     import torch  # noqa: F401
-    hip = C.CDLL("libamdhip64.so.7")
+    path = None
+    try:  # the very object the process has mapped (torch's), whatever its soname
+        for line in open("/proc/self/maps"):
+            if "libamdhip64.so" in line:
+                path = line.split()[-1]
+                break
+    except OSError:
+        pass
+    hip = None
+    for cand in ([path] if path else []) + ["libamdhip64.so.7", "libamdhip64.so"]:
+        try:
+            hip = C.CDLL(cand)
+            break
+        except OSError:
+            continue
+    if hip is None:
+        raise RuntimeError("the HIP runtime (libamdhip64.so) is not loadable")
     hip.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
     hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
     hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
