@@ -99,6 +99,8 @@ class StandardComposer {
     // capacity is explicit here (the reference's Vecs grow on their own): reserve, or let appends double it
     void reserve(uint64_t gate_capacity, uint64_t var_capacity) { pg_throw(pg_composer_reserve(h, gate_capacity, var_capacity), "reserve"); }
     void auto_grow(bool on = true) { pg_throw(pg_composer_auto_grow(h, on ? 1 : 0), "auto_grow"); }
+    // the columns in ONE allocation, the selector columns stride_bytes apart (0: nine allocations): plonk_gadgets_hip.h
+    void spread_columns(uint64_t stride_bytes) { pg_throw(pg_composer_spread_columns(h, stride_bytes), "spread_columns"); }
 
     // the command queue behind the single calls (plonk_gadgets_hip.h): calls are validated and numbered at once and
     // recorded; anything that needs the device state flushes them, in order, as few launches.  queue(false) = one launch

@@ -313,6 +313,11 @@ pg_status pg_composer_columns(const pg_composer *c, pg_columns *out);
  *                          append needs) instead of returning PG_ERR_CAPACITY; off (the default) = fixed capacity. */
 pg_status pg_composer_reserve(pg_composer *c, uint64_t gate_capacity, uint64_t var_capacity);
 pg_status pg_composer_auto_grow(pg_composer *c, int on);
+/* Where the composer's columns lie (see pg_columns_slab_layout below): stride_bytes > 0 moves the nine arrays into ONE
+ * allocation with the selector columns that far apart (live rows and variables are copied; later growth keeps the layout and
+ * needs room for the old block and the new one at once); 0 goes back to nine separate allocations.  For a composer of a few
+ * GB on a card with room to spare: 24 GiB.  The columns move: pointers from pg_composer_columns are stale afterwards. */
+pg_status pg_composer_spread_columns(pg_composer *c, uint64_t stride_bytes);
 uint64_t pg_composer_gate_capacity(const pg_composer *c);
 uint64_t pg_composer_var_capacity(const pg_composer *c);
 pg_status pg_composer_sync(pg_composer *c);

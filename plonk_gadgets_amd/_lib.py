@@ -123,6 +123,7 @@ SIGNATURES = {
     "pg_composer_columns": (C.c_int, [C.c_void_p, _P(ColumnsC)]),
     "pg_composer_reserve": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
     "pg_composer_auto_grow": (C.c_int, [C.c_void_p, C.c_int]),
+    "pg_composer_spread_columns": (C.c_int, [C.c_void_p, C.c_uint64]),
     "pg_composer_gate_capacity": (C.c_uint64, [C.c_void_p]),
     "pg_composer_var_capacity": (C.c_uint64, [C.c_void_p]),
     "pg_composer_sync": (C.c_int, [C.c_void_p]),

@@ -66,6 +66,11 @@ class StandardComposer:
         """like the reference's Vecs: an append that does not fit doubles the capacity instead of failing"""
         _chk(self._lib.pg_composer_auto_grow(self._h, int(on)), "pg_composer_auto_grow")
 
+    def spread_columns(self, gib: float):
+        """the composer's nine arrays in ONE allocation, the selector columns `gib` GiB apart (0: nine allocations again); the
+        live part is copied.  For a composer of a few GB on a card with room to spare (pg_composer_spread_columns)"""
+        _chk(self._lib.pg_composer_spread_columns(self._h, int(gib * (1 << 30))), "pg_composer_spread_columns")
+
     def capacity(self) -> tuple:
         return int(self._lib.pg_composer_gate_capacity(self._h)), int(self._lib.pg_composer_var_capacity(self._h))
 

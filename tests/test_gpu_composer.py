@@ -866,6 +866,38 @@ def test_fuzz_composer_programs(engine, seed):
         raise AssertionError(f"seed {seed}, program {log}: {e}")
 
 
+def test_spread_columns_keeps_the_circuit(engine):
+    """pg_composer_spread_columns: the columns move into one block (selector columns a stride apart) in the middle of a program,
+    the composer grows in that layout, and moves back: columns, first unsatisfied row and sigma == the oracle's throughout"""
+    import ctypes as C
+    from oracle import pyoracle as po
+    from plonk_gadgets_amd import _lib
+    dev, ora = pg.StandardComposer(engine, 1 << 12, 1 << 12), po.Composer()
+    dev.auto_grow()
+    run_fuzz_program(dev, ora, 301, steps=8)
+    same(dev, ora)
+    dev.spread_columns(6 / 1024)  # 6 MiB between the selector columns
+    cc = _lib.ColumnsC()
+    assert dev._lib.pg_composer_columns(dev._h, C.byref(cc)) == 0
+    sel = [cc.q_m, cc.q_l, cc.q_r, cc.q_o, cc.q_c]
+    gate_cap = dev.capacity()[0]
+    want = max(6 << 20, (gate_cap * 32 + (2 << 20) - 1) // (2 << 20) * (2 << 20))
+    assert [b - a for a, b in zip(sel, sel[1:])] == [want] * 4 and cc.w_l > cc.q_c and cc.var_values > cc.w_o
+    same(dev, ora)
+    cap0 = dev.capacity()
+    run_fuzz_program(dev, ora, 302, steps=25)  # (grows: seeds above 100 append items by the thousand)
+    assert dev.capacity() != cap0, "the program was meant to outgrow the composer"
+    same(dev, ora)
+    assert dev.check() == ora.check()
+    dev.spread_columns(0)
+    same(dev, ora)
+    run_fuzz_program(dev, ora, 303, steps=6)
+    same(dev, ora)
+    n = dev.circuit_size()
+    padded = 1 << (n - 1).bit_length()
+    assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded))
+
+
 def test_two_host_threads_two_composers():
     """one engine + composer per host thread (ctypes releases the GIL during the calls): both threads build the golden
     circuit twenty times over, each result equals the fixture"""
