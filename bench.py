@@ -311,7 +311,14 @@ class Workload:
             nb, roff, voff = eng.ragged_buffers(chunk)
             lay = eng.max_bound_ragged_plan(mr, nb, roff, voff)
             self.rows_per_launch, self.vars_per_launch = lay.n_gates, lay.n_vars
-            cols = pg.Columns.allocate(lay.n_gates, lay.n_vars, dev)
+            # columns of 17 GB each lie far apart by themselves; 32 GiB between the selector columns (16-GiB gaps) is still worth
+            # 1.5 % over nine allocations in a row (ten of each in turn: 17.34-17.71 against 17.64-17.98 ms, tools/c4_instances.py)
+            self.spread_gib = float(os.environ.get("PG_BENCH_C4_SPREAD_GIB", "32"))
+            try:
+                cols = pg.Columns.allocate(lay.n_gates, lay.n_vars, dev, spread_gib=self.spread_gib)
+            except torch.OutOfMemoryError:  # (a 175-GiB block: a card with less room gets nine allocations)
+                self.spread_gib = 0.0
+                cols = pg.Columns.allocate(lay.n_gates, lay.n_vars, dev)
             res = torch.empty((chunk,), dtype=torch.int64, device=dev)
             self.read_bytes = chunk * 64
 

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main(instances=6, steps=8, slab=0):
+def main(instances=6, steps=8, slab=0, slab2=None):
     import numpy as np
     import torch
     import bench
@@ -33,7 +33,9 @@ def main(instances=6, steps=8, slab=0):
     lay = _lib.LayoutC()
     assert lib.pg_max_bound_ragged_plan(eng._h, mr.data_ptr(), chunk, nb.data_ptr(), roff.data_ptr(), voff.data_ptr(), C.byref(lay), sp) == 0
     G, V = int(lay.n_gates), int(lay.n_vars)
+    modes = [slab] if slab2 is None else [slab, slab2]  # two modes: alternating
     for inst in range(instances):
+        slab = modes[inst % len(modes)]
         if slab < 0:  # Columns.allocate(spread_gib=-slab): selector columns that far apart, the rest behind the last
             cols = pg.Columns.allocate(G, V, dev, spread_gib=-slab)
             cc = cols.as_c()
