@@ -69,6 +69,24 @@ def test_c5_two_ranks_from_plain_c(tmp_path, variables_only, delay_us):
         assert line.endswith("digest %016x" % want), (r, line, "%016x" % want)
 
 
+@pytest.mark.parametrize("variables_only", [0, 1])
+def test_c5_four_ranks_from_plain_c(tmp_path, variables_only):
+    """the same with FOUR ranks on the one GPU (four fresh child processes; the box allows six): every rank folds the other
+    three's parts of every chunk in rank order -- world = 2 cannot tell rank order from "the other one" -- and the collective
+    publishes its data 5 ms late"""
+    binary = ce.C5_BIN if os.path.exists(ce.C5_BIN) else (ce.build() and ce.C5_BIN)
+    world, total, chunk, bits = 4, 128, 32, 18
+    ident = str(tmp_path / "comm4.id")
+    res = run_ranks([[binary, str(r), str(world), ident, str(total), str(chunk), str(variables_only), str(bits)] for r in range(world)],
+                    rank_env({"FAKE_RCCL_DELAY_US": "5000", "FAKE_RCCL_PIECE_BYTES": str(1 << 20)}))
+    want, words = ce.c5_oracle_digest(world, total, chunk, bits)
+    for r, (code, so, se) in enumerate(res):
+        assert code == 0, (r, se[-2000:])
+        line = so.strip().splitlines()[-1]
+        assert line.startswith(f"rank {r} of {world}: {total // chunk} chunks, {words} words"), line
+        assert line.endswith("digest %016x" % want), (r, line, "%016x" % want)
+
+
 def test_c5_rank_default_bits(tmp_path):
     """the example's default MAX_BITS (advisor finding: 254 made ~9 % of the witnesses non-canonical and the program exit 1)"""
     binary = ce.C5_BIN if os.path.exists(ce.C5_BIN) else (ce.build() and ce.C5_BIN)
