@@ -110,3 +110,16 @@ def test_two_ranks_through_the_python_layer():
                     rank_env({"FAKE_RCCL_PIECE_BYTES": str(1 << 20), "FAKE_RCCL_DELAY_US": "2000"}), timeout=900)
     for r, (code, so, se) in enumerate(res):
         assert code == 0 and f"rank {r} OK" in so, (r, se[-3000:])
+
+
+def test_three_ranks_through_the_python_layer():
+    """the same script with THREE ranks (three processes on the GPU): a world that is not a power of two, ragged shards cut in
+    thirds -- rank 2's bases = the totals of ranks 0 AND 1 --, three parts in pg_allgather_columns and in every chunk"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    res = run_ranks([[sys.executable, os.path.join(ROOT, "tests", "world2_rank.py"), str(r), "3", str(port)] for r in range(3)],
+                    rank_env({"FAKE_RCCL_PIECE_BYTES": str(1 << 20), "FAKE_RCCL_DELAY_US": "2000"}), timeout=900)
+    for r, (code, so, se) in enumerate(res):
+        assert code == 0 and f"rank {r} OK" in so, (r, se[-3000:])
