@@ -275,6 +275,7 @@ class Workload:
         elif name == "c3":
             ins = [to_dev(x) for x in mix_inputs(batch, seed=0xC3 + rank)]
             _, roff, voff = eng.ragged_buffers(chunk)
+            self.plan_buffers = (None, roff, voff)  # (what the launch's plan writes: the exhaustive parity test reads them)
             lay, nerr = eng.scalar_mix_plan(ins[0][:chunk], roff, voff)
             assert nerr == 0 and (lay.n_gates, lay.n_vars) == (10 * chunk, 15 * chunk)
             self.rows_per_launch, self.vars_per_launch = lay.n_gates, lay.n_vars
@@ -309,6 +310,7 @@ class Workload:
             mr_np, wt_np = c4_inputs(batch, seed=0xC4 + rank)
             mr, wt = to_dev(mr_np), to_dev(wt_np)
             nb, roff, voff = eng.ragged_buffers(chunk)
+            self.plan_buffers = (nb, roff, voff)
             lay = eng.max_bound_ragged_plan(mr, nb, roff, voff)
             self.rows_per_launch, self.vars_per_launch = lay.n_gates, lay.n_vars
             # columns of 17 GB each lie far apart by themselves; 32 GiB between the selector columns (16-GiB gaps) is still worth
@@ -334,7 +336,7 @@ class Workload:
         self.algo_bytes_per_launch = rows_written * BYTES_PER_GATE + self.vars_per_launch * BYTES_PER_VAR
 
     def release(self):
-        self.launch = self.cols = self.res = None
+        self.launch = self.cols = self.res = self.plan_buffers = None
 
 
 def hip_runtime():

@@ -67,6 +67,20 @@ int oracle_range_check_batch(fr_t min_range, fr_t max_range, const fr_t *witness
 int oracle_range_check_fast(fr_t min_range, fr_t max_range, const fr_t *witness, size_t batch, uint64_t var_base,
                             int threads, oracle_columns_t *out, uint64_t *result_vars);
 
+/* oracle/fast.c, ragged forms: the columns of oracle_max_bound_batch / oracle_scalar_mix_batch for items [lo, hi) of a
+ * batch whose prefix sums (row_off / var_off, batch + 1 entries, from the *_plan calls) the caller holds: rows are
+ * written at row_off[i] - row_off[lo], item i's first Variable is var_base + var_off[i] and its assignment lies at
+ * var_off[i] - var_off[lo] of out->var_values; inputs are indexed by i, result_vars by i - lo. */
+int oracle_max_bound_plan(const fr_t *max_range, size_t batch, int threads, uint64_t *num_bits, uint64_t *row_off,
+                          uint64_t *var_off);
+int oracle_max_bound_fast(const fr_t *max_range, const fr_t *witness, const uint64_t *num_bits, const uint64_t *row_off,
+                          const uint64_t *var_off, size_t lo, size_t hi, uint64_t var_base, int threads,
+                          oracle_columns_t *out, uint64_t *result_vars);
+int oracle_scalar_mix_plan(const fr_t *v, size_t batch, uint64_t *row_off, uint64_t *var_off, uint8_t *err_mask);
+int oracle_scalar_mix_fast(const fr_t *v, const fr_t *y, const fr_t *s, const fr_t *a, const fr_t *b,
+                           const uint64_t *row_off, const uint64_t *var_off, size_t lo, size_t hi, uint64_t var_base,
+                           uint64_t zero_var, int threads, oracle_columns_t *out, uint64_t *result_vars);
+
 /* for i: allocate(witness[i]); max_bound(max_range[i], .) */
 int oracle_max_bound_batch(const fr_t *max_range, const fr_t *witness, size_t batch, int check, oracle_columns_t *out,
                            uint64_t *result_vars, uint64_t *num_bits, uint64_t *gate_base, uint64_t *var_base,

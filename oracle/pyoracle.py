@@ -73,6 +73,10 @@ def lib():
         "is_non_zero": (C.c_int, [vp, u64, Fr]), "maybe_equal": (u64, [vp, AllocatedScalar, AllocatedScalar]),
         "oracle_range_check_batch": (C.c_int, [Fr, Fr, vp, sz, C.c_int, P(Columns), vp, P(u64), P(u64), P(u64), P(u64)]),
         "oracle_range_check_fast": (C.c_int, [Fr, Fr, vp, sz, u64, C.c_int, P(Columns), vp]),
+        "oracle_max_bound_plan": (C.c_int, [vp, sz, C.c_int, vp, vp, vp]),
+        "oracle_max_bound_fast": (C.c_int, [vp, vp, vp, vp, vp, sz, sz, u64, C.c_int, P(Columns), vp]),
+        "oracle_scalar_mix_plan": (C.c_int, [vp, sz, vp, vp, vp]),
+        "oracle_scalar_mix_fast": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, sz, sz, u64, u64, C.c_int, P(Columns), vp]),
         "oracle_max_bound_batch": (C.c_int, [vp, vp, sz, C.c_int, P(Columns), vp, vp, P(u64), P(u64), P(u64), P(u64)]),
         "oracle_scalar_mix_batch": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_int, P(Columns), vp, vp, P(u64), P(u64),
                                             P(u64), P(u64)]),
@@ -124,6 +128,24 @@ def _alloc_columns(n_gates: int, n_vars: int):
     return arrs, cols
 
 
+def _columns_into(out: dict | None, n_gates: int, n_vars: int):
+    """the nine arrays of a call: fresh ones, or views of the caller's (e.g. pinned) buffers `out[name]`, which must be
+    C-contiguous uint64 arrays at least that long -- the oracle writes straight into them"""
+    if out is None:
+        return _alloc_columns(n_gates, n_vars)
+    arrs = {}
+    for k in ("q_m", "q_l", "q_r", "q_o", "q_c", "var_values"):
+        n = n_vars if k == "var_values" else n_gates
+        a = out[k]
+        assert a.dtype == np.uint64 and a.flags.c_contiguous and a.size >= 4 * n, k
+        arrs[k] = a.reshape(-1)[:4 * n].reshape(n, 4)
+    for k in ("w_l", "w_r", "w_o"):
+        a = out[k]
+        assert a.dtype == np.uint64 and a.flags.c_contiguous and a.size >= n_gates, k
+        arrs[k] = a.reshape(-1)[:n_gates]
+    return arrs, Columns(**{k: v.ctypes.data for k, v in arrs.items()})
+
+
 def _as_fr_array(a) -> np.ndarray:
     a = np.ascontiguousarray(a, dtype=np.uint64)
     assert a.ndim == 2 and a.shape[1] == 4
@@ -150,7 +172,8 @@ def range_check_batch(min_mont, max_mont, witness: np.ndarray, check: bool = Tru
     return arrs
 
 
-def range_check_fast(min_mont, max_mont, witness: np.ndarray, threads: int = 1, var_base: int = 5, timed_passes: int = 1):
+def range_check_fast(min_mont, max_mont, witness: np.ndarray, threads: int = 1, var_base: int = 5, timed_passes: int = 1,
+                     out: dict | None = None):
     """oracle/fast.c: same columns as range_check_batch, flat arrays + mont(2^i) table + threads.  `seconds` is the LAST of
     1 + timed_passes... passes when timed_passes > 1: the first pass lets every thread touch the output pages it writes
     (first touch = placement on the thread's own NUMA node), the timed one then measures the loop, not page faults."""
@@ -160,10 +183,10 @@ def range_check_fast(min_mont, max_mont, witness: np.ndarray, threads: int = 1, 
     mn, mx = fr(min_mont), fr(max_mont)
     n = int(L.num_bits_closest_power_of_two(L.fr_sub(mx, L.fr_from_u64(1))))
     G, V = 4 * n + 11, 2 * n + 524
-    arrs, cols = _alloc_columns(G * batch, V * batch)
+    arrs, cols = _columns_into(out, G * batch, V * batch)
     res = np.zeros(batch, dtype=np.uint64)
     import time
-    if timed_passes <= 1:
+    if timed_passes <= 1 and out is None:
         for a in arrs.values():
             a.fill(0)  # touch the pages: first-touch faults are not the algorithm's time
     for _ in range(max(1, timed_passes)):
@@ -190,6 +213,58 @@ def max_bound_batch(max_mont: np.ndarray, witness: np.ndarray, check: bool = Tru
     assert ng.value == G and nv.value == V
     arrs.update(result_vars=res, num_bits=nb, gate_base=gb.value, var_base=vb.value, n_gates=G, n_vars=V,
                 satisfied=(rc == 0))
+    return arrs
+
+
+def max_bound_plan(max_mont: np.ndarray, threads: int = 1):
+    """ladder length per item and the prefix sums of rows / variables (batch + 1 entries each) of
+    `for i: allocate(w_i); max_bound(bound_i, w_i)`"""
+    max_mont = _as_fr_array(max_mont)
+    batch = max_mont.shape[0]
+    nb = np.zeros(batch, dtype=np.uint64)
+    roff, voff = np.zeros(batch + 1, dtype=np.uint64), np.zeros(batch + 1, dtype=np.uint64)
+    lib().oracle_max_bound_plan(max_mont.ctypes.data, batch, threads, nb.ctypes.data, roff.ctypes.data, voff.ctypes.data)
+    return nb, roff, voff
+
+
+def max_bound_fast(max_mont: np.ndarray, witness: np.ndarray, plan, lo: int, hi: int, var_base: int = 5, threads: int = 1,
+                   out: dict | None = None):
+    """oracle/fast.c: items [lo, hi) of max_bound_batch's columns at the numbering of the whole batch (`plan` from
+    max_bound_plan over the whole batch); rows relative to item lo's first row"""
+    max_mont, witness = _as_fr_array(max_mont), _as_fr_array(witness)
+    nb, roff, voff = plan
+    G, V = int(roff[hi] - roff[lo]), int(voff[hi] - voff[lo])
+    arrs, cols = _columns_into(out, G, V)
+    res = np.zeros(hi - lo, dtype=np.uint64)
+    rc = lib().oracle_max_bound_fast(max_mont.ctypes.data, witness.ctypes.data, nb.ctypes.data, roff.ctypes.data,
+                                     voff.ctypes.data, lo, hi, var_base, threads, C.byref(cols), res.ctypes.data)
+    assert rc == 0
+    arrs.update(result_vars=res, n_gates=G, n_vars=V, num_bits=nb[lo:hi])
+    return arrs
+
+
+def scalar_mix_plan(v: np.ndarray):
+    v = _as_fr_array(v)
+    batch = v.shape[0]
+    roff, voff = np.zeros(batch + 1, dtype=np.uint64), np.zeros(batch + 1, dtype=np.uint64)
+    err = np.zeros(batch, dtype=np.uint8)
+    lib().oracle_scalar_mix_plan(v.ctypes.data, batch, roff.ctypes.data, voff.ctypes.data, err.ctypes.data)
+    return roff, voff, err
+
+
+def scalar_mix_fast(v, y, s, a, b, plan, lo: int, hi: int, var_base: int = 5, zero_var: int = 0, threads: int = 1,
+                    out: dict | None = None):
+    """oracle/fast.c: items [lo, hi) of scalar_mix_batch's columns at the numbering of the whole batch"""
+    v, y, s, a, b = (_as_fr_array(x) for x in (v, y, s, a, b))
+    roff, voff = plan[0], plan[1]
+    G, V = int(roff[hi] - roff[lo]), int(voff[hi] - voff[lo])
+    arrs, cols = _columns_into(out, G, V)
+    res = np.zeros(2 * (hi - lo), dtype=np.uint64)
+    rc = lib().oracle_scalar_mix_fast(v.ctypes.data, y.ctypes.data, s.ctypes.data, a.ctypes.data, b.ctypes.data,
+                                      roff.ctypes.data, voff.ctypes.data, lo, hi, var_base, zero_var, threads,
+                                      C.byref(cols), res.ctypes.data)
+    assert rc == 0
+    arrs.update(result_vars=res.reshape(-1, 2), n_gates=G, n_vars=V)
     return arrs
 
 
