@@ -48,6 +48,13 @@ def engine():
     e.close()
 
 
+def release_hbm():
+    """a failed comparison's traceback (pytest.raises in flip_and_find) keeps views of the columns alive in frame cycles"""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(DEV)
 
@@ -156,6 +163,7 @@ def test_config_c2_every_limb(engine):
     import bench
     from oracle import pyoracle as po
     G, V = 1031, 1034
+    release_hbm()
     free, _ = torch.cuda.mem_get_info()
     if free < BATCH * (G * 184 + V * 32) + (24 << 30):
         pytest.skip("not enough free HBM for the full-size batch")
@@ -185,14 +193,14 @@ def test_config_c2_every_limb(engine):
     assert n_chunks == BATCH // chunk and words * 8 == BATCH * (G * 184 + V * 32) == 233_614_344_192
     assert torch.equal(wl.res, dev(np.concatenate(results)))
     # one flipped bit anywhere is found and named
-    item = 777 * chunk + 3
+    item = 177 * chunk + 3
     results.clear()
-    flip_and_find(wl.cols, "q_l", item * G + 517, 2, lambda: run(only=777))
-    flip_and_find(wl.cols, "w_o", item * G + 1030, 0, lambda: run(only=777))
-    flip_and_find(wl.cols, "var_values", item * V + 600, 3, lambda: run(only=777))
+    flip_and_find(wl.cols, "q_l", item * G + 517, 2, lambda: run(only=177))
+    flip_and_find(wl.cols, "w_o", item * G + 1030, 0, lambda: run(only=177))
+    flip_and_find(wl.cols, "var_values", item * V + 600, 3, lambda: run(only=177))
     wl.release()
-    del wl
-    torch.cuda.empty_cache()
+    del wl, run, produce
+    release_hbm()
 
 
 def test_config_c4_every_limb(engine):
@@ -200,6 +208,7 @@ def test_config_c4_every_limb(engine):
     the ladder lengths and both prefix sums (/root/reference/src/range.rs:82-113, :185-189)"""
     import bench
     from oracle import pyoracle as po
+    release_hbm()
     free, _ = torch.cuda.mem_get_info()
     if free < BATCH * (515 * 184 + 517 * 32) + (16 << 30):
         pytest.skip("not enough free HBM for the full-size batch")
@@ -241,8 +250,8 @@ def test_config_c4_every_limb(engine):
     flip_and_find(wl.cols, "w_r", int(roff[item + 1]) - 1, 0, lambda: run(only=100))
     flip_and_find(wl.cols, "var_values", int(voff[item]) + 300, 0, lambda: run(only=100))
     wl.release()
-    del wl
-    torch.cuda.empty_cache()
+    del wl, run, produce
+    release_hbm()
 
 
 @pytest.mark.parametrize("form", ["bench", "failing_items"])
@@ -254,6 +263,7 @@ def test_config_c3_every_limb(engine, form):
     import bench
     import plonk_gadgets_amd as pg
     from oracle import pyoracle as po
+    release_hbm()
     v, y, s, a, b = bench.mix_inputs(BATCH, seed=0xC3)
     if form == "bench":
         wl = bench.Workload("c3", engine, DEV, 0, 1, LOG2_BATCH, -1)
@@ -306,5 +316,5 @@ def test_config_c3_every_limb(engine, form):
     flip_and_find(cols, "q_o", int(roff[item]) + 1, 3, lambda: run(only=k))
     flip_and_find(cols, "w_l", int(roff[item]), 0, lambda: run(only=k))
     flip_and_find(cols, "var_values", int(voff[item]) + 5, 1, lambda: run(only=k))
-    del cols
-    torch.cuda.empty_cache()
+    del cols, run, produce
+    release_hbm()
