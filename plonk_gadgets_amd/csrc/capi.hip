@@ -263,6 +263,20 @@ struct StreamScope {  // declared right after enter_stream succeeds; its destruc
     ~StreamScope() { (void)hipEventRecord(e->ev_switch, st); }
 };
 
+// Once a call has forked its pre-pass to the engine's side stream, the caller's stream waits for the side stream on EVERY way
+// out of the call, the failing ones included: StreamScope (declared before, so destroyed after) then records ev_switch behind
+// that wait, and a following call on another stream is ordered after the pre-pass, which writes e->d_prefix and variable slots.
+struct SideJoin {
+    pg_engine *e;
+    hipStream_t st;
+    bool forked = false, joined = false;
+    ~SideJoin() {
+        if (!forked || joined) return;
+        (void)hipEventRecord(e->ev_inv, e->side);
+        (void)hipStreamWaitEvent(st, e->ev_inv, 0);
+    }
+};
+
 #ifndef PG_INV_LANES_PER_CU  // lanes of the pre-pass per CU (256 = one wave per SIMD)
 #define PG_INV_LANES_PER_CU 256
 #endif
@@ -335,6 +349,7 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
     } else {
         pg::EmitOut O = make_out(c, batch, GD::W, gate_base, var_base, zero_var, row_off, var_off);
         bool side = false;  // the inversion pre-pass runs on the engine's side stream
+        SideJoin join{e, st};
         if constexpr (GD::kInv > 0) {
             constexpr int GRP = GD::kInvGroup;
             const uint64_t elems = batch * GD::kInv;
@@ -356,6 +371,7 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
             if (side) {
                 PG_HIP_TRY(hipEventRecord(e->ev_fork, st));  // the pre-pass reads the call's inputs: order it after the stream
                 PG_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+                join.forked = true;
                 inv_st = e->side;
             }
             if constexpr (pg::InvDense<GD>::ok) {
@@ -377,7 +393,10 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
             hipLaunchKernelGGL(pg::emit_kernel<GD>, egrid, dim3(pg::kThreads), 0, st, A, O);
         }
         PG_HIP_TRY(hipGetLastError());
-        if (side) PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_inv, 0));  // join
+        if (side) {
+            PG_HIP_TRY(hipStreamWaitEvent(st, e->ev_inv, 0));  // join
+            join.joined = true;
+        }
         return PG_OK;
     }
 }

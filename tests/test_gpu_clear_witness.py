@@ -382,3 +382,73 @@ def test_appends_on_device_arrays_are_signed_by_their_contents(engine):
     assert not refreshing and kept == 60 + 20 + 20 * (4 * 31 + 11) and rewritten > 0, (kept, rewritten)
     same(dev, ora)
     assert dev.check() == ora.check()
+
+
+def test_a_failed_append_leaves_no_signature(engine):
+    """an append that fails AFTER its in-place decision (a misaligned witness array is found by the engine call, behind the
+    composer's own checks) must leave nothing in the log: the failed call, a DIFFERENT append at the same row, clear_witness,
+    then the first call again -- successfully, at the same place -- must be emitted in full, not taken for a refresh of rows
+    that are the other call's.  First in a fresh build, then with the failure in the middle of a refresh (which ends the
+    refresh: what follows is written in full)."""
+    from oracle import pyoracle as po
+    lib = engine._lib
+    mn, mx = S(50_000), S(250_000)
+    wits_a = synth.scalars_from_ints([60_000, 40_000, 250_000, 77_777])
+    wits_b = synth.scalars_from_ints([50_000, 249_999, 1, 100_000])
+    d_a, d_b = t(wits_a), t(wits_b)
+    spare = torch.zeros((4 * 4 + 1,), dtype=torch.int64, device="cuda:0")
+    misaligned = spare.data_ptr() + 8  # 8 mod 16: pg_scalar arrays must be 16-byte aligned (plonk_gadgets_hip.h)
+
+    def oracle_batch(ora, wits, lo, hi):
+        for w in wits:
+            a = ora.allocate(w)
+            ora.L.range_check(ora.c, F(lo), F(hi), a)
+
+    dev = pg.StandardComposer(engine, 1 << 13, 1 << 14)
+    st = lib.pg_composer_range_check_batch(dev._h, C.byref(mn.c), C.byref(mx.c), C.c_void_p(misaligned), 4, None)
+    assert st == 2 and dev.circuit_size() == 3, "PG_ERR_INVALID_ARGUMENT, nothing appended"
+    dev.max_bound_batch(S(2**40), d_a)  # another append at the row where the failed one would have landed
+    dev.clear_witness()
+    dev.range_check_batch(mn, mx, d_b)  # the first call again, valid this time: must NOT be taken for a refresh
+    kept, rewritten, refreshing = dev.refresh_stats()
+    assert kept == 0 and not refreshing, (kept, rewritten, refreshing)
+    ora = po.Composer()
+    oracle_batch(ora, wits_b, 50_000, 250_000)
+    same(dev, ora)
+    assert dev.check() == -1
+
+    # the failure in the middle of a refresh: [range_check_batch, max_bound_batch] built, cleared; the first append is found in
+    # place, the second fails, a different one takes its place: the rest is emitted in full and equals the oracle's
+    dev = pg.StandardComposer(engine, 1 << 13, 1 << 14)
+    dev.range_check_batch(mn, mx, d_a)
+    dev.max_bound_batch(S(2**40), d_a)
+    rows_first = 4 * (4 * 19 + 11)
+    dev.clear_witness()
+    dev.range_check_batch(mn, mx, d_b)
+    m40 = S(2**40)
+    st = lib.pg_composer_max_bound_batch(dev._h, C.byref(m40.c), C.c_void_p(misaligned), 4, None, None)
+    assert st == 2 and dev.circuit_size() == 3 + rows_first
+    kept, rewritten, refreshing = dev.refresh_stats()
+    assert kept == rows_first and not refreshing, "the failed append ended the refresh"
+    dev.max_bound_batch(S(2**41), d_b)  # (would have been a mismatch anyway)
+    dev.max_bound_batch(S(2**40), d_b)
+    ora = po.Composer()
+    oracle_batch(ora, wits_b, 50_000, 250_000)
+    for bound in (2**41, 2**40):
+        for w in wits_b:
+            ora.L.max_bound(ora.c, F(bound), ora.allocate(w), None)
+    same(dev, ora)
+    assert dev.check() == -1
+    # and a third build of that circuit is a refresh again from its first row to its last
+    dev.clear_witness()
+    dev.range_check_batch(mn, mx, d_a)
+    dev.max_bound_batch(S(2**41), d_a)
+    dev.max_bound_batch(S(2**40), d_a)
+    kept, rewritten, refreshing = dev.refresh_stats()
+    assert refreshing and rewritten == 0 and kept == dev.circuit_size() - 3
+    ora = po.Composer()
+    oracle_batch(ora, wits_a, 50_000, 250_000)
+    for bound in (2**41, 2**40):
+        for w in wits_a:
+            ora.L.max_bound(ora.c, F(bound), ora.allocate(w), None)
+    same(dev, ora)

@@ -1,10 +1,12 @@
 #!/bin/bash
 # tools/c4_timeline.sh VARIANT... -- on the GPU box: the C4 step per variant library (tools/variants/lib_V.so) under rocprofv3
 # --kernel-trace; prints when each kernel of the LAST step started and ended (us, relative to the step's first kernel)
+set -eu
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the root of the copy of the repository there)}"
 cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
-  rm -rf /tmp/tl4_$v
-  rocprofv3 --kernel-trace --output-format csv -d /tmp/tl4_$v -o t -- python3 $GRAFT_REPO_ROOT/tools/c4_pieces.py $GRAFT_REPO_ROOT/tools/variants/lib_$v.so > /dev/null 2>&1 || exit 1
+  rm -rf "/tmp/tl4_$v"
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/tl4_$v -o t -- python3 "$GRAFT_REPO_ROOT"/tools/c4_pieces.py "$GRAFT_REPO_ROOT/tools/variants/lib_$v.so" > /dev/null 2>&1 || exit 1
   f=$(find /tmp/tl4_$v -name "*kernel_trace.csv" | head -1)
   python3 - "$f" "$v" <<'PY'
 import csv, sys

@@ -2,12 +2,14 @@
 # tools/pmc_any.sh KERNEL_SUBSTRING -- PYTHON_SCRIPT [ARGS...]: FETCH_SIZE and WRITE_SIZE (own rocprofv3 --pmc passes) of every
 # dispatch of a kernel while a tool script runs; prints per dispatch FETCH_SIZE x 2 (the gfx950 correction of
 # MI355X_MICROARCH.md: the counter tallies 128-B requests at 64 B) and WRITE_SIZE, in GB
+set -eu
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the root of the copy of the repository there)}"
 K=$1; shift; shift
 export TMPDIR=/tmp
 cd /tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_any_$ctr
-  PYTHONPATH=$GRAFT_REPO_ROOT timeout -k 10 600 rocprofv3 --pmc $ctr --output-format csv -d /tmp/pmc_any_$ctr -o p -- python3 "$@" > /tmp/pmc_any_$ctr.log 2>&1 || { tail -5 /tmp/pmc_any_$ctr.log; exit 1; }
+  PYTHONPATH="$GRAFT_REPO_ROOT" timeout -k 10 600 rocprofv3 --pmc $ctr --output-format csv -d /tmp/pmc_any_$ctr -o p -- python3 "$@" > /tmp/pmc_any_$ctr.log 2>&1 || { tail -5 /tmp/pmc_any_$ctr.log; exit 1; }
 done
 python3 - "$K" <<'PY'
 import csv, glob, sys
