@@ -283,11 +283,7 @@ class Workload:
             # allocations in a row happen to land decides 0.51 ... 0.59 ms per step otherwise: DESIGN.md section 2,
             # tools/c3_instances.py, tools/placement_sweep.py); PG_BENCH_SPREAD_GIB=0 allocates them one after the other
             self.spread_gib = float(os.environ.get("PG_BENCH_SPREAD_GIB", "24"))
-            try:
-                cols = pg.Columns.allocate(lay.n_gates, lay.n_vars, dev, spread_gib=self.spread_gib)
-            except torch.OutOfMemoryError:  # a card that does not have the room: nine allocations, and the line says so
-                self.spread_gib = 0.0
-                cols = pg.Columns.allocate(lay.n_gates, lay.n_vars, dev)
+            cols = self.allocate_columns(lay.n_gates, lay.n_vars, self.spread_gib)
             res = torch.empty((chunk, 2), dtype=torch.int64, device=dev)
             self.read_bytes = chunk * 160
 
@@ -297,9 +293,9 @@ class Workload:
                 # no host round trip: the buffers hold the worst case
                 if os.environ.get("PG_C3_SEPARATE_PLAN") == "1":  # (A/B: the plan as its own call ahead of the emit call)
                     eng.scalar_mix_plan_async(part[0], roff, voff)
-                    eng.scalar_mix_emit(*part, roff, voff, cols, res, 3, 5, 0)
+                    eng.scalar_mix_emit(*part, roff, voff, self.cols, res, 3, 5, 0)
                 else:
-                    eng.scalar_mix_planned(*part, roff, voff, cols, res, None, 3, 5, 0)
+                    eng.scalar_mix_planned(*part, roff, voff, self.cols, res, None, 3, 5, 0)
             self.kernel = ("one step (pg_scalar_mix_planned_batch): pg::scalar_mix_vars_kernel<true> (prefix sums, inversions, "
                            "variable table), then pg::rows_periodic_kernel<pg::ScalarMixGD> (+ the generic rows launch for "
                            "tiles with a failing item)")
@@ -316,17 +312,13 @@ class Workload:
             # columns of 17 GB each lie far apart by themselves; 32 GiB between the selector columns (16-GiB gaps) is still worth
             # 1.5 % over nine allocations in a row (ten of each in turn: 17.34-17.71 against 17.64-17.98 ms, tools/c4_instances.py)
             self.spread_gib = float(os.environ.get("PG_BENCH_C4_SPREAD_GIB", "32"))
-            try:
-                cols = pg.Columns.allocate(lay.n_gates, lay.n_vars, dev, spread_gib=self.spread_gib)
-            except torch.OutOfMemoryError:  # (a 175-GiB block: a card with less room gets nine allocations)
-                self.spread_gib = 0.0
-                cols = pg.Columns.allocate(lay.n_gates, lay.n_vars, dev)
+            cols = self.allocate_columns(lay.n_gates, lay.n_vars, self.spread_gib)
             res = torch.empty((chunk,), dtype=torch.int64, device=dev)
             self.read_bytes = chunk * 64
 
             def launch(c):
                 eng.max_bound_ragged_plan_async(mr, nb, roff, voff)
-                eng.max_bound_ragged_emit(mr, wt, nb, roff, voff, cols, res, 3, 5)
+                eng.max_bound_ragged_emit(mr, wt, nb, roff, voff, self.cols, res, 3, 5)
             self.kernel = "pg::emit_kernel<pg::MaxBoundGD<true>> (+ the plan kernel and the inversion pre-pass)"
             self.desc = ("C4: 2^%d items/GPU x (allocate + max_bound(random 253-bit bound)), data-dependent ladder "
                          "length, ragged rows" % log2_batch)
@@ -334,6 +326,35 @@ class Workload:
         self.batch, self.chunk, self.n_chunks = batch, chunk, batch // chunk
         rows_written = getattr(self, "rows_written_per_launch", self.rows_per_launch)
         self.algo_bytes_per_launch = rows_written * BYTES_PER_GATE + self.vars_per_launch * BYTES_PER_VAR
+
+    def allocate_columns(self, n_gates, n_vars, spread_gib):
+        """the nine output arrays: ONE slab with the selector columns spread_gib GiB apart, or -- spread_gib =
+        0, or a card without the room -- nine allocations in a row; self.spread_gib / self.slab_bytes say which it became"""
+        import torch
+        import plonk_gadgets_amd as pg
+        self.slab_bytes = 0
+        if spread_gib > 0:
+            try:
+                cols = pg.Columns.allocate(n_gates, n_vars, self.dev, spread_gib=spread_gib)
+                self.spread_gib, self.slab_bytes = spread_gib, cols.slab.numel() * 8
+                return cols
+            except torch.OutOfMemoryError:  # a card that does not have the room: nine allocations, and the line says so
+                pass
+        self.spread_gib = 0.0
+        return pg.Columns.allocate(n_gates, n_vars, self.dev)
+
+    def reallocate_columns(self, spread_gib):
+        """the same workload into other arrays (c3 / c4: the launch writes self.cols)"""
+        import torch
+        n_gates, n_vars = self.cols.q_m.shape[0], self.cols.var_values.shape[0]
+        self.cols = None
+        torch.cuda.empty_cache()
+        self.cols = self.allocate_columns(n_gates, n_vars, spread_gib)
+
+    def layout_note(self):
+        if getattr(self, "spread_gib", 0):
+            return {"column_layout": "one slab, selector columns %g GiB apart" % self.spread_gib, "slab_total_bytes": self.slab_bytes}
+        return {"column_layout": "nine allocations in a row"}
 
     def release(self):
         self.launch = self.cols = self.res = self.plan_buffers = None
@@ -430,6 +451,61 @@ def measure(wl: Workload, steps: int, warmup: int, sync_all):
     elapsed = time.perf_counter() - t0
     kernel_ms = [a.elapsed_ms(b) for a, b in zip(events[:-1], events[1:])]
     return elapsed, kernel_ms
+
+
+def bare_fill(wl: Workload, reps: int = 5):
+    """"a bare fill-kernel ceiling measured on the same box" -- in this process, on the very arrays the workload has
+    just written.  `columns`: pg_fill_columns, the emitters' store stream with nothing behind it (five selector columns in lock
+    step, the wires, the variable table; tiles of 32768 rows) = the workload's store ceiling ON THESE ARRAYS; `one_window` /
+    `one_stream`: pg_fill_bytes over the variable table alone (short-lived workgroups = one moving window; long-lived ones);
+    `torch_fill`: torch's fill_ over every array in turn.  GB/s, medians of `reps` launches (HIP events on the launch stream)."""
+    import ctypes as C
+    import torch
+    stream = C.c_void_p(torch.cuda.current_stream(wl.dev).cuda_stream)
+    hip = hip_runtime()
+    eng = wl.eng
+
+    def med_ms(fn):
+        fn()
+        ev = [TimingEvent(hip).record(stream)]
+        for _ in range(reps):
+            fn()
+            ev.append(TimingEvent(hip).record(stream))
+        torch.cuda.synchronize(wl.dev)
+        ms = sorted(a.elapsed_ms(b) for a, b in zip(ev[:-1], ev[1:]))
+        return ms[len(ms) // 2]
+
+    out = {"what": "bare store streams over the arrays this workload writes, timed in this process: GB/s"}
+    cols = wl.cols
+    if isinstance(cols, torch.Tensor):  # (the witness refresh writes ONE array: the variable table)
+        arrays, table = [cols], cols
+    else:
+        arrays = [getattr(cols, k) for k in ("q_m", "q_l", "q_r", "q_o", "q_c", "w_l", "w_r", "w_o", "var_values")]
+        table = cols.var_values
+        nbytes = cols.nbytes()
+        out["columns"] = nbytes / med_ms(lambda: eng.fill_columns(cols)) / 1e6
+        out["columns_kernel"] = "pg::fill_columns_kernel (pg_fill_columns): the emitters' sweeps, one constant, no table, no arithmetic"
+    tb = table.numel() * 8
+    out["one_window"] = tb / med_ms(lambda: eng.fill_bytes(table, 0)) / 1e6
+    out["one_stream"] = tb / med_ms(lambda: eng.fill_bytes(table, 1)) / 1e6
+
+    def torch_fill():
+        for a in arrays:
+            a.fill_(0x5A)
+    out["torch_fill"] = sum(a.numel() * 8 for a in arrays) / med_ms(torch_fill) / 1e6
+    out["best"] = max(v for k, v in out.items() if isinstance(v, float))
+    return out
+
+
+def roofline_with_fill(wl: Workload, kernel_ms):
+    """the roofline object plus the same-process bare-fill ceiling (measured AFTER the timed steps: it overwrites the outputs)"""
+    r = roofline_of(wl, kernel_ms)
+    try:
+        r["bare_fill"] = bare_fill(wl)
+        r["frac_of_bare_fill"] = r["achieved"] / r["bare_fill"]["best"]
+    except Exception as ex:  # a comparison point must never cost the line
+        r["bare_fill"] = {"error": repr(ex)}
+    return r
 
 
 def next_rows_secondary(eng, dev, log2_batch: int, steps: int):
@@ -619,12 +695,12 @@ def main():
         print("launch ms:", " ".join("%.2f" % t for t in kernel_ms), file=sys.stderr)
     constraints = world * wl.rows_per_launch * wl.n_chunks * args.steps
     value = constraints / elapsed
-    roofline = roofline_of(wl, kernel_ms)
+    roofline = roofline_with_fill(wl, kernel_ms) if world == 1 else roofline_of(wl, kernel_ms)
     config = {"workload": wl.desc, "items_per_gpu": wl.batch, "items_per_launch": wl.chunk,
               "launches_per_step": wl.n_chunks,
               "sharding": "contiguous witness ranges per rank at global numbering, no data-path collective"}
-    if getattr(wl, "spread_gib", 0):
-        config["column_layout"] = "one slab, selector columns %g GiB apart" % wl.spread_gib
+    if args.workload in ("c3", "c4"):
+        config.update(wl.layout_note())
     wit = getattr(wl, "wit", None)
     mn, mx = getattr(wl, "mn", None), getattr(wl, "mx", None)
     wl.release()
@@ -643,9 +719,18 @@ def main():
                                    "value": w2.rows_per_launch * w2.n_chunks * args.steps / el2, "unit": "constraints/s",
                                    "ms_per_step": el2 / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
                                    "config": {"workload": w2.desc, "items_per_gpu": w2.batch, "items_per_launch": w2.chunk,
-                                              **({"column_layout": "one slab, selector columns %g GiB apart" % w2.spread_gib}
-                                                 if getattr(w2, "spread_gib", 0) else {})},
-                                   "roofline": roofline_of(w2, ms2)}
+                                              **(w2.layout_note() if name in ("c3", "c4") else {})},
+                                   "roofline": roofline_with_fill(w2, ms2)}
+                if name in ("c3", "c4") and getattr(w2, "spread_gib", 0):
+                    # the same launches into nine plain allocations, wherever the driver puts them: what a caller who does not
+                    # lay its columns out gets (the placement effect, driver-observed: DESIGN.md section 2)
+                    w2.reallocate_columns(0)
+                    el3, ms3 = measure(w2, args.steps, args.warmup, sync_all)
+                    r3 = roofline_with_fill(w2, ms3)
+                    secondary[name]["nine_allocations"] = {
+                        "ms_per_step": el3 / args.steps * 1e3, "value": w2.rows_per_launch * w2.n_chunks * args.steps / el3,
+                        "frac": r3["achieved"] / HBM_PEAK_GBPS, "achieved": r3["achieved"], "launch_ms": r3["launch_ms"],
+                        "bare_fill": r3.get("bare_fill"), "frac_of_bare_fill": r3.get("frac_of_bare_fill")}
                 w2.release()
                 del w2
                 torch.cuda.empty_cache()

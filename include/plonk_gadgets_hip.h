@@ -615,10 +615,17 @@ pg_status pg_columns_slab_layout(uint64_t n_gates, uint64_t n_vars, uint64_t str
                                  uint64_t *total_bytes);
 
 /* ---- diagnostics ----------------------------------------------------------
- * pg_fill_bytes: a bare streaming fill (16 B per lane, same store form as the emitters) that bench.py times on the same
- * box as a comparison point.  streams = 1..16: the buffer is written as that many equal parts
- * advanced together by long-lived workgroups, like the emitters' concurrent columns; streams = 0: one short-lived
- * workgroup per 16 KiB. */
+ * Bare store streams, the comparison points bench.py measures in the same process as every workload (SURVEY.md section
+ * 8d; `roofline.bare_fill` of its line).
+ * pg_fill_columns: the emitters' store stream with nothing behind it -- a workgroup owns a tile of `rows_per_tile`
+ * consecutive rows (0: 32768; a multiple of 8) and sweeps the five selector columns in lock step, then the three wire columns,
+ * then its share of the variable table, 16 B per lane, one constant.  On the arrays a workload writes it is that workload's
+ * store ceiling on those arrays (where lock-step streams lie decides 10-18 % on MI355X).  All nine
+ * pointers 16-byte aligned.
+ * pg_fill_bytes: one buffer.  streams = 1..16: written as that many equal parts advanced together by long-lived
+ * workgroups; streams = 0: one short-lived workgroup per 16 KiB (one moving window, like a library fill). */
+pg_status pg_fill_columns(pg_engine *e, const pg_columns *out, uint64_t n_gates, uint64_t n_vars, uint64_t rows_per_tile,
+                          uint64_t pattern, void *stream);
 pg_status pg_fill_bytes(pg_engine *e, void *d_dst /* 16-byte aligned */, uint64_t bytes /* multiple of 16 */,
                         uint32_t streams, uint64_t pattern, void *stream);
 

@@ -195,6 +195,7 @@ SIGNATURES = {
     "pg_comm_world": (C.c_uint32, [C.c_void_p]),
     "pg_allgather_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "pg_allgather_columns": (C.c_int, [C.c_void_p, _P(ColumnsC), C.c_uint64, C.c_uint64, _P(ColumnsC), C.c_void_p]),
+    "pg_fill_columns": (C.c_int, [C.c_void_p, C.POINTER(ColumnsC), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "pg_fill_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]),
     "pg_columns_slab_layout": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "pg_scalar_mix_batch": (C.c_int, [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,

@@ -1092,6 +1092,28 @@ pg_status pg_fill_bytes(pg_engine *e, void *d_dst, uint64_t bytes, uint32_t stre
     return PG_OK;
 }
 
+pg_status pg_fill_columns(pg_engine *e, const pg_columns *out, uint64_t n_gates, uint64_t n_vars, uint64_t rows_per_tile,
+                          uint64_t pattern, void *stream) {
+    if (!e || !out) return fail(PG_ERR_INVALID_ARGUMENT, "NULL argument");
+    PG_HIP_TRY(hipSetDevice(e->device));
+    if (n_gates == 0 && n_vars == 0) return PG_OK;
+    PG_TRY(check_columns(out));
+    for (const void *p : {(const void *)out->w_l, (const void *)out->w_r, (const void *)out->w_o})
+        if (!aligned(p, 16)) return fail(PG_ERR_INVALID_ARGUMENT, "pg_fill_columns: wire columns must be 16-byte aligned");
+    if (rows_per_tile == 0) rows_per_tile = 32768;  // (about the emitters' tiles: 32 x 1031 rows of range_check, 16 x ~511 of max_bound)
+    if (rows_per_tile % 8) return fail(PG_ERR_INVALID_ARGUMENT, "rows_per_tile must be a multiple of 8 (whole lines of every column)");
+    uint64_t tiles = n_gates ? (n_gates + rows_per_tile - 1) / rows_per_tile : 1;
+    if (tiles > 0xffffffffull) return fail(PG_ERR_INVALID_ARGUMENT, "too many tiles for one call");
+    const uint64_t vars_per_tile = ((n_vars + tiles - 1) / tiles + 3) / 4 * 4;
+    pg::EmitOut O = make_out(out, 0, 1, 0, 0, 0, nullptr, nullptr);
+    O.tiles = (uint32_t)tiles;
+    const uint64_t cap = (uint64_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
+    hipLaunchKernelGGL(pg::fill_columns_kernel, dim3((uint32_t)(tiles < cap ? tiles : cap)), dim3(pg::kThreads), 0,
+                       static_cast<hipStream_t>(stream), O, n_gates, n_vars, rows_per_tile, vars_per_tile, pattern);
+    PG_HIP_TRY(hipGetLastError());
+    return PG_OK;
+}
+
 }  // extern "C"
 
 #include "capi_composer.inc"

@@ -754,6 +754,34 @@ __global__ __launch_bounds__(kThreads) void fill_oneshot_kernel(uint4 *dst, uint
         if (base + k * kThreads < n16) store16(dst + base + k * kThreads, v);
 }
 
+// the emitters' store stream with nothing behind it: a workgroup owns a tile of consecutive rows (and the matching share of
+// the variable table) and sweeps the five selector columns in lock step (16 B per lane, 4 KiB of each column per pass), then
+// the three wire columns, then the variable table -- exactly the emit kernel's sweeps, one constant instead of the table
+// look-ups and the arithmetic.  What it reaches on the arrays a workload writes is that workload's store ceiling ON THOSE
+// ARRAYS (where lock-step streams lie decides 10-18 % on MI355X: DESIGN.md section 2): bench.py times it beside every
+// workload.  rows_per_tile is even and a multiple of 8 (whole 128-byte lines of every column), vars_per_tile a multiple of 4.
+__global__ __launch_bounds__(kThreads) void fill_columns_kernel(EmitOut O, uint64_t n_gates, uint64_t n_vars, uint64_t rows_per_tile,
+                                                                uint64_t vars_per_tile, uint64_t pattern) {
+    const uint4 v = make_uint4((uint32_t)pattern, (uint32_t)(pattern >> 32), (uint32_t)~pattern, (uint32_t)(~pattern >> 32));
+    for (uint64_t tile = blockIdx.x; tile < O.tiles; tile += gridDim.x) {
+        const uint64_t r0 = tile * rows_per_tile, r1 = r0 + rows_per_tile < n_gates ? r0 + rows_per_tile : n_gates;
+        const uint64_t v0 = tile * vars_per_tile, v1 = tile + 1 == O.tiles ? n_vars : (v0 + vars_per_tile < n_vars ? v0 + vars_per_tile : n_vars);
+        if (r0 < r1) {
+            for (uint64_t u = 2 * r0 + threadIdx.x; u < 2 * r1; u += kThreads) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) store16(O.q[c] + u, v);
+            }
+            for (uint64_t u = r0 / 2 + threadIdx.x; u < r1 / 2; u += kThreads) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) store16(reinterpret_cast<uint4 *>(O.w[c]) + u, v);
+            }
+            if ((r1 & 1) && threadIdx.x == 0)  // (only the call's last row can be an odd one out)
+                for (int c = 0; c < 3; c++) O.w[c][r1 - 1] = pattern;
+        }
+        for (uint64_t u = 2 * v0 + threadIdx.x; u < 2 * v1; u += kThreads) store16(O.vars + u, v);
+    }
+}
+
 // ---- BlsScalar <-> its 32-byte little-endian canonical encoding, in bulk ----------------
 // (dusk-bytes Serializable: from_bytes rejects values >= q, to_bytes leaves Montgomery form; src/range.rs:162)
 __global__ __launch_bounds__(kThreads) void from_canonical_kernel(const uint4 *raw, uint64_t n, uint4 *out, uint8_t *bad_mask,

@@ -355,6 +355,17 @@ class Engine:
         return out, res, err, nerr, lay
 
     # ---- diagnostics -----------------------------------------------------------------
+    def fill_columns(self, cols: "Columns", n_gates: int | None = None, n_vars: int | None = None, rows_per_tile: int = 0,
+                     pattern: int = 0x0123456789ABCDEF):
+        """pg_fill_columns: the emitters' store stream with nothing behind it, over these nine arrays (the store ceiling of
+        a workload ON ITS OWN ARRAYS; bench.py times it beside every workload)"""
+        n_gates = cols.q_m.shape[0] if n_gates is None else n_gates
+        n_vars = cols.var_values.shape[0] if n_vars is None else n_vars
+        cc = cols.as_c()
+        st = self._lib.pg_fill_columns(self._h, C.byref(cc), n_gates, n_vars, rows_per_tile, pattern, self._stream())
+        if st != 0:
+            raise PgError(st, "pg_fill_columns")
+
     def fill_bytes(self, dst: torch.Tensor, streams: int = 5, pattern: int = 0x0123456789ABCDEF):
         """bare 16-B-per-lane streaming fill of `dst` as `streams` concurrent parts (the write ceiling bench.py quotes)"""
         nbytes = dst.numel() * dst.element_size()
