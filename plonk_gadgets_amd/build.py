@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libplonk_gadgets_hip.so")
 SOURCES = ["capi.hip"]
-HEADERS = ["experiment.hpp", "fr.hpp", "emit.hpp", "invert.hpp", "range_gadgets.hpp", "scalar_gadgets.hpp", "composer.hpp", "permutation.hpp",
+HEADERS = ["experiment.hpp", "fr.hpp", "emit.hpp", "invert.hpp", "range_gadgets.hpp", "scalar_gadgets.hpp", "composer.hpp", "permutation.hpp", "materialize.hpp",
            "capi_composer.inc", "capi_dist.inc"]
 
 

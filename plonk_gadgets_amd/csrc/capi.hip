@@ -24,6 +24,7 @@
 #include "scalar_gadgets.hpp"
 #include "composer.hpp"
 #include "permutation.hpp"
+#include "materialize.hpp"
 
 #ifndef PG_GRID_BLOCKS_PER_CU
 // more workgroups than can be resident: the dispatcher back-fills CUs as tiles finish (+6 % over a persistent

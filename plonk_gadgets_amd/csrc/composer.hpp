@@ -268,15 +268,15 @@ struct MaterializeOut {
     uint4 *val[3];    // w_l_value, w_r_value, w_o_value
     uint64_t *w_4;
 };
-__global__ __launch_bounds__(kThreads) void materialize_kernel(const ComposerCols C, const MaterializeOut M, uint64_t n_rows,
-                                                              uint64_t zero_var) {
+__global__ __launch_bounds__(kThreads) void materialize_kernel(const ComposerCols C, const MaterializeOut M, uint64_t row_begin,
+                                                              uint64_t n_rows /* end of the range */, uint64_t zero_var) {
     constexpr uint64_t kPiece = 16384;  // 16-byte units per workgroup piece = 8192 rows
     constexpr int U = 2;            // (1 or 4, pieces of 64 Ki units: the same 5.9 TB/s of reads + writes, profiles/NOTES_r04.md)
     FrVec one;
     one.f = fr_one();
     const uint4 v1 = (threadIdx.x & 1) ? one.v[1] : one.v[0], v0 = make_uint4(0, 0, 0, 0);  // (a select: indexing the halves by the lane costs scratch)
     const uint64_t units = 2 * n_rows;
-    for (uint64_t base = (uint64_t)blockIdx.x * kPiece; base < units; base += (uint64_t)gridDim.x * kPiece) {
+    for (uint64_t base = 2 * row_begin + (uint64_t)blockIdx.x * kPiece; base < units; base += (uint64_t)gridDim.x * kPiece) {
         const uint64_t end = base + kPiece < units ? base + kPiece : units;
         for (uint64_t i0 = base + threadIdx.x; i0 < end; i0 += (uint64_t)U * kThreads) {
             uint64_t idx[U][3];
