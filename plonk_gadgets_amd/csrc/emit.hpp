@@ -702,12 +702,15 @@ __global__ __launch_bounds__(kThreads, PG_ROWS_WAVES_PER_SIMD) void rows_periodi
                 uint64_t wbase[2], slope[2];
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
+                    // (shifted columns: lane 0's first row is row -1 of the pass -- masked in the tile's first pass, but the LAST
+                    // row of the item before the pass's first in every later one: item -1, row R - 1, not item 0, row 0)
                     const int32_t r = (int32_t)(2 * tid + k) - (int32_t)shift;
-                    const uint32_t rr = r < 0 ? 0u : (uint32_t)r, it = rr / R, j = rr - it * R;
-                    const uint64_t vb = O.var_base + var0 + (uint64_t)it * VV;
+                    const int32_t it = r < 0 ? -1 : r / (int32_t)R;
+                    const uint32_t j = (uint32_t)(r - it * (int32_t)R);
+                    const uint64_t vb = O.var_base + var0 + (uint64_t)(int64_t)it * VV;
                     uint64_t a[3], b[3];
-                    GD::wires(A, O, full, w0 + it, vb, j, a);
-                    GD::wires(A, O, full, w0 + it, vb + 1, j, b);
+                    GD::wires(A, O, full, w0 + (uint64_t)(int64_t)it, vb, j, a);
+                    GD::wires(A, O, full, w0 + (uint64_t)(int64_t)it, vb + 1, j, b);
                     wbase[k] = a[c];
                     slope[k] = b[c] - a[c];  // 1: a Variable of the item; 0: a constant (zero_var)
                 }

@@ -16,9 +16,18 @@
 
 namespace pg {
 
-constexpr int kMatThreads = 512;
+#ifndef PG_MAT_THREADS
+#define PG_MAT_THREADS 512
+#endif
+#ifndef PG_MAT_UNROLL
+#define PG_MAT_UNROLL 2
+#endif
+constexpr int kMatThreads = PG_MAT_THREADS;
 constexpr uint32_t kMatWindowVars = 1040;  // 33 280 B of LDS: four workgroups per CU; range_check's 1034 Variables per item fit
 
+// CLOSED: the segment's wires are known in closed form (PermSeg::wire_kind, a uniform ladder gadget): a row's three Variables are
+// computed from its position in its item, and only a reference to a witness allocated elsewhere is read from the wire column
+template <bool CLOSED>
 __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const ComposerCols C, const MaterializeOut M, const PermSeg S,
                                                                         uint32_t group, uint64_t zero_var) {
     __shared__ uint4 s_win[2 * kMatWindowVars];
@@ -40,27 +49,52 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
         // lines' worth -- with items of 1031 rows that would be two of every 258 lines.  The few rows
         // of the next group that come along find their Variables outside the window and fetch them from memory.
         const uint64_t ubeg = g == 0 ? 2 * r0 : (2 * r0 + 31) & ~31ull, uend = g + 1 == n_groups ? 2 * r1 : (2 * r1 + 31) & ~31ull;
-        for (uint64_t u = (ubeg & ~7ull) + tid; u < uend; u += kMatThreads) {
-            const bool live = u >= ubeg;
-            const uint64_t r = (live ? u : ubeg) >> 1;
-            const uint32_t half = (uint32_t)(u & 1);
-            uint64_t idx[3];
+        constexpr int U = PG_MAT_UNROLL;  // units per lane and pass: the index loads of all of them are in flight together
+        for (uint64_t ub = (ubeg & ~7ull) + tid; ub < uend; ub += (uint64_t)U * kMatThreads) {
+            uint64_t idx[U][3];
+            uint4 got[U][3];
 #pragma unroll
-            for (int k = 0; k < 3; k++) idx[k] = M.val[k] ? C.w[k][r] : w0;
-            uint4 got[3];
+            for (int j = 0; j < U; j++) {
+                const uint64_t u = ub + (uint64_t)j * kMatThreads;
+                const uint64_t r = (u < ubeg ? ubeg : (u < uend ? u : uend - 1)) >> 1;
+                if constexpr (CLOSED) {
+                    // the row's item (of the group, or -- the rows that come along with the last line -- the one after it) and
+                    // its place in it; Variables relative to the window's first
+                    uint32_t rr = (uint32_t)(r - r0), vb = 0;
+                    for (; rr >= S.L; rr -= S.L) vb += S.V;
+                    uint32_t off[3];
+                    seg_wire_offsets(S.wire_kind, S.wire_n, rr, off);
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const uint64_t rel = idx[k] - w0;
-                got[k] = rel < nv ? s_win[2 * (uint32_t)rel + half] : C.vars[2 * idx[k] + half];
+                    for (int k = 0; k < 3; k++) {
+                        idx[j][k] = w0 + vb + off[k];
+                        if (off[k] == kWitnessWire) idx[j][k] = M.val[k] ? C.w[k][r] : w0;  // (an `_allocated` call's witness)
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) idx[j][k] = M.val[k] ? C.w[k][r] : w0;
+                }
             }
-            if (live) {
 #pragma unroll
-                for (int k = 0; k < 7; k++)
-                    if (M.konst[k]) store16(M.konst[k] + u, k == 1 ? v1 : v0);
-                if (M.w_4 && !half) M.w_4[r] = zero_var;
+            for (int j = 0; j < U; j++) {
+                const uint32_t half = (uint32_t)((ub + (uint64_t)j * kMatThreads) & 1);
 #pragma unroll
-                for (int k = 0; k < 3; k++)
-                    if (M.val[k]) store16(M.val[k] + u, got[k]);
+                for (int k = 0; k < 3; k++) {
+                    const uint64_t rel = idx[j][k] - w0;
+                    got[j][k] = rel < nv ? s_win[2 * (uint32_t)rel + half] : C.vars[2 * idx[j][k] + half];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const uint64_t u = ub + (uint64_t)j * kMatThreads;
+                if (u >= ubeg && u < uend) {
+#pragma unroll
+                    for (int k = 0; k < 7; k++)
+                        if (M.konst[k]) store16(M.konst[k] + u, k == 1 ? v1 : v0);
+                    if (M.w_4 && !(u & 1)) M.w_4[u >> 1] = zero_var;
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+                        if (M.val[k]) store16(M.val[k] + u, got[j][k]);
+                }
             }
         }
         __syncthreads();  // the window is the next group's

@@ -28,6 +28,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "composer.hpp"
+#include "range_gadgets.hpp"
 
 namespace pg {
 
@@ -41,7 +42,34 @@ struct PermSeg {
     uint64_t items;
     const uint64_t *row_off, *var_off;
     uint32_t group;
+    // The call's wires in closed form (0: not known -- read the wire columns): the ladder gadgets' rows reference the item's own
+    // Variables at offsets that are a function of the row and the ladder length alone (range_gadgets.hpp, bound_wire_offsets:
+    // what the emitter wrote them from), so whoever needs the Variables of a row -- the wire-value columns of
+    // pg_composer_materialize -- can compute them instead of reading 24 bytes per row back.
+    uint32_t wire_kind, wire_n;
 };
+enum : uint32_t { WIRES_UNKNOWN = 0, WIRES_RANGE_CHECK = 1, WIRES_MAX_BOUND = 2, WIRES_RANGE_CHECK_ALLOCATED = 3, WIRES_MAX_BOUND_ALLOCATED = 4,
+                  WIRES_DECOMPOSITION = 5 };
+// offsets (from the item's first own Variable) of the three wires of item-row j; kWitnessWire: the witness, which is the item's
+// first Variable for the kinds that allocate it and a Variable from elsewhere (read it from the wire column) for the others
+__device__ __forceinline__ void seg_wire_offsets(uint32_t kind, uint32_t n, uint32_t j, uint32_t off[3]) {
+    const uint32_t x0 = kind == WIRES_RANGE_CHECK || kind == WIRES_MAX_BOUND ? 1u : 0u;
+    if (kind == WIRES_RANGE_CHECK || kind == WIRES_RANGE_CHECK_ALLOCATED) {  // RangeCheckGD::wires
+        const uint32_t L = 2 * n + 5, VB = n + 261;
+        if (j == 2 * L) {
+            off[0] = x0 + 260 + n; off[1] = x0 + VB + 260 + n; off[2] = x0 + 2 * VB;
+        } else {
+            const bool is_min = j >= L;
+            bound_wire_offsets(is_min ? j - L : j, n, is_min ? x0 + VB : x0, kWitnessWire, off);
+        }
+    } else if (kind == WIRES_DECOMPOSITION) {  // DecompositionGD::wires
+        bound_wire_offsets(j + 1, n, kWitnessWire, kWitnessWire, off);
+    } else {  // MaxBoundGD<false>::wires
+        bound_wire_offsets(j, n, x0, kWitnessWire, off);
+    }
+    if (x0)
+        for (int c = 0; c < 3; c++) off[c] = off[c] == kWitnessWire ? 0u : off[c];
+}
 __device__ __forceinline__ uint64_t perm_rows_before(const PermSeg &s, uint64_t i) { return s.row_off ? s.row_off[i] : i * s.L; }
 __device__ __forceinline__ uint64_t perm_vars_before(const PermSeg &s, uint64_t i) { return s.var_off ? s.var_off[i] : i * s.V; }
 // item owning Variable v of the segment

@@ -931,3 +931,55 @@ def test_two_host_threads_two_composers():
     for t in threads:
         t.join()
     assert not failures, failures[0]
+
+
+def test_materialize_rows_of_batched_calls(engine):
+    """pg_composer_materialize on a circuit whose rows come from every kind of batched append -- big enough that each call is
+    served by the windowed kernel (csrc/materialize.hpp: the items' own Variables from LDS; the ladder gadgets' wires in closed
+    form, never read back) -- with single calls in between (the generic gather).  Expected: the sentinel-filled outputs equal
+    variables[w] gathered by torch from the composer's own columns, row for row; q_arith = 1, the other constant columns 0,
+    w_4 = zero_var; nothing beyond the circuit's last row is written."""
+    import bench
+    n_items = 70
+    dev = pg.StandardComposer(engine, 1 << 18, 1 << 18)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:0")
+    wit = d(synth.random_scalars(n_items, 11))
+    small = d(synth.uniform_below(n_items, 300_000, seed=12))
+    x = dev.add_input(S(9))
+    dev.range_check_batch(S(0), S(2**254), wit[:9])                    # n = 255: one item per window, lines shared with the next
+    dev.boolean_gate(dev.add_witness_to_circuit_description(S(1)))
+    dev.range_check_batch(S(50_000), S(250_000), small)                # n = 19: eight items per window
+    first = dev.add_input_batch(wit)                                  # Variables allocated elsewhere, then gadgets on them
+    vars_ = torch.arange(first, first + n_items, dtype=torch.int64, device="cuda:0")
+    dev.range_check_allocated_batch(S(0), S(2**200), vars_, wit)
+    dev.assert_equal(x, x)
+    dev.max_bound_batch(S(2**100), wit)
+    dev.max_bound_allocated_batch(S(2**64), vars_, wit)
+    dev.scalar_decomposition_batch(64, vars_, wit)
+    dev.scalar_decomposition_batch(256, vars_[:20], wit[:20])           # (range.rs:134 allows 256)
+    mr, wt = bench.c4_inputs(40, seed=5)
+    dev.max_bound_ragged_batch(d(mr), d(wt))                           # ragged: wires read from the columns
+    v, y, s, a, b = bench.mix_inputs(900, seed=6)
+    v[[3, 500]] = 0
+    assert dev.scalar_mix_batch(d(v), d(y), d(s), d(a), d(b))[2] == 2  # two items stop at is_non_zero's error: a ragged call
+    big = torch.arange(first, first + n_items, dtype=torch.int64, device="cuda:0").repeat(70)
+    dev.maybe_equal_batch(big, big.flip(0))
+    dev.add_batch(S(3), big, S(5), big.flip(0), S(1))
+    dev.mul(S(2), x, x, S(0), None)
+    assert dev.check() == -1
+    n = dev.circuit_size()
+    cols = dev.device_columns()
+    m = dev.materialize()
+    one = torch.tensor(np.array(synth.mont(1), dtype=np.uint64).view(np.int64), device="cuda:0")
+    for wname in ("w_l", "w_r", "w_o"):
+        w = getattr(cols, wname)[:n]
+        exp, got = cols.var_values[w], m[wname + "_value"]
+        if not torch.equal(got, exp):
+            bad = int((got != exp).any(dim=1).nonzero()[0])
+            raise AssertionError(f"{wname}_value differs first at row {bad} (Variable {int(w[bad])})")
+    assert bool((m["q_arith"] == one).all())
+    for k in ("q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add"):
+        assert not bool(m[k].any()), k
+    w4 = m["w_4"]
+    assert int((w4 != 0).sum()) == 1 and int(w4[1]) == 2  # the dummy rows' live fourth wire
+    assert torch.equal(m["w_4_value"], cols.var_values[w4])

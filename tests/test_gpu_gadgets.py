@@ -10,6 +10,7 @@ from plonk_gadgets_amd import synth
 pytestmark = pytest.mark.gpu
 
 COLS = ("q_m", "q_l", "q_r", "q_o", "q_c", "w_l", "w_r", "w_o", "var_values")
+SEL, WIRES = COLS[:5], COLS[5:8]
 Q = synth.Q
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -743,3 +744,43 @@ def test_bulk_encodings(engine):
     assert lib.pg_scalars_from_canonical_batch(engine._h, r2.data_ptr(), 4, o2.data_ptr(), None, C.byref(n), st) == 6 and n.value == 3
     assert lib.pg_scalars_from_canonical_batch(engine._h, r2.data_ptr() + 8, 3, o2.data_ptr(), None, C.byref(n), st) == 2
     assert lib.pg_scalars_from_canonical_batch(engine._h, None, 3, o2.data_ptr(), None, C.byref(n), st) == 2
+
+
+@pytest.mark.parametrize("batch,zeros", [(52, ()), (300, ()), (1000, (0, 51, 255, 256, 700)), (2600, (2599,))])
+@pytest.mark.parametrize("shifted", [("w_l",), ("w_l", "w_r", "w_o"), ("w_r",)])
+def test_fused_mix_into_misaligned_wire_columns(engine, batch, zeros, shifted):
+    """the fused mix into wire columns that start on an ODD 8-byte boundary -- what a composer appending at an odd row hands the
+    call (include/plonk_gadgets_hip.h asks for 8-byte alignment of the wire columns, no more).  More than 51 items: the periodic
+    rows launch pairs rows so that its 16-byte stores stay aligned, and from its second pass on the pair that straddles two
+    passes belongs to the item BEFORE the pass's first (round 5 found row 512 of every such call with item 0's wires; the
+    engine-level tests only ever passed aligned columns).  Every column == the oracle's, the elements around the columns intact."""
+    import bench
+    import plonk_gadgets_amd as pg
+    from oracle import pyoracle as po
+    v, y, s, a, b = bench.mix_inputs(batch, seed=batch)
+    v[list(zeros)] = 0
+    ora = po.scalar_mix_batch(v, y, s, a, b)
+    ins = [dev(x) for x in (v, y, s, a, b)]
+    _, roff, voff = engine.ragged_buffers(batch)
+    big = pg.Columns.allocate(10 * batch + 2, 15 * batch + 2, "cuda:0")
+    for t in (big.w_l, big.w_r, big.w_o):
+        t.fill_(-1)
+    G, V = ora["n_gates"], ora["n_vars"]
+    wires = {k: (getattr(big, k)[1:1 + 10 * batch] if k in shifted else getattr(big, k)[2:2 + 10 * batch]) for k in WIRES}
+    view = pg.Columns(big.q_m[:10 * batch], big.q_l[:10 * batch], big.q_r[:10 * batch], big.q_o[:10 * batch], big.q_c[:10 * batch],
+                      wires["w_l"], wires["w_r"], wires["w_o"], big.var_values[:15 * batch])
+    assert all((wires[k].data_ptr() % 16 == 8) == (k in shifted) for k in WIRES)
+    res = torch.zeros((batch, 2), dtype=torch.int64, device="cuda:0")
+    engine.scalar_mix_planned(*ins, roff, voff, view, res, None, 3, 5, 0)
+    torch.cuda.synchronize()
+    lay, nerr = engine.plan_result()
+    assert (lay.n_gates, lay.n_vars, nerr) == (G, V, len(zeros))
+    got = view.to_numpy()
+    for k in SEL + WIRES:
+        if not np.array_equal(got[k][:G], ora[k]):
+            raise AssertionError(f"{k} differs first at row {int(np.argwhere(got[k][:G] != ora[k])[0][0])}")
+    assert np.array_equal(got["var_values"][:V], ora["var_values"])
+    for k in WIRES:
+        lo = 1 if k in shifted else 2
+        t = getattr(big, k)
+        assert bool((t[:lo] == -1).all()) and bool((t[lo + G:] == -1).all()), k
