@@ -510,8 +510,7 @@ def roofline_with_fill(wl: Workload, kernel_ms):
 
 def next_rows_secondary(eng, dev, log2_batch: int, steps: int):
     """SURVEY 8f rows on a composer holding 2^log2_batch x range_check(0, 2^254): f1 pg_composer_materialize (per row 328 B
-    written -- seven constant columns, w_4, three wire-value columns -- and 24 B of wire indices + 96 B of gathered assignments
-    read) and f2 pg_composer_permutation (24 B of wire indices read per row, four sigma columns of 8 B written per PADDED
+    written -- seven constant columns, w_4, three wire-value columns -- and 32 B read per Variable, each once) and f2 pg_composer_permutation (24 B of wire indices read per row, four sigma columns of 8 B written per PADDED
     row).  Both calls are synchronous; outputs are allocated once, ahead of the timed calls."""
     import ctypes as C
     import numpy as np
@@ -546,13 +545,17 @@ def next_rows_secondary(eng, dev, log2_batch: int, steps: int):
 
     out = {"config": {"workload": "composer of 2^%d x (allocate + range_check(0, 2^254)): %d rows, sigma padded to %d" % (log2_batch, n, padded)}}
     med, lo, hi = timed(lambda: lib.pg_composer_materialize(comp._h, C.byref(fc)))
-    wr, rd = 328 * n, 120 * n
+    # algorithmic bytes: 328 B written per row; read: every assignment ONCE (32 B per Variable -- the rows of a batched call take their
+    # item's Variables from an LDS window read linearly, and the ladder gadgets' wires are computed, not read back: csrc/materialize.hpp).
+    # (Rounds 1-4 counted the gather's 24 B of indices + 96 B of assignments per row as "read": 120 B per row, most of it cache hits.)
+    wr, rd = 328 * n, 32 * comp.num_variables()
     out["materialize"] = {"ms": {"min": lo, "median": med, "max": hi}, "rows_per_s": n / (med / 1e3),
                           "roofline": {"bound": "hbm", "achieved": (wr + rd) / (med / 1e3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                        "frac": (wr + rd) / (med / 1e3) / 1e9 / HBM_PEAK_GBPS,
                                        "algorithmic_bytes": {"written": wr, "read": rd},
                                        "frac_counting_writes_only": wr / (med / 1e3) / 1e9 / HBM_PEAK_GBPS,
-                                       "kernel": "pg::materialize_kernel (one launch: constant columns, w_4, three gathers)"}}
+                                       "kernel": "pg::materialize_items_kernel<true> (one launch per batched call: constant columns, w_4, three "
+                                                 "wire-value columns from an LDS window of the items' Variables, wires in closed form)"}}
     med, lo, hi = timed(lambda: lib.pg_composer_permutation(comp._h, padded, sigma.data_ptr()))
     pb = 24 * n + 32 * padded
     out["permutation"] = {"ms": {"min": lo, "median": med, "max": hi}, "rows_per_s": n / (med / 1e3),

@@ -196,6 +196,9 @@ __host__ __device__ inline uint32_t perm_local_lds_bytes(uint32_t L, uint32_t V)
     return 4 * V + 2 * (V + 2) + 2 * (3 * L + 3 * L + L) + L + 16;
 }
 
+// CLOSED: the segment's wires in closed form (PermSeg::wire_kind, a uniform ladder gadget): the item's 3L Variables are computed,
+// not read back -- 24 of the 56 bytes the pass moves per row; only a witness allocated elsewhere is read from its wire column
+template <bool CLOSED>
 __global__ __launch_bounds__(kThreads, 7) void perm_item_kernel(const PermCtx X, const PermSeg S, uint64_t groups, const PermSparse Q,
                                                             uint64_t *sigma) {
     extern __shared__ uint32_t perm_lds[];
@@ -220,8 +223,20 @@ __global__ __launch_bounds__(kThreads, 7) void perm_item_kernel(const PermCtx X,
 #pragma unroll
             for (uint32_t u = 0; u < kPermRowsPerThread; u++) {
                 const uint32_t r = rb + u * kThreads + tid;
+                if constexpr (CLOSED) {
+                    uint32_t rr = r < L ? r : 0, vb = 0;
+                    for (; rr >= S.L; rr -= S.L) vb += S.V;  // (a group of small items: which one)
+                    uint32_t o3[3];
+                    seg_wire_offsets(S.wire_kind, S.wire_n, rr, o3);
 #pragma unroll
-                for (uint32_t w = 0; w < 3; w++) var[u][w] = r < L ? X.C.w[w][g0 + r] : 0;
+                    for (uint32_t w = 0; w < 3; w++) {
+                        var[u][w] = v0 + vb + o3[w];
+                        if (o3[w] == kWitnessWire) var[u][w] = X.C.w[w][g0 + (r < L ? r : 0)];
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t w = 0; w < 3; w++) var[u][w] = r < L ? X.C.w[w][g0 + r] : 0;
+                }
             }
 #pragma unroll
             for (uint32_t u = 0; u < kPermRowsPerThread; u++) {
