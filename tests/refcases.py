@@ -28,6 +28,27 @@ RANGE_CHECK_CASES = [
     (50_000, 250_000, 18_598, False),
 ]
 
+# The commit-key degree every one of the reference's test circuits is proven and verified under:
+# `PublicParameters::setup(2 << k)` / `pub_params.trim(1 << k)` at tests/range_gadgets_tests.rs:49-50,111-112 and src/range.rs:208-209
+# (k = 10), tests/scalar_gadgets_tests.rs:16-17 (maybe_equal: k = 9), :82-83, :139-140, :193-194 (select_zero / select_one /
+# is_non_zero: k = 7).  Those tests pass in the reference's CI, so each circuit -- StandardComposer::new()'s rows, the gadget's,
+# the closing constrain_to_constant -- padded to a power of two fits a key of that degree (dusk-plonk 0.8 preprocesses under
+# trim(padded_circuit_size): its Circuit::compile does exactly that).  An UPPER bound on the row count, held by the reference
+# itself: it is the one thing about rows the reference pins.  E.g. range_check over [2^126, 2^127 + 1) must stay within 1024 rows:
+# 3 + (4n + 11) + 1 <= 1024 <=> n <= 252 -- a ladder length of 253 or more (a wrong num_bits_closest_power_of_two) would not.
+TRIM_LOG2 = {"max_bound": 10, "range_check": 10, "scalar_decomposition": 10, "maybe_equal": 9, "select_zero": 7, "select_one": 7,
+             "is_non_zero": 7}
+
+
+def padded_circuit_size(circuit_size: int) -> int:
+    """next power of two (dusk-plonk pads the circuit to one before it commits to the selector polynomials)"""
+    return 1 << max(0, (circuit_size - 1).bit_length())
+
+
+def fits_trim_degree(circuit_size: int, which: str) -> bool:
+    return padded_circuit_size(circuit_size) <= (1 << TRIM_LOG2[which])
+
+
 # (a, b, expected)
 MAYBE_EQUAL_CASES = [(100, 100, True), (20, 3330, False), (0, 0, True)]
 

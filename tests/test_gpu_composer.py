@@ -8,7 +8,7 @@ import torch
 
 import plonk_gadgets_amd as pg
 from plonk_gadgets_amd import synth
-from tests.refcases import MAX_BOUND_CASES, MAYBE_EQUAL_CASES, RANGE_CHECK_CASES
+from tests.refcases import MAX_BOUND_CASES, MAYBE_EQUAL_CASES, RANGE_CHECK_CASES, fits_trim_degree
 
 pytestmark = pytest.mark.gpu
 
@@ -65,6 +65,8 @@ def test_range_check_reference_circuit(engine, min_range, max_range, witness, ex
     same(dev, ora)
     assert dev.value(res).to_int() == int(expected)
     assert dev.check() == -1
+    # the reference proves this very circuit under trim(1 << 10) (tests/range_gadgets_tests.rs:111-112)
+    assert fits_trim_degree(dev.circuit_size(), "range_check")
     dev.constrain_to_constant(res, S(1 - int(expected)), None)  # the wrong outcome must not verify
     assert dev.check() == dev.circuit_size() - 1
 
@@ -82,6 +84,7 @@ def test_max_bound_reference_circuit(engine, max_range, witness, expected):
     assert (res, nbits) == (ores, onb.value)
     same(dev, ora)
     assert dev.check() == -1 and dev.value(res).to_int() == int(expected)
+    assert fits_trim_degree(dev.circuit_size(), "max_bound")  # tests/range_gadgets_tests.rs:49-50
 
 
 @pytest.mark.parametrize("a,b,expected", MAYBE_EQUAL_CASES)
@@ -96,6 +99,7 @@ def test_maybe_equal_reference_circuit(engine, a, b, expected):
     assert bit == obit
     same(dev, ora)
     assert dev.check() == -1
+    assert fits_trim_degree(dev.circuit_size(), "maybe_equal")  # tests/scalar_gadgets_tests.rs:16-17
 
 
 def test_select_zero_reference_circuit(engine):
@@ -113,6 +117,7 @@ def test_select_zero_reference_circuit(engine):
         assert res == ores
         same(dev, ora)
         assert (dev.check() == -1) == (sel == 0)
+        assert fits_trim_degree(dev.circuit_size(), "select_zero")  # tests/scalar_gadgets_tests.rs:82-83
 
 
 def test_select_one_reference_circuit_with_public_input(engine):
@@ -132,6 +137,7 @@ def test_select_one_reference_circuit_with_public_input(engine):
         assert res == ores
         same(dev, ora)
         assert dev.check() == -1 and dev.value(res).to_int() == expected
+        assert fits_trim_degree(dev.circuit_size(), "select_one")  # tests/scalar_gadgets_tests.rs:139-140
         dense = dev.construct_dense_pi_vec().cpu().numpy().view(np.uint64)
         odense = np.zeros((ora.n, 4), dtype=np.uint64)
         ora.L.composer_dense_pi(ora.c, odense.ctypes.data)
@@ -161,6 +167,7 @@ def test_is_non_zero_reference_circuit(engine):
     assert ora.L.is_non_zero(ora.c, ora.add_input(synth.mont(r)), po.fr(synth.mont(r))) == 0
     same(dev, ora)
     assert dev.check() == -1
+    assert fits_trim_degree(dev.circuit_size(), "is_non_zero")  # tests/scalar_gadgets_tests.rs:193-194
 
 
 def test_composer_gate_calls(engine):
@@ -303,6 +310,7 @@ def test_scalar_decomposition_reference_unit_test(engine):
         # prover: -100 needs more than 8 bits -> is_eq = 0 and the circuit is satisfied; verifier's witness 1 fits
         assert (dev.check() == -1) == (name == "prover")
         assert dev.value(is_eq).to_int() == (0 if name == "prover" else 1)
+        assert fits_trim_degree(dev.circuit_size(), "scalar_decomposition")  # src/range.rs:208-209
     for k in ("q_m", "q_l", "q_r", "q_o", "q_c", "w_l", "w_r", "w_o"):
         assert np.array_equal(built["prover"][k], built["verifier"][k])
     # num_bits edge cases: 0, 255, 256 bits, and > 256 (the reference panics on the slice, src/range.rs:134)
