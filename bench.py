@@ -690,6 +690,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    # ---- N > 1: what this rank will hold, said before anything is allocated ---------------------------------------------
+    # the gather-inclusive sample runs with the native collective (pg_comm: RCCL, or whatever PG_RCCL_LIB names -- the test-only
+    # stand-in of the one-GPU rehearsals, with torch.distributed on gloo for the rendezvous)
+    native_gather = distributed and args.workload == "c2" and args.allgather_chunks > 0 and (
+        backend == "nccl" or bool(os.environ.get("PG_RCCL_LIB")))
+    hbm_budget = None
+    if distributed:
+        per_item = 1031 * BYTES_PER_GATE + 1034 * BYTES_PER_VAR
+        sharing = max(1, -(-world // ngpu)) if backend != "nccl" else 1  # (a rehearsal: several ranks on one card)
+        gchunk_bytes = (1 << args.allgather_log2_chunk) * per_item
+        want_cols = (1 << args.log2_batch) * (per_item + 40) if args.log2_chunk < 0 else (1 << min(args.log2_batch, args.log2_chunk)) * (per_item + 40)
+        cols_bytes = min(want_cols, int(0.85 * free / sharing))  # (the workload halves its launch until it fits)
+        # two slots, each the rank's own packed chunk and every rank's gathered chunk; the variables-only form regenerates the
+        # other ranks' rows into the same slots
+        pipe_bytes = 2 * (world + 1) * gchunk_bytes if native_gather else 0
+        hbm_budget = {"columns_bytes": cols_bytes, "gather_pipeline_bytes": pipe_bytes, "free_bytes": free, "ranks_sharing_the_card": sharing,
+                      "note": "per rank: the step's nine arrays, then (after they are released) two slots x (world + 1) packed chunks"}
+        if rank == 0:
+            print("bench.py rank budget: columns %.1f GB, gather pipeline %.2f GB (2 slots x %d chunks of %.2f GB), %.1f GB free, %d rank(s) "
+                  "on this card" % (cols_bytes / 1e9, pipe_bytes / 1e9, world + 1, gchunk_bytes / 1e9, free / 1e9, sharing), file=sys.stderr)
+        if pipe_bytes * sharing > 0.9 * free:
+            raise SystemExit("bench.py --gpus %d: the gather pipeline alone needs %.1f GB per rank (2 slots x %d chunks of 2^%d witnesses) and "
+                             "%.1f GB are free for %d rank(s): lower --allgather-log2-chunk" % (
+                                 world, pipe_bytes / 1e9, world + 1, args.allgather_log2_chunk, free / 1e9, sharing))
+
     # ---- headline ------------------------------------------------------------------------------------------
     wl = Workload(args.workload, eng, dev, rank, world, args.log2_batch, args.log2_chunk)
     elapsed, kernel_ms = measure(wl, args.steps, args.warmup, sync_all)
@@ -762,6 +787,8 @@ def main():
         "roofline": roofline,
         "hbm_free_gb_at_start": free / 1e9, "hbm_total_gb": total / 1e9,
     }
+    if hbm_budget:
+        line["hbm_budget"] = hbm_budget
     if secondary:
         line["secondary"] = secondary
 
@@ -769,7 +796,7 @@ def main():
     allgather = None
     watchdog = None
     finished = threading.Event()
-    if distributed and backend == "nccl" and args.workload == "c2" and args.allgather_chunks > 0:
+    if native_gather:
         # the headline is measured; a collective that hangs (a link, a rank that died) must not cost it: after the limit
         # rank 0 prints the line it has, and every rank leaves
         def bail():
@@ -797,8 +824,10 @@ def main():
             pipe.run(wit[:per_rank], per_rank)
             sync_all()
             return max_over_ranks(time.perf_counter() - t1)
+        # (gloo rendezvous + a library named by PG_RCCL_LIB: the pipelines are told to use the native collective themselves)
+        coll = None if backend == "nccl" else pd.NativeCollective(eng)
         try:
-            pipe = pd.GatherPipeline(eng, mn, mx, gchunk)
+            pipe = pd.GatherPipeline(eng, mn, mx, gchunk, collective=coll)
             dt = timed(pipe)
             allgather = {"value": world * per_rank * G / dt, "unit": "constraints/s (every rank ends with every shard)",
                          "witnesses_per_rank": per_rank, "witnesses_per_chunk": gchunk,
@@ -811,7 +840,7 @@ def main():
             allgather = {"error": repr(ex)}
         # the same stream with only the variable tables on the links; the other ranks' rows are regenerated locally
         try:
-            vpipe = pd.VariablesOnlyPipeline(eng, mn, mx, gchunk)
+            vpipe = pd.VariablesOnlyPipeline(eng, mn, mx, gchunk, collective=coll)
             dtv = timed(vpipe)
             allgather["variables_only"] = {
                 "value": world * per_rank * G / dtv, "unit": "constraints/s (every rank ends with every shard)",

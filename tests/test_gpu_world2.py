@@ -123,3 +123,57 @@ def test_three_ranks_through_the_python_layer():
                     rank_env({"FAKE_RCCL_PIECE_BYTES": str(1 << 20), "FAKE_RCCL_DELAY_US": "2000"}), timeout=900)
     for r, (code, so, se) in enumerate(res):
         assert code == 0 and f"rank {r} OK" in so, (r, se[-3000:])
+
+
+def _run_bench(args, extra_env, timeout=600):
+    import json
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=rank_env(dict(PG_DIST_BACKEND="gloo", **extra_env)),
+                       capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, [json.loads(ln) for ln in lines]
+
+
+def test_bench_five_ranks_rehearsal_with_the_gather_leg():
+    """`bench.py --gpus 5`, the EXACT N > 1 code path of config 5 at tiny sizes: a GPU-less parent starts five fresh rank
+    processes (this box admits six on its one card, this test runner being one of them: the driver's N = 8 is the same
+    code with three more children), torch.distributed on gloo for the rendezvous, the library's own collective (pg_comm) bound to
+    the test-only stand-in through PG_RCCL_LIB.  The line must carry the headline at n_gpus = 5, the per-rank HBM budget, and BOTH
+    gather-inclusive figures -- GatherPipeline (every packed chunk gathered) and VariablesOnlyPipeline (tables gathered, the other
+    ranks' rows regenerated) -- with the watchdog armed and cancelled."""
+    world, lg = 5, 8
+    p, lines = _run_bench(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--log2-batch", str(lg), "--no-cpu", "--allgather-log2-chunk", "5",
+                           "--allgather-chunks", "3", "--allgather-timeout", "240"], {"FAKE_RCCL_PIECE_BYTES": str(1 << 20)})
+    assert p.returncode == 0, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+    assert len(lines) == 1, p.stdout
+    line = lines[0]
+    assert line["n_gpus"] == world and line["scaling"] == "weak" and line["config"]["items_per_gpu"] == 1 << lg
+    rows = world * 2 * (1 << lg) * 1031  # ranks x steps x witnesses x rows
+    assert abs(line["value"] * line["ms_per_step"] * 2 / 1e3 - rows) < 1e-6 * rows
+    ag = line["allgather"]
+    assert "error" not in ag and ag["value"] > 0 and ag["witnesses_per_rank"] == 3 * 32 and ag["witnesses_per_chunk"] == 32
+    assert ag["bytes_per_rank_per_chunk"] >= 32 * 222_792
+    vo = ag["variables_only"]
+    assert "error" not in vo and vo["value"] > 0 and vo["bytes_per_rank_per_chunk"] == 32 * 1034 * 32
+    b = line["hbm_budget"]
+    assert b["ranks_sharing_the_card"] == world and b["gather_pipeline_bytes"] == 2 * (world + 1) * 32 * 222_792
+    assert "rank budget" in p.stderr
+
+
+def test_bench_watchdog_abandons_a_gather_that_hangs():
+    """a collective that does not come back (here: the stand-in publishes every exchange 3 s late, the limit is 2 s) must not
+    cost the headline: rank 0 prints the line it has -- exactly one -- with the reason in `allgather.error`, and the run exits
+    3, not 0; no rank is re-exec'd or restarted"""
+    p, lines = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--log2-batch", "8", "--no-cpu", "--allgather-log2-chunk", "5",
+                           "--allgather-chunks", "2", "--allgather-timeout", "2"], {"FAKE_RCCL_DELAY_US": "3000000"}, timeout=300)
+    assert p.returncode == 3, (p.returncode, p.stderr[-3000:])
+    assert len(lines) == 1, p.stdout
+    assert lines[0]["n_gpus"] == 2 and lines[0]["value"] > 0 and "did not finish" in lines[0]["allgather"]["error"]
+
+
+def test_bench_refuses_a_gather_pipeline_that_cannot_fit():
+    """the per-rank budget is checked before anything is allocated: two slots x (world + 1) packed chunks of 2^22 witnesses are
+    5.6 TB -- refused with the figures, exit code non-zero, no line"""
+    p, lines = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--log2-batch", "8", "--no-cpu", "--allgather-log2-chunk", "22"], {},
+                          timeout=300)
+    assert p.returncode != 0 and not lines
+    assert "gather pipeline alone needs" in p.stderr and "--allgather-log2-chunk" in p.stderr
