@@ -225,6 +225,7 @@ pg::EmitOut make_out(const pg_columns *c, uint64_t batch, int W, uint64_t gate_b
     O.inv_dense = nullptr;
     O.inv_elems = 0;
     O.inv_in_place = 1;
+    O.early_span = O.early_tiles = 0;
     return O;
 }
 
@@ -278,6 +279,9 @@ struct SideJoin {
     }
 };
 
+#ifndef PG_MIX_EARLY_TILES  // row tiles (256 items) per workgroup of the fused mix's arithmetic launch written during its inversions
+#define PG_MIX_EARLY_TILES 1
+#endif
 #ifndef PG_INV_LANES_PER_CU  // lanes of the pre-pass per CU (256 = one wave per SIMD)
 #define PG_INV_LANES_PER_CU 256
 #endif
@@ -308,8 +312,16 @@ pg_status launch_mix(pg_engine *e, const pg::ScalarMixArgs &A, const pg_columns 
     if (ipl < 1) ipl = 1;
     if (ipl > pg::kMixMaxIpl) ipl = pg::kMixMaxIpl;
     const uint64_t waves = (batch + 32 * ipl - 1) / (32 * ipl);
-    const pg::EmitOut V = make_out(c, batch, GD::W, gate_base, var_base, zero_var, row_off, var_off);
-    const pg::EmitOut R = make_out(c, batch, GD::kRowsW, gate_base, var_base, zero_var, row_off, var_off);
+    pg::EmitOut V = make_out(c, batch, GD::W, gate_base, var_base, zero_var, row_off, var_off);
+    pg::EmitOut R = make_out(c, batch, GD::kRowsW, gate_base, var_base, zero_var, row_off, var_off);
+    // early rows: the arithmetic launch's waiting waves write the first PG_MIX_EARLY_TILES row tiles of every workgroup's items
+    // during its inversions (scalar_gadgets.hpp); the rows launches leave them alone.  Only where a workgroup holds enough tiles
+    // for that to be a fraction of its rows (a small call's inversions are not worth hiding)
+    const uint64_t span = (uint64_t)pg::kMixWaves * 32 * ipl;
+    if (!values_only && ipl >= 8 && span <= 0xffffffffull) {
+        V.early_span = R.early_span = (uint32_t)span;
+        V.early_tiles = R.early_tiles = PG_MIX_EARLY_TILES;
+    }
     const uint32_t max_blocks = (uint32_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
     const dim3 grid(R.tiles < max_blocks ? R.tiles : max_blocks), vgrid((uint32_t)((waves + pg::kMixWaves - 1) / pg::kMixWaves));
     const dim3 vblock(pg::kMixWaves * 64);

@@ -54,7 +54,23 @@ struct EmitOut {
     const uint4 *inv_dense;
     uint64_t inv_elems;
     uint32_t inv_in_place;
+    // Split gadgets (the fused mix): the launch that inverts writes the rows of the first `early_tiles` row tiles of every
+    // `early_span` items itself, while its inversions leave HBM idle (scalar_gadgets.hpp); the rows launches leave those tiles alone.
+    // 0: no such tiles.
+    uint32_t early_span, early_tiles;
 };
+// is row tile `tile` (kRowsW = W items from item w0, Wt of them inside the batch) one of the tiles the inverting launch wrote?
+// Both launches decide from the call's prefix sums alone: the tile is complete, among the first early_tiles of its span, and NO item of
+// the span stopped early (the span's rows are then 10 per item -- R -- and the inverting launch, which counts failing items per
+// span, knows the same thing without reading them).
+// (two steps, so that the caller can issue the two loads with its own and wait once: candidate -> the span's ends; then the test)
+__device__ __forceinline__ bool early_rows_candidate(const EmitOut &O, uint64_t w0, uint32_t Wt, uint32_t W, uint64_t &s0, uint64_t &s1) {
+    s0 = s1 = 0;
+    if (!O.early_tiles || Wt != W) return false;
+    s0 = w0 - w0 % O.early_span;
+    s1 = s0 + O.early_span < O.batch ? s0 + O.early_span : O.batch;
+    return (w0 - s0) / W < O.early_tiles;
+}
 
 // the inverse of element s of the call, from the pre-pass's dense output into an item record (16-byte halves straight into
 // the record: a copy through an Fr temporary goes through private memory).  Unconditional -- beside a running pre-pass
@@ -636,10 +652,89 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
 #ifndef PG_ROWS_WAVES_PER_SIMD
 #define PG_ROWS_WAVES_PER_SIMD 8
 #endif
+// the rows of ONE tile of full-shape items (Wt items from item w0; first row row0 and first Variable var0, relative to the call) by
+// 256 lanes `tid` -- the periodic launch's workgroup, or the four waiting waves of the inverting launch (scalar_gadgets.hpp).  v[5]: the
+// lane's selector halves (lanes 2r, 2r + 1 hold the halves of row r of a pass of IPP whole items: the same on every pass)
+template <class GD>
+__device__ __forceinline__ void periodic_tile_rows(const typename GD::Args &A, const EmitOut &O, const uint4 v[5], uint32_t tid, uint64_t w0,
+                                                   uint32_t Wt, uint64_t row0, uint64_t var0) {
+    constexpr uint32_t R = GD::kUniformRows, VV = GD::kUniformVars;
+    constexpr uint32_t IPP = (kThreads / 2) / R, LS = IPP * R * 2;
+    constexpr uint32_t LW = periodic_wire_lanes(R), IPW = 2 * LW / R;  // wires: two rows per lane, IPW whole items per pass
+    typename GD::RowRec full{};  // the shape record of a full item
+    const uint32_t total_rows = Wt * R;
+    if (tid < LS) {
+        // A lane's five stores of one pass would go to the same row of five arrays of the same size: whether those five
+        // addresses fall on the same memory channel is then decided by the arrays' base addresses, once, for the whole
+        // call (up to 25 % between placements of the same columns, profiles/NOTES_r02.md).  The values of a lane do not
+        // depend on the pass, so column c starts c fifths of the tile further on and wraps: the five streams are that far
+        // apart in their arrays, by an amount that is not a power of two (-3 % on the fused mix's step).
+        const uint32_t passes = (total_rows * 2 + LS - 1) / LS;
+        uint4 *base[5];
+        uint32_t at[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            base[c] = O.q[c] + (row0 * 2 + tid);
+            at[c] = (uint32_t)(((uint64_t)c * passes) / 5);
+        }
+        for (uint32_t p = 0; p < passes; p++) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const uint32_t off = at[c] * LS;
+                if (off + tid < total_rows * 2) store16(base[c] + off, v[c]);
+                at[c] = at[c] + 1 == passes ? 0 : at[c] + 1;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        uint64_t *col = O.w[c] + row0;
+        // pair rows so that every pair starts on a 16-byte boundary
+        const uint32_t shift = (uint32_t)((reinterpret_cast<uintptr_t>(col) >> 3) & 1);
+        if (tid < LW) {
+            uint64_t wbase[2], slope[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                // (shifted columns: lane 0's first row is row -1 of the pass -- masked in the tile's first pass, but the LAST
+                // row of the item before the pass's first in every later one: item -1, row R - 1, not item 0, row 0)
+                const int32_t r = (int32_t)(2 * tid + k) - (int32_t)shift;
+                const int32_t it = r < 0 ? -1 : r / (int32_t)R;
+                const uint32_t j = (uint32_t)(r - it * (int32_t)R);
+                const uint64_t vb = O.var_base + var0 + (uint64_t)(int64_t)it * VV;
+                uint64_t a[3], b[3];
+                GD::wires(A, O, full, w0 + (uint64_t)(int64_t)it, vb, j, a);
+                GD::wires(A, O, full, w0 + (uint64_t)(int64_t)it, vb + 1, j, b);
+                wbase[k] = a[c];
+                slope[k] = b[c] - a[c];  // 1: a Variable of the item; 0: a constant (zero_var)
+            }
+            const uint64_t step = (uint64_t)IPW * VV;
+            uint64_t adv = 0;
+            for (int64_t r0 = (int64_t)2 * tid - shift; r0 < (int64_t)total_rows; r0 += 2 * LW, adv += step) {
+                const uint64_t v0 = wbase[0] + slope[0] * adv, v1 = wbase[1] + slope[1] * adv;
+                if (r0 >= 0 && r0 + 1 < (int64_t)total_rows) {
+                    store16(reinterpret_cast<uint4 *>(col + r0),
+                            make_uint4((uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32)));
+                } else {
+                    if (r0 >= 0) col[r0] = v0;
+                    if (r0 + 1 < (int64_t)total_rows) col[r0 + 1] = v1;
+                }
+            }
+        }
+    }
+}
+// the lane's selector halves for periodic_tile_rows (table: the eight common constants, fill_common_table)
+template <class GD>
+__device__ __forceinline__ void periodic_lane_selectors(const typename GD::Args &A, const uint4 *table, uint32_t tid, uint4 v[5]) {
+    constexpr uint32_t R = GD::kUniformRows, IPP = (kThreads / 2) / R, LS = IPP * R * 2;
+    typename GD::RowRec full{};
+    const uint32_t rl = (tid < LS ? tid : 0) >> 1;
+    GD::selectors(A, full, rl - (rl / R) * R, table, tid & 1, v);
+}
+
 template <class GD>
 __global__ __launch_bounds__(kThreads, PG_ROWS_WAVES_PER_SIMD) void rows_periodic_kernel(const typename GD::Args A, const EmitOut O) {
     constexpr int W = GD::kRowsW;
-    constexpr uint32_t R = GD::kUniformRows, VV = GD::kUniformVars;
+    constexpr uint32_t R = GD::kUniformRows;
     __shared__ uint4 s_table[T_POW * 2];
     const uint32_t tid = threadIdx.x;
 #if defined(PG_ROWS_SETPRIO)
@@ -648,17 +743,10 @@ __global__ __launch_bounds__(kThreads, PG_ROWS_WAVES_PER_SIMD) void rows_periodi
     fill_common_table(s_table, nullptr, tid, T_POW);
     GD::fill_table(A, s_table, tid);
     lds_barrier();
-    typename GD::RowRec full{};  // the shape record of a full item
-
     // selectors: lanes 2r, 2r+1 hold the halves of row r; IPP whole items per pass.  What a lane stores is the same on
     // every pass of every tile
-    constexpr uint32_t IPP = (kThreads / 2) / R, LS = IPP * R * 2;
     uint4 v[5];
-    {
-        const uint32_t rl = (tid < LS ? tid : 0) >> 1;
-        GD::selectors(A, full, rl - (rl / R) * R, s_table, tid & 1, v);
-    }
-    constexpr uint32_t LW = periodic_wire_lanes(R), IPW = 2 * LW / R;  // wires: two rows per lane, IPW whole items per pass
+    periodic_lane_selectors<GD>(A, s_table, tid, v);
 
     for (uint32_t tile = blockIdx.x; tile < O.tiles; tile += gridDim.x) {
         const uint64_t w0 = (uint64_t)tile * W;
@@ -666,68 +754,13 @@ __global__ __launch_bounds__(kThreads, PG_ROWS_WAVES_PER_SIMD) void rows_periodi
         // (the three offsets are the same for every lane, but the compiler cannot load them through the scalar cache -- the
         // columns' stores might alias them -- and would make the wire sweep wait for them behind EVERY selector store of the
         // tile: vmcnt counts loads and stores alike.  Made scalar here, they are waited for before the first store.)
+        uint64_t s0, s1;
+        const bool cand = early_rows_candidate(O, w0, Wt, W, s0, s1);
+        const uint64_t span_rows = cand ? O.row_off[s1] - O.row_off[s0] : 0;  // (issued with the three below, waited for once)
         const uint64_t row0 = uniform64(O.row_off[w0]), var0 = uniform64(O.var_off[w0]), row1 = uniform64(O.row_off[w0 + Wt]);
-        const uint32_t total_rows = Wt * R;
-        if (row1 - row0 != total_rows) continue;  // an item of another shape: the generic launch's tile
-
-        if (tid < LS) {
-            // A lane's five stores of one pass would go to the same row of five arrays of the same size: whether those five
-            // addresses fall on the same memory channel is then decided by the arrays' base addresses, once, for the whole
-            // call (up to 25 % between placements of the same columns, profiles/NOTES_r02.md).  The values of a lane do not
-            // depend on the pass, so column c starts c fifths of the tile further on and wraps: the five streams are that far
-            // apart in their arrays, by an amount that is not a power of two (-3 % on the fused mix's step).
-            const uint32_t passes = (total_rows * 2 + LS - 1) / LS;
-            uint4 *base[5];
-            uint32_t at[5];
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                base[c] = O.q[c] + (row0 * 2 + tid);
-                at[c] = (uint32_t)(((uint64_t)c * passes) / 5);
-            }
-            for (uint32_t p = 0; p < passes; p++) {
-#pragma unroll
-                for (int c = 0; c < 5; c++) {
-                    const uint32_t off = at[c] * LS;
-                    if (off + tid < total_rows * 2) store16(base[c] + off, v[c]);
-                    at[c] = at[c] + 1 == passes ? 0 : at[c] + 1;
-                }
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            uint64_t *col = O.w[c] + row0;
-            // pair rows so that every pair starts on a 16-byte boundary
-            const uint32_t shift = (uint32_t)((reinterpret_cast<uintptr_t>(col) >> 3) & 1);
-            if (tid < LW) {
-                uint64_t wbase[2], slope[2];
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    // (shifted columns: lane 0's first row is row -1 of the pass -- masked in the tile's first pass, but the LAST
-                    // row of the item before the pass's first in every later one: item -1, row R - 1, not item 0, row 0)
-                    const int32_t r = (int32_t)(2 * tid + k) - (int32_t)shift;
-                    const int32_t it = r < 0 ? -1 : r / (int32_t)R;
-                    const uint32_t j = (uint32_t)(r - it * (int32_t)R);
-                    const uint64_t vb = O.var_base + var0 + (uint64_t)(int64_t)it * VV;
-                    uint64_t a[3], b[3];
-                    GD::wires(A, O, full, w0 + (uint64_t)(int64_t)it, vb, j, a);
-                    GD::wires(A, O, full, w0 + (uint64_t)(int64_t)it, vb + 1, j, b);
-                    wbase[k] = a[c];
-                    slope[k] = b[c] - a[c];  // 1: a Variable of the item; 0: a constant (zero_var)
-                }
-                const uint64_t step = (uint64_t)IPW * VV;
-                uint64_t adv = 0;
-                for (int64_t r0 = (int64_t)2 * tid - shift; r0 < (int64_t)total_rows; r0 += 2 * LW, adv += step) {
-                    const uint64_t v0 = wbase[0] + slope[0] * adv, v1 = wbase[1] + slope[1] * adv;
-                    if (r0 >= 0 && r0 + 1 < (int64_t)total_rows) {
-                        store16(reinterpret_cast<uint4 *>(col + r0),
-                                make_uint4((uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32)));
-                    } else {
-                        if (r0 >= 0) col[r0] = v0;
-                        if (r0 + 1 < (int64_t)total_rows) col[r0 + 1] = v1;
-                    }
-                }
-            }
-        }
+        if (row1 - row0 != Wt * R) continue;  // an item of another shape: the generic launch's tile
+        if (cand && uniform64(span_rows) == (s1 - s0) * R) continue;  // written by the inverting launch while it inverted
+        periodic_tile_rows<GD>(A, O, v, tid, w0, Wt, row0, var0);
     }
 }
 

@@ -396,6 +396,8 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
     const ScalarMixArgs A, const EmitOut O, uint32_t ipl, uint4 *scratch, uint4 *sink, const MixPlan P) {
     __shared__ uint4 s_img[kMixWaves][32 * 15 * 2];
     __shared__ uint64_t s_errs[kMixWaves], s_before;  // PLAN: failing items of the workgroup's waves, and before the workgroup
+    __shared__ uint4 s_consts[T_POW * 2];             // the rows' constants (early rows, below)
+    __shared__ uint32_t s_before_ready;               // PLAN: s_before is written (the waves that write early rows wait for it)
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 31;
     const bool bside = lane >= 32;  // the a - b side of item p
     const uint64_t gw = (uint64_t)blockIdx.x * kMixWaves + wave;  // the wave's index in the launch
@@ -511,6 +513,10 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
         };
         if (wave >= 4) set(acc);
         if (PLAN && lane == 0) s_errs[wave] = errs;  // (a wave without items counted none)
+        if (O.early_tiles) {
+            fill_common_table(s_consts, nullptr, threadIdx.x, T_POW);
+            if (threadIdx.x == 0) s_before_ready = 0;
+        }
         __syncthreads();
         if (wave < 4) {
             const Fr other = get();
@@ -549,6 +555,7 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
                 if (gave_up) P.host->pad = 1;
                 __hip_atomic_exchange(&P.agg[b], kAggP | (before + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_before = before;
+                __hip_atomic_store(&s_before_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (b + 1 == P.nwaves) {  // the workgroup of the last item: the totals
                     const uint64_t e_all = before + mine;
                     P.row_off[O.batch] = 10 * O.batch - 2 * e_all;
@@ -565,6 +572,46 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
             if (done == P.nwaves - 1) {
                 for (uint32_t j = lane; j < P.nwaves; j += 64) __hip_atomic_exchange(&P.agg[j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (lane == 0) __hip_atomic_exchange(&P.agg[P.cap], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // ---- early rows: what the waiting waves do meanwhile ------------------------------------------------------------
+        // The inversions take ~50 us during which nothing moves: four of the workgroup's eight waves compute a chain of dependent
+        // instructions, the other four wait, HBM is idle.  A store stream needs neither many waves nor the multiplier (four
+        // waves per CU with a tight store loop write at the chip's rate, and 240 MB written beside a 50-us arithmetic phase
+        // cost it 5 us: tools/probes/store_occupancy.hip, hidden_stores.hip) -- so the waiting waves write the rows of the first
+        // early_tiles row tiles of the workgroup's items, and the rows launch that follows leaves those alone (emit.hpp,
+        // early_rows_candidate: both sides decide from the same thing, "no item of the span stopped early").
+        if (O.early_tiles && wave >= 4) {
+            using GD = ScalarMixGD;
+            constexpr uint32_t W = GD::kRowsW, R = GD::kUniformRows, VV = GD::kUniformVars;
+            const uint64_t s0 = (uint64_t)blockIdx.x * O.early_span;
+            if (s0 < O.batch) {
+                const uint64_t s1 = s0 + O.early_span < O.batch ? s0 + O.early_span : O.batch;
+                bool full;
+                uint64_t row0, var0;
+                if constexpr (PLAN) {
+                    uint64_t mine = 0;
+#pragma unroll
+                    for (int w = 0; w < kMixWaves; w++) mine += s_errs[w];
+                    full = mine == 0;
+                    if (full && wave != kMixWaves - 1)  // (the last wave has just written it itself)
+                        while (__hip_atomic_load(&s_before_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(8);
+                    const uint64_t before = full ? s_before : 0;
+                    row0 = R * s0 - 2 * before;
+                    var0 = VV * s0 - 2 * before;
+                } else {
+                    row0 = O.row_off[s0];
+                    var0 = O.var_off[s0];
+                    full = O.row_off[s1] - row0 == (s1 - s0) * R;
+                }
+                if (full) {
+                    const uint32_t tid = (wave - 4) * 64 + lane;
+                    uint4 v[5];
+                    periodic_lane_selectors<GD>(A, s_consts, tid, v);
+                    const uint32_t tiles = (uint32_t)((s1 - s0) / W) < O.early_tiles ? (uint32_t)((s1 - s0) / W) : O.early_tiles;  // complete tiles only
+                    for (uint32_t t = 0; t < tiles; t++)
+                        periodic_tile_rows<GD>(A, O, v, tid, s0 + (uint64_t)t * W, W, row0 + (uint64_t)t * W * R, var0 + (uint64_t)t * W * VV);
+                }
             }
         }
         __syncthreads();

@@ -318,3 +318,65 @@ def test_config_c3_every_limb(engine, form):
     flip_and_find(cols, "var_values", int(voff[item]) + 5, 1, lambda: run(only=k))
     del cols, run, produce
     release_hbm()
+
+
+@pytest.mark.parametrize("batch,form", [(524_288 + 77, "planned"), (700_001, "planned"), (700_001, "two_step"), (1_000_003, "two_step")])
+def test_fused_mix_early_rows_every_limb(engine, batch, form):
+    """the fused mix at sizes where the arithmetic launch writes row tiles itself while it inverts (calls of half a million items and
+    more: csrc/scalar_gadgets.hpp, "early rows"), with everything that decides which tiles those are: a batch that is no multiple of
+    a workgroup's span or of a tile, failing items in some spans and not in others (first, last and middle spans; a span whose only
+    failing item is its last), wire columns on an odd 8-byte boundary, the planned call (prefix sums by look-back: the writers wait for
+    them) and plan + emit.  Every row and variable against the oracle; nothing beyond the totals touched."""
+    import bench
+    import plonk_gadgets_amd as pg
+    from oracle import pyoracle as po
+    release_hbm()
+    v, y, s, a, b = bench.mix_inputs(batch, seed=batch & 0xFFFF)
+    ipl = -(-batch // (256 * 8 * 32))
+    span = 256 * ipl
+    zeros = sorted({0, span + 5, 3 * span - 1, 7 * span, 7 * span + 1, batch - 1} | set(range(10 * span + 300, 10 * span + 330)))
+    zeros = [z for z in zeros if z < batch]
+    v[zeros] = 0
+    ins = [dev(x) for x in (v, y, s, a, b)]
+    plan = po.scalar_mix_plan(v)
+    roff, voff, o_err = plan
+    G, V = int(roff[-1]), int(voff[-1])
+    _, d_roff, d_voff = engine.ragged_buffers(batch)
+    big = pg.Columns.allocate(10 * batch + 2, 15 * batch + 2, DEV)
+    for name in NINE:
+        getattr(big, name).fill_(-1)
+    # wire columns one element in: an odd 8-byte boundary, as a composer appending at an odd row has them
+    cols = pg.Columns(big.q_m[:10 * batch], big.q_l[:10 * batch], big.q_r[:10 * batch], big.q_o[:10 * batch], big.q_c[:10 * batch],
+                      big.w_l[1:1 + 10 * batch], big.w_r[1:1 + 10 * batch], big.w_o[1:1 + 10 * batch], big.var_values[:15 * batch])
+    res = torch.full((batch, 2), -1, dtype=torch.int64, device=DEV)
+    if form == "planned":
+        err = torch.full((batch,), 7, dtype=torch.uint8, device=DEV)
+        engine.scalar_mix_planned(*ins, d_roff, d_voff, cols, res, err, 3, 5, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(err, torch.from_numpy(o_err).to(DEV))
+    else:
+        lay0, nerr0 = engine.scalar_mix_plan(ins[0], d_roff, d_voff)
+        assert (lay0.n_gates, lay0.n_vars, nerr0) == (G, V, len(zeros))
+        engine.scalar_mix_emit(*ins, d_roff, d_voff, cols, res, 3, 5, 0)
+        torch.cuda.synchronize()
+    lay, nerr = engine.plan_result()
+    assert (lay.n_gates, lay.n_vars, nerr) == (G, V, len(zeros))
+    assert torch.equal(d_roff, dev(roff)) and torch.equal(d_voff, dev(voff))
+    threads = oracle_threads()
+    chunk = 1 << 16
+    results = []
+
+    def produce(lo, hi, out):
+        results.append(po.scalar_mix_fast(v, y, s, a, b, plan, lo, hi, var_base=5, zero_var=0, threads=threads, out=out)["result_vars"])
+
+    n_chunks, words = stream_compare(cols, lambda i: (int(roff[i]), int(voff[i])), produce, chunk, chunk * 10, chunk * 15, n_items=batch)
+    assert words * 8 == G * 184 + V * 32
+    assert torch.equal(res, dev(np.concatenate(results)))
+    for name in SEL:
+        assert bool((getattr(big, name)[G:] == -1).all()), name
+    for name in WIRES:
+        t = getattr(big, name)
+        assert int(t[0]) == -1 and bool((t[1 + G:] == -1).all()), name
+    assert bool((big.var_values[V:] == -1).all())
+    del big, cols, produce
+    release_hbm()

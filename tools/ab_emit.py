@@ -18,6 +18,9 @@ VARIANTS = {
     "r2": None,  # round 2's library, built by hand from `git archive 74bdd0d` (not rebuilt by `build`)
     "base": [],
     "prev": None,  # the commit before, built by hand (git stash; build(out=...); git stash pop)
+    # round 5: row tiles per workgroup that the fused mix's arithmetic launch writes while it inverts (the library: 2)
+    "fb": ["-DPG_EXP_FWD_BURST"], "fb_stamps": ["-DPG_EXP_FWD_BURST", "-DPG_MIX_STAMPS"],
+    "et0": ["-DPG_MIX_EARLY_TILES=0"], "et1": ["-DPG_MIX_EARLY_TILES=1"], "et3": ["-DPG_MIX_EARLY_TILES=3"], "et4": ["-DPG_MIX_EARLY_TILES=4"],
     # the fused mix (C3)
     "mix_stamps": ["-DPG_MIX_STAMPS"],  # timing build for tools/mix_phases.py
     "mix_stamps_nomem": ["-DPG_MIX_STAMPS", "-DPG_MIX_ABLATE_MEM"],
@@ -86,6 +89,7 @@ PATCHES = {  # builds that are NOT in the sources: a patch (tools/patches/) appl
     "f3_stamps": "r04_mix_experiments.patch", "stag50": "r04_mix_experiments.patch", "stag100": "r04_mix_experiments.patch",
     "rows128": "r04_mix_experiments.patch", "rows512": "r04_mix_experiments.patch", "rowsgrid8": "r04_mix_experiments.patch",
     "rowsgrid12": "r04_mix_experiments.patch", "gen_side": "r04_mix_experiments.patch",
+    "fb": "r05_fwd_burst.patch", "fb_stamps": "r05_fwd_burst.patch",  # round 5: four steps' elements per fetch in the forward pass
 }
 
 

@@ -30,8 +30,14 @@ cc = cols.as_c()
 sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 h = C.c_void_p()
 assert lib.pg_engine_create(0, C.byref(h)) == 0
+two_step = len(sys.argv) > 2 and sys.argv[2] == "twostep"  # the plan as a call of its own, then pg_scalar_mix_batch (no look-back in the arithmetic launch)
 for _ in range(5):
-    assert lib.pg_scalar_mix_planned_batch(h, *[t.data_ptr() for t in ins], chunk, roff.data_ptr(), voff.data_ptr(), None, 3, 5, 0,
-                                           C.byref(cc), res.data_ptr(), sp) == 0
+    if two_step:
+        assert lib.pg_scalar_mix_plan_async(h, ins[0].data_ptr(), chunk, roff.data_ptr(), voff.data_ptr(), None, sp) == 0
+        assert lib.pg_scalar_mix_batch(h, *[t.data_ptr() for t in ins], chunk, roff.data_ptr(), voff.data_ptr(), 3, 5, 0, C.byref(cc),
+                                       res.data_ptr(), sp) == 0
+    else:
+        assert lib.pg_scalar_mix_planned_batch(h, *[t.data_ptr() for t in ins], chunk, roff.data_ptr(), voff.data_ptr(), None, 3, 5, 0,
+                                               C.byref(cc), res.data_ptr(), sp) == 0
     torch.cuda.synchronize()
 print("done")
