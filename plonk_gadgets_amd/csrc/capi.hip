@@ -1061,9 +1061,9 @@ pg_status pg_scalar_mix_values_batch(pg_engine *e, const pg_scalar *d_v, const p
 }
 
 #if defined(PG_MIX_STAMPS)  // timing build only: ticks (100 MHz) the fused mix's waves spent per phase since the last call; not in the header
-extern "C" int pg_debug_mix_phases(unsigned long long out[8]) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pg::g_mix_phase_ticks), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
-    const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+extern "C" int pg_debug_mix_phases(unsigned long long out[12]) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pg::g_mix_phase_ticks), 12 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    const unsigned long long zero[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     return hipMemcpyToSymbol(HIP_SYMBOL(pg::g_mix_phase_ticks), zero, sizeof zero) == hipSuccess ? 0 : 1;
 }
 #endif

@@ -380,7 +380,7 @@ struct MixPlan {
 constexpr int kMixWaves = 8;
 
 #if defined(PG_MIX_STAMPS)  // timing build (tools/mix_phases.py): time the waves spend in each phase, summed over the launch
-__device__ unsigned long long g_mix_phase_ticks[8];
+__device__ unsigned long long g_mix_phase_ticks[12];
 #define PG_STAMP(k)                                                                                              \
     do {                                                                                                         \
         const unsigned long long now_ = wall_clock64();                                                          \
@@ -397,9 +397,15 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
     __shared__ uint4 s_img[kMixWaves][32 * 15 * 2];
     __shared__ uint64_t s_errs[kMixWaves], s_before;  // PLAN: failing items of the workgroup's waves, and before the workgroup
     __shared__ uint4 s_consts[T_POW * 2];             // the rows' constants (early rows, below)
-    __shared__ uint32_t s_before_ready;               // PLAN: s_before is written (the waves that write early rows wait for it)
+    __shared__ uint32_t s_before_ready;               // PLAN: s_before is written (every wave waits for it before its backward pass)
+    __shared__ uint32_t s_pair_in[4], s_pair_out[4];  // pair p: the upper wave's products are in LDS / the lower wave's answer is
+    __shared__ uint32_t s_arrived;                    // PLAN: waves whose count of failing items is in s_errs
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 31;
     const bool bside = lane >= 32;  // the a - b side of item p
+    if (threadIdx.x < 4) s_pair_in[threadIdx.x] = s_pair_out[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_arrived = s_before_ready = 0;
+    fill_common_table(s_consts, nullptr, threadIdx.x, T_POW);
+    __syncthreads();  // (the only workgroup barrier of the launch: the flags and the rows' constants, before any wave's first load)
     const uint64_t gw = (uint64_t)blockIdx.x * kMixWaves + wave;  // the wave's index in the launch
     const uint64_t chunk0 = gw * 32 * ipl;                         // the wave's first item
     // (the launch's last workgroup may hold waves without items: they take no step, but stand at the two barriers)
@@ -495,10 +501,16 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
     // eight waves (14 multiplications by a single wave first) measured 15 us slower.
     Fr accinv;
     {
+        // Waves w and w + 4 -- the two that share a SIMD -- share ONE inversion (above), and that pair is all that has to meet:
+        // the upper wave hands its lanes' products over through its own image area and raises a flag, the lower one inverts
+        // the product of both, hands the upper wave's inverse back and raises another.  No workgroup barrier: a pair whose
+        // forward passes end early inverts early and is in its backward pass -- which is bound by HBM -- while slower pairs
+        // still invert with HBM idle (a barrier made every wave wait 19 us on average for the workgroup's slowest).  PLAN: the one
+        // thing all waves do wait for is the count of failing items before the workgroup (s_before_ready), which the look-back
+        // delivers ~35 us after the workgroup's last forward pass -- every workgroup before this one has to be through its own.
         static_assert(kMixWaves == 8, "waves w and w + 4 pair up");
-        uint4 *xch = &s_img[0][0];  // [pair][half][lane]
         const uint32_t pair = wave & 3;
-        uint4 *slot = xch + (pair * 2) * 64 + lane;
+        uint4 *slot = &s_img[4 + pair][0] + lane;  // [half][lane] in the upper wave's image area (idle until its backward pass)
         auto get = [&]() {
             FrVec t;
             t.v[0] = slot[0];
@@ -511,19 +523,38 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
             slot[0] = t.v[0];
             slot[64] = t.v[1];
         };
-        if (wave >= 4) set(acc);
-        if (PLAN && lane == 0) s_errs[wave] = errs;  // (a wave without items counted none)
-        if (O.early_tiles) {
-            fill_common_table(s_consts, nullptr, threadIdx.x, T_POW);
-            if (threadIdx.x == 0) s_before_ready = 0;
+        auto raise = [&](uint32_t *flag) {  // (the wave's LDS writes above are ordered before it)
+            if (lane == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        auto await = [&](uint32_t *flag, uint32_t want) {
+            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(4);
+        };
+#if defined(PG_MIX_STAMPS)
+        const unsigned long long after_b1_ = wall_clock64();
+#endif
+        if (PLAN && lane == 0) {
+            s_errs[wave] = errs;  // (a wave without items counted none)
+            __hip_atomic_fetch_add(&s_arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        __syncthreads();
         if (wave < 4) {
+            await(&s_pair_in[pair], 1);
+#if defined(PG_MIX_STAMPS)
+            const unsigned long long t0_ = wall_clock64();
+            if (lane == 0) atomicAdd(&g_mix_phase_ticks[4], t0_ - after_b1_);  // a lower wave's wait for its partner's products
+#endif
             const Fr other = get();
             const Fr t = fr_invert_or_zero(fr_mul(acc, other));  // (a product of non-zero elements, or mont(1))
             accinv = fr_mul(t, other);
             set(fr_mul(t, acc));
-        } else if (PLAN && wave == kMixWaves - 1) {
+            raise(&s_pair_out[pair]);
+#if defined(PG_MIX_STAMPS)
+            if (lane == 0) atomicAdd(&g_mix_phase_ticks[5], wall_clock64() - t0_);  // the inversion itself (lower waves)
+#endif
+        } else {
+            set(acc);
+            raise(&s_pair_in[pair]);
+            if (PLAN && wave == kMixWaves - 1) {
+                await(&s_arrived, kMixWaves);  // every wave's count is in s_errs
             // PLAN: failing items in the WORKGROUPS before this one, by the last wave while it would only wait for its
             // inverse: the decoupled look-back of the plan kernels, one word per workgroup, 64 predecessors per round.
             // (Per wave instead -- 2048 words, every wave adding up its own predecessors ahead of the inversion -- it took
@@ -573,7 +604,7 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
                 for (uint32_t j = lane; j < P.nwaves; j += 64) __hip_atomic_exchange(&P.agg[j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (lane == 0) __hip_atomic_exchange(&P.agg[P.cap], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-        }
+            }
         // ---- early rows: what the waiting waves do meanwhile ------------------------------------------------------------
         // The inversions take ~50 us during which nothing moves: four of the workgroup's eight waves compute a chain of dependent
         // instructions, the other four wait, HBM is idle.  A store stream needs neither many waves nor the multiplier (four
@@ -581,7 +612,7 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
         // cost it 5 us: tools/probes/store_occupancy.hip, hidden_stores.hip) -- so the waiting waves write the rows of the first
         // early_tiles row tiles of the workgroup's items, and the rows launch that follows leaves those alone (emit.hpp,
         // early_rows_candidate: both sides decide from the same thing, "no item of the span stopped early").
-        if (O.early_tiles && wave >= 4) {
+        if (O.early_tiles) {
             using GD = ScalarMixGD;
             constexpr uint32_t W = GD::kRowsW, R = GD::kUniformRows, VV = GD::kUniformVars;
             const uint64_t s0 = (uint64_t)blockIdx.x * O.early_span;
@@ -590,12 +621,14 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
                 bool full;
                 uint64_t row0, var0;
                 if constexpr (PLAN) {
+                    await(&s_before_ready, 1);  // (implies every wave's count: the look-back waited for them)
                     uint64_t mine = 0;
 #pragma unroll
                     for (int w = 0; w < kMixWaves; w++) mine += s_errs[w];
                     full = mine == 0;
-                    if (full && wave != kMixWaves - 1)  // (the last wave has just written it itself)
-                        while (__hip_atomic_load(&s_before_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(8);
+#if defined(PG_MIX_STAMPS)
+                    if (lane == 0) atomicAdd(&g_mix_phase_ticks[7], wall_clock64() - after_b1_);  // until the prefix is known (upper waves)
+#endif
                     const uint64_t before = full ? s_before : 0;
                     row0 = R * s0 - 2 * before;
                     var0 = VV * s0 - 2 * before;
@@ -609,18 +642,29 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
                     uint4 v[5];
                     periodic_lane_selectors<GD>(A, s_consts, tid, v);
                     const uint32_t tiles = (uint32_t)((s1 - s0) / W) < O.early_tiles ? (uint32_t)((s1 - s0) / W) : O.early_tiles;  // complete tiles only
-                    for (uint32_t t = 0; t < tiles; t++)
+                    for (uint32_t t = 0; t < tiles; t++) {
+#if defined(PG_MIX_STAMPS)
+                        const unsigned long long t0_ = wall_clock64();
+#endif
                         periodic_tile_rows<GD>(A, O, v, tid, s0 + (uint64_t)t * W, W, row0 + (uint64_t)t * W * R, var0 + (uint64_t)t * W * VV);
+#if defined(PG_MIX_STAMPS)
+                        if (lane == 0) atomicAdd(&g_mix_phase_ticks[8 + (t < 3 ? t : 3)], wall_clock64() - t0_);  // issuing tile t's stores
+#endif
+                    }
                 }
             }
         }
-        __syncthreads();
-        if (wave >= 4) accinv = get();
+#if defined(PG_MIX_STAMPS)
+            if (lane == 0) atomicAdd(&g_mix_phase_ticks[6], wall_clock64() - after_b1_);  // look-back / early rows (upper waves)
+#endif
+            await(&s_pair_out[pair], 1);
+            accinv = get();
+        }
         if constexpr (PLAN) {  // before this wave = before the workgroup + in its earlier waves
+            await(&s_before_ready, 1);
             errs_before = s_before;
             for (uint32_t w = 0; w < wave; w++) errs_before += s_errs[w];
         }
-        __syncthreads();  // the exchange area is the images' from here on
     }
 
     PG_STAMP(2);  // inversion (and waiting for it)

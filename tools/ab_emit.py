@@ -20,6 +20,7 @@ VARIANTS = {
     "prev": None,  # the commit before, built by hand (git stash; build(out=...); git stash pop)
     # round 5: row tiles per workgroup that the fused mix's arithmetic launch writes while it inverts (the library: 2)
     "fb": ["-DPG_EXP_FWD_BURST"], "fb_stamps": ["-DPG_EXP_FWD_BURST", "-DPG_MIX_STAMPS"],
+    "et2": ["-DPG_MIX_EARLY_TILES=2"],
     "et0": ["-DPG_MIX_EARLY_TILES=0"], "et1": ["-DPG_MIX_EARLY_TILES=1"], "et3": ["-DPG_MIX_EARLY_TILES=3"], "et4": ["-DPG_MIX_EARLY_TILES=4"],
     # the fused mix (C3)
     "mix_stamps": ["-DPG_MIX_STAMPS"],  # timing build for tools/mix_phases.py
@@ -208,6 +209,11 @@ def run_c3_b2b(log2_chunk=20, steps=40, rounds=5):
             torch.cuda.synchronize()
             e0.record(stream)
             for _ in range(steps):
+                if os.environ.get("C3_FORM") == "twostep":  # the plan as a call of its own (a plan kernel, no look-back in the arithmetic launch)
+                    assert lib.pg_scalar_mix_plan_async(h, ins[0].data_ptr(), chunk, roff.data_ptr(), voff.data_ptr(), None, sp) == 0
+                    assert lib.pg_scalar_mix_batch(h, *[t.data_ptr() for t in ins], chunk, roff.data_ptr(), voff.data_ptr(), 3, 5, 0,
+                                                   C.byref(cc), res.data_ptr(), sp) == 0
+                    continue
                 assert lib.pg_scalar_mix_planned_batch(h, *[t.data_ptr() for t in ins], chunk, roff.data_ptr(), voff.data_ptr(), None,
                                                        3, 5, 0, C.byref(cc), res.data_ptr(), sp) == 0
             e1.record(stream)

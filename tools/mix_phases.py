@@ -29,7 +29,7 @@ cols = pg.Columns.allocate(10 * n, 15 * n, dev)
 cc = cols.as_c()
 h = C.c_void_p()
 assert lib.pg_engine_create(0, C.byref(h)) == 0
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 12)()
 ipl = int(os.environ.get("PG_EXP_MIX_IPL", "16"))
 for rep in range(6):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -44,6 +44,13 @@ for rep in range(6):
             w = 2048
             print("forward us per wave: first fetches + wait %.1f | steps 0-3 %.1f | 4-7 %.1f | 8-11 %.1f | 12-15 %.1f ; inversion %.1f backward %.1f" % (
                 out[4] / w / 100, out[5] / w / 100, out[6] / w / 100, out[7] / w / 100, out[0] / w / 100, out[2] / w / 100, out[3] / w / 100))
+        elif os.environ.get("MIX_DETAIL"):  # round 5's stamps: the wait at the first barrier, the inversion itself, the waiting waves' work
+            waves = (n + 32 * ipl - 1) // (32 * ipl)
+            print("us per wave: forward %.1f | inversion phase %.1f = wait at the first barrier %.1f + [lower waves: inversion %.1f | upper waves: look-back / early rows %.1f] + second barrier | backward %.1f   (the call %.1f us)"
+                  % (out[0] / waves / 100, out[2] / waves / 100, out[4] / waves / 100, out[5] / (waves / 2) / 100, out[6] / (waves / 2) / 100,
+                     out[3] / waves / 100, 1e3 * e0.elapsed_time(e1)))
+            print("   upper waves: the prefix known after %.1f us; issuing the stores of tile 0 / 1 / 2 / 3+: %.1f / %.1f / %.1f / %.1f us"
+                  % tuple(out[k] / (waves / 2) / 100 for k in (7, 8, 9, 10, 11)))
         elif any(out[k] for k in range(4, 8)):  # a staggered build (PG_EXP_STAGGER_TICKS): even / odd workgroups apart
             for g, name in ((0, "even"), (4, "odd ")):
                 print("us per wave (%s workgroups): forward %.1f  look-back %.1f  inversion %.1f  backward %.1f" % ((name,) + tuple(out[g + k] / 1024 / 100.0 for k in range(4))))
