@@ -58,6 +58,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=0, help="items timed on the CPU oracle (0: workload default)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C4 measurements after the headline")
+    ap.add_argument("--no-fill", action="store_true", help="skip the bare-fill comparison launches (profiling runs: only the workload's kernels)")
     ap.add_argument("--allgather-log2-chunk", type=int, default=12, help="N>1: witnesses per rank per gathered chunk")
     ap.add_argument("--allgather-timeout", type=float, default=240.0, help="N>1: seconds before the gather-inclusive sample is abandoned")
     ap.add_argument("--allgather-chunks", type=int, default=8, help="N>1: chunks in the gather-inclusive sample (0: skip)")
@@ -723,7 +724,7 @@ def main():
         print("launch ms:", " ".join("%.2f" % t for t in kernel_ms), file=sys.stderr)
     constraints = world * wl.rows_per_launch * wl.n_chunks * args.steps
     value = constraints / elapsed
-    roofline = roofline_with_fill(wl, kernel_ms) if world == 1 else roofline_of(wl, kernel_ms)
+    roofline = roofline_with_fill(wl, kernel_ms) if world == 1 and not args.no_fill else roofline_of(wl, kernel_ms)
     config = {"workload": wl.desc, "items_per_gpu": wl.batch, "items_per_launch": wl.chunk,
               "launches_per_step": wl.n_chunks,
               "sharding": "contiguous witness ranges per rank at global numbering, no data-path collective"}

@@ -319,7 +319,7 @@ struct ScalarMixGD {
 //   the wave lays the variables of its 32 items out in a private LDS image exactly as they lie in memory (ragged: an item
 //   that stopped at its error has 13; ballots give every lane its item's offset), and copies the image out linearly -- 16
 //   bytes per lane, every wave store one contiguous KiB.
-// Waves meet only around the inversion (one per pair of waves, below).  Two lanes per item halve what a lane carries (half an
+// Waves meet only around the inversion, and only in PAIRS (one inversion per pair of waves, two LDS flags: below).  Two lanes per item halve what a lane carries (half an
 // item and its prefetch: 226 registers with the forward pass's four prefetch sets) and make every load and store of a step
 // a full-width access.  The launch is built for TWO waves per SIMD (amdgpu_num_vgpr(256), 120 KB of LDS = one workgroup per
 // CU): the multiplier needs two (one wave alone issues every other cycle), and the rows launches do NOT run beside it --
@@ -494,11 +494,10 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
     // ---- one inversion per PAIR of waves --------------------------------------------------------------------------
     // The inversion is 20 k vector instructions against the 25 k of everything else a wave does here, and a wave pays it
     // whether one lane wants an inverse or sixty-four.  Waves w and w + 4 of the workgroup -- the two that share a SIMD --
-    // therefore share one: the upper wave hands its lanes' products to the lower one (through the LDS that will hold the
-    // images), which multiplies them to its own, inverts the product and takes the two inverses apart again (three
-    // multiplications); the upper wave waits at a barrier meanwhile.  Every SIMD then runs exactly one inversion, alone --
-    // the chain of dependent instructions that it is gains nothing from a second wave beside it, and one inversion for all
-    // eight waves (14 multiplications by a single wave first) measured 15 us slower.
+    // therefore share one: the upper wave hands its lanes' products to the lower one (through LDS), which multiplies them to
+    // its own, inverts the product and takes the two inverses apart again (three multiplications).  Every SIMD then runs exactly
+    // one inversion, alone -- the chain of dependent instructions that it is gains nothing from a second wave beside it, and one
+    // inversion for all eight waves (14 multiplications by a single wave first) measured 15 us slower.
     Fr accinv;
     {
         // Waves w and w + 4 -- the two that share a SIMD -- share ONE inversion (above), and that pair is all that has to meet:
@@ -555,105 +554,108 @@ __global__ __launch_bounds__(kMixWaves * 64) __attribute__((amdgpu_num_vgpr(PG_M
             raise(&s_pair_in[pair]);
             if (PLAN && wave == kMixWaves - 1) {
                 await(&s_arrived, kMixWaves);  // every wave's count is in s_errs
-            // PLAN: failing items in the WORKGROUPS before this one, by the last wave while it would only wait for its
-            // inverse: the decoupled look-back of the plan kernels, one word per workgroup, 64 predecessors per round.
-            // (Per wave instead -- 2048 words, every wave adding up its own predecessors ahead of the inversion -- it took
-            // every wave 21 us: thirty-two rounds of agent-scope atomics, all waves of the chip at once.)
-            const uint32_t b = blockIdx.x;
-            uint64_t mine = 0;
+                // PLAN: failing items in the WORKGROUPS before this one, by the last wave while it would only wait for its
+                // inverse: the decoupled look-back of the plan kernels, one word per workgroup, 64 predecessors per round.
+                // (Per wave instead -- 2048 words, every wave adding up its own predecessors ahead of the inversion -- it took
+                // every wave 21 us: thirty-two rounds of agent-scope atomics, all waves of the chip at once.)
+                const uint32_t b = blockIdx.x;
+                uint64_t mine = 0;
 #pragma unroll
-            for (int w = 0; w < kMixWaves; w++) mine += s_errs[w];
-            if (lane == 0 && b > 0) __hip_atomic_exchange(&P.agg[b], kAggA | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint64_t before = 0;
-            bool gave_up = false;
-            int64_t back = (int64_t)b - 1;
-            for (bool more = b > 0; more; back -= 64) {
-                const int64_t j = back - (int64_t)lane;
-                unsigned long long w = kAggP;  // before workgroup 0: the empty prefix
-                if (j >= 0) {
-                    w = plan_rmw_read(&P.agg[j]);
-                    for (uint32_t polls = 0; !(w >> 62); w = plan_rmw_read(&P.agg[j])) {
-                        if (++polls > kPlanSpinLimit) { gave_up = true; w = kAggP; break; }
-                        __builtin_amdgcn_s_sleep(1);
+                for (int w = 0; w < kMixWaves; w++) mine += s_errs[w];
+                if (lane == 0 && b > 0) __hip_atomic_exchange(&P.agg[b], kAggA | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint64_t before = 0;
+                bool gave_up = false;
+                int64_t back = (int64_t)b - 1;
+                for (bool more = b > 0; more; back -= 64) {
+                    const int64_t j = back - (int64_t)lane;
+                    unsigned long long w = kAggP;  // before workgroup 0: the empty prefix
+                    if (j >= 0) {
+                        w = plan_rmw_read(&P.agg[j]);
+                        for (uint32_t polls = 0; !(w >> 62); w = plan_rmw_read(&P.agg[j])) {
+                            if (++polls > kPlanSpinLimit) { gave_up = true; w = kAggP; break; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    const uint64_t has_prefix = __ballot((w & kAggP) != 0);
+                    const uint32_t first = has_prefix ? (uint32_t)__ffsll((unsigned long long)has_prefix) - 1 : 64u;  // the nearest one
+                    before += wave_sum(lane <= first ? w & 0xffffffffull : 0);
+                    more = has_prefix == 0;
+                }
+                if (lane == 0) {
+                    if (gave_up) P.host->pad = 1;
+                    __hip_atomic_exchange(&P.agg[b], kAggP | (before + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_before = before;
+                    __hip_atomic_store(&s_before_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (b + 1 == P.nwaves) {  // the workgroup of the last item: the totals
+                        const uint64_t e_all = before + mine;
+                        P.row_off[O.batch] = 10 * O.batch - 2 * e_all;
+                        P.var_off[O.batch] = 15 * O.batch - 2 * e_all;
+                        P.host->n_gates = 10 * O.batch - 2 * e_all;
+                        P.host->n_vars = 15 * O.batch - 2 * e_all;
+                        P.host->errs = (uint32_t)e_all;
                     }
                 }
-                const uint64_t has_prefix = __ballot((w & kAggP) != 0);
-                const uint32_t first = has_prefix ? (uint32_t)__ffsll((unsigned long long)has_prefix) - 1 : 64u;  // the nearest one
-                before += wave_sum(lane <= first ? w & 0xffffffffull : 0);
-                more = has_prefix == 0;
-            }
-            if (lane == 0) {
-                if (gave_up) P.host->pad = 1;
-                __hip_atomic_exchange(&P.agg[b], kAggP | (before + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_before = before;
-                __hip_atomic_store(&s_before_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (b + 1 == P.nwaves) {  // the workgroup of the last item: the totals
-                    const uint64_t e_all = before + mine;
-                    P.row_off[O.batch] = 10 * O.batch - 2 * e_all;
-                    P.var_off[O.batch] = 15 * O.batch - 2 * e_all;
-                    P.host->n_gates = 10 * O.batch - 2 * e_all;
-                    P.host->n_vars = 15 * O.batch - 2 * e_all;
-                    P.host->errs = (uint32_t)e_all;
+                // the last workgroup to get here has every look-back behind it: the words go back to zero
+                unsigned long long done = 0;
+                if (lane == 0) done = __hip_atomic_fetch_add(&P.agg[P.cap], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                done = __shfl(done, 0, 64);
+                if (done == P.nwaves - 1) {
+                    for (uint32_t j = lane; j < P.nwaves; j += 64) __hip_atomic_exchange(&P.agg[j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) __hip_atomic_exchange(&P.agg[P.cap], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            // the last workgroup to get here has every look-back behind it: the words go back to zero
-            unsigned long long done = 0;
-            if (lane == 0) done = __hip_atomic_fetch_add(&P.agg[P.cap], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            done = __shfl(done, 0, 64);
-            if (done == P.nwaves - 1) {
-                for (uint32_t j = lane; j < P.nwaves; j += 64) __hip_atomic_exchange(&P.agg[j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (lane == 0) __hip_atomic_exchange(&P.agg[P.cap], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            }
-        // ---- early rows: what the waiting waves do meanwhile ------------------------------------------------------------
-        // The inversions take ~50 us during which nothing moves: four of the workgroup's eight waves compute a chain of dependent
-        // instructions, the other four wait, HBM is idle.  A store stream needs neither many waves nor the multiplier (four
-        // waves per CU with a tight store loop write at the chip's rate, and 240 MB written beside a 50-us arithmetic phase
-        // cost it 5 us: tools/probes/store_occupancy.hip, hidden_stores.hip) -- so the waiting waves write the rows of the first
-        // early_tiles row tiles of the workgroup's items, and the rows launch that follows leaves those alone (emit.hpp,
-        // early_rows_candidate: both sides decide from the same thing, "no item of the span stopped early").
-        if (O.early_tiles) {
-            using GD = ScalarMixGD;
-            constexpr uint32_t W = GD::kRowsW, R = GD::kUniformRows, VV = GD::kUniformVars;
-            const uint64_t s0 = (uint64_t)blockIdx.x * O.early_span;
-            if (s0 < O.batch) {
-                const uint64_t s1 = s0 + O.early_span < O.batch ? s0 + O.early_span : O.batch;
-                bool full;
-                uint64_t row0, var0;
-                if constexpr (PLAN) {
-                    await(&s_before_ready, 1);  // (implies every wave's count: the look-back waited for them)
-                    uint64_t mine = 0;
+            // ---- early rows: what the waiting waves do meanwhile --------------------------------------------------------
+            // A pair's inversion takes ~42 us during which nothing of the pair moves: the lower wave computes a chain of dependent
+            // instructions, the upper one waits, and HBM is idle whenever most pairs are there.  A store stream needs neither
+            // many waves nor the multiplier (four waves per CU with a tight store loop write at the chip's rate, and 240 MB
+            // written beside a 50-us arithmetic phase cost it 5 us: tools/probes/store_occupancy.hip, hidden_stores.hip) -- so
+            // the waiting waves write the rows of the first early_tiles row tiles of the workgroup's items, and the rows launch
+            // that follows leaves those alone (emit.hpp, early_rows_candidate: both sides decide from the same thing, "no item
+            // of the span stopped early").  PLAN: where those rows lie is only known with the prefix (~32-35 us after the
+            // workgroup's last forward pass), which leaves room for ONE tile; a second one costs the launch more than it saves
+            // the rows launch (profiles/NOTES_r05.md).
+            if (O.early_tiles) {
+                using GD = ScalarMixGD;
+                constexpr uint32_t W = GD::kRowsW, R = GD::kUniformRows, VV = GD::kUniformVars;
+                const uint64_t s0 = (uint64_t)blockIdx.x * O.early_span;
+                if (s0 < O.batch) {
+                    const uint64_t s1 = s0 + O.early_span < O.batch ? s0 + O.early_span : O.batch;
+                    bool full;
+                    uint64_t row0, var0;
+                    if constexpr (PLAN) {
+                        await(&s_before_ready, 1);  // (implies every wave's count: the look-back waited for them)
+                        uint64_t mine = 0;
 #pragma unroll
-                    for (int w = 0; w < kMixWaves; w++) mine += s_errs[w];
-                    full = mine == 0;
+                        for (int w = 0; w < kMixWaves; w++) mine += s_errs[w];
+                        full = mine == 0;
 #if defined(PG_MIX_STAMPS)
-                    if (lane == 0) atomicAdd(&g_mix_phase_ticks[7], wall_clock64() - after_b1_);  // until the prefix is known (upper waves)
+                        if (lane == 0) atomicAdd(&g_mix_phase_ticks[7], wall_clock64() - after_b1_);  // until the prefix is known (upper waves)
 #endif
-                    const uint64_t before = full ? s_before : 0;
-                    row0 = R * s0 - 2 * before;
-                    var0 = VV * s0 - 2 * before;
-                } else {
-                    row0 = O.row_off[s0];
-                    var0 = O.var_off[s0];
-                    full = O.row_off[s1] - row0 == (s1 - s0) * R;
-                }
-                if (full) {
-                    const uint32_t tid = (wave - 4) * 64 + lane;
-                    uint4 v[5];
-                    periodic_lane_selectors<GD>(A, s_consts, tid, v);
-                    const uint32_t tiles = (uint32_t)((s1 - s0) / W) < O.early_tiles ? (uint32_t)((s1 - s0) / W) : O.early_tiles;  // complete tiles only
-                    for (uint32_t t = 0; t < tiles; t++) {
+                        const uint64_t before = full ? s_before : 0;
+                        row0 = R * s0 - 2 * before;
+                        var0 = VV * s0 - 2 * before;
+                    } else {
+                        row0 = O.row_off[s0];
+                        var0 = O.var_off[s0];
+                        full = O.row_off[s1] - row0 == (s1 - s0) * R;
+                    }
+                    if (full) {
+                        const uint32_t tid = (wave - 4) * 64 + lane;
+                        uint4 v[5];
+                        periodic_lane_selectors<GD>(A, s_consts, tid, v);
+                        const uint32_t tiles = (uint32_t)((s1 - s0) / W) < O.early_tiles ? (uint32_t)((s1 - s0) / W) : O.early_tiles;  // complete tiles only
+                        for (uint32_t t = 0; t < tiles; t++) {
 #if defined(PG_MIX_STAMPS)
-                        const unsigned long long t0_ = wall_clock64();
+                            const unsigned long long t0_ = wall_clock64();
 #endif
-                        periodic_tile_rows<GD>(A, O, v, tid, s0 + (uint64_t)t * W, W, row0 + (uint64_t)t * W * R, var0 + (uint64_t)t * W * VV);
+                            periodic_tile_rows<GD>(A, O, v, tid, s0 + (uint64_t)t * W, W, row0 + (uint64_t)t * W * R, var0 + (uint64_t)t * W * VV);
 #if defined(PG_MIX_STAMPS)
-                        if (lane == 0) atomicAdd(&g_mix_phase_ticks[8 + (t < 3 ? t : 3)], wall_clock64() - t0_);  // issuing tile t's stores
+                            if (lane == 0) atomicAdd(&g_mix_phase_ticks[8 + (t < 3 ? t : 3)], wall_clock64() - t0_);  // issuing tile t's stores
 #endif
+                        }
                     }
                 }
             }
-        }
 #if defined(PG_MIX_STAMPS)
             if (lane == 0) atomicAdd(&g_mix_phase_ticks[6], wall_clock64() - after_b1_);  // look-back / early rows (upper waves)
 #endif

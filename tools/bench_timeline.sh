@@ -5,7 +5,7 @@ W=${1:-c3}; shift
 for kv in "$@"; do export "$kv"; done
 export TMPDIR=/tmp
 D=/tmp/bt_$$
-rocprofv3 --kernel-trace --output-format csv -d $D -o t -- python3 bench.py --workload $W --steps 5 --warmup 1 --no-cpu --no-secondary > /dev/null 2>&1 || exit 1
+rocprofv3 --kernel-trace --output-format csv -d $D -o t -- python3 bench.py --workload $W --steps 5 --warmup 1 --no-cpu --no-secondary --no-fill > /dev/null 2>&1 || exit 1
 python3 - "$(find $D -name '*kernel_trace.csv' | head -1)" <<'PY'
 import csv, sys
 ks = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 D=/tmp/bt_x
 rm -rf "$D"
 cd "$GRAFT_REPO_ROOT"
-rocprofv3 --kernel-trace --output-format csv -d "$D" -o t -- python3 bench.py --workload c3 --steps 6 --warmup 2 --no-cpu --no-secondary > /dev/null 2>&1 || exit 1
+rocprofv3 --kernel-trace --output-format csv -d "$D" -o t -- python3 bench.py --workload c3 --steps 6 --warmup 2 --no-cpu --no-secondary --no-fill > /dev/null 2>&1 || exit 1
 python3 - "$(find "$D" -name '*kernel_trace.csv' | head -1)" <<'PY'
 import csv, sys
 ks = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))

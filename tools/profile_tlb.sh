@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/tlb_$R
 mkdir -p $OUT
 for w in c2 c3 c4; do
-  ARGS="bench.py --workload $w --log2-batch 19 --steps 2 --warmup 1 --no-cpu --no-secondary"
+  ARGS="bench.py --workload $w --log2-batch 19 --steps 2 --warmup 1 --no-cpu --no-secondary --no-fill"
   timeout -k 10 300 rocprofv3 --pmc TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE --output-format csv -d $OUT/$w -- python3 $ARGS > $OUT/$w.log 2>&1 || echo "pass failed for $w"
 done
 python3 - <<PY
