@@ -558,11 +558,15 @@ def next_rows_secondary(eng, dev, log2_batch: int, steps: int):
                                        "kernel": "pg::materialize_items_kernel<true> (one launch per batched call: constant columns, w_4, three "
                                                  "wire-value columns from an LDS window of the items' Variables, wires in closed form)"}}
     med, lo, hi = timed(lambda: lib.pg_composer_permutation(comp._h, padded, sigma.data_ptr()))
-    pb = 24 * n + 32 * padded
+    # algorithmic bytes: four sigma columns of 8 B per PADDED row written; the rows of a ladder gadget are linked in closed form (nothing
+    # read: csrc/permutation.hpp, perm_ladder_kernel).  (Rounds 1-4 read the 24 B of wire indices per row and counted them.)
+    pb = 32 * padded
     out["permutation"] = {"ms": {"min": lo, "median": med, "max": hi}, "rows_per_s": n / (med / 1e3),
                           "roofline": {"bound": "hbm", "achieved": pb / (med / 1e3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                        "frac": pb / (med / 1e3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": pb,
-                                       "kernel": "pg::perm_item_kernel + perm_identity_kernel (+ the sparse list's sort)"}}
+                                       "frac_with_the_wire_reads_of_rounds_1_to_4": (pb + 24 * n) / (med / 1e3) / 1e9 / HBM_PEAK_GBPS,
+                                       "kernel": "pg::perm_ladder_kernel (sigma of the ladder gadgets' rows in closed form) + perm_identity_kernel "
+                                                 "(the padding) (+ perm_gap_kernel and the sparse list's sort for the rows of single calls)"}}
     del comp, t, sigma
     torch.cuda.empty_cache()
     return out

@@ -196,9 +196,6 @@ __host__ __device__ inline uint32_t perm_local_lds_bytes(uint32_t L, uint32_t V)
     return 4 * V + 2 * (V + 2) + 2 * (3 * L + 3 * L + L) + L + 16;
 }
 
-// CLOSED: the segment's wires in closed form (PermSeg::wire_kind, a uniform ladder gadget): the item's 3L Variables are computed,
-// not read back -- 24 of the 56 bytes the pass moves per row; only a witness allocated elsewhere is read from its wire column
-template <bool CLOSED>
 __global__ __launch_bounds__(kThreads, 7) void perm_item_kernel(const PermCtx X, const PermSeg S, uint64_t groups, const PermSparse Q,
                                                             uint64_t *sigma) {
     extern __shared__ uint32_t perm_lds[];
@@ -223,20 +220,8 @@ __global__ __launch_bounds__(kThreads, 7) void perm_item_kernel(const PermCtx X,
 #pragma unroll
             for (uint32_t u = 0; u < kPermRowsPerThread; u++) {
                 const uint32_t r = rb + u * kThreads + tid;
-                if constexpr (CLOSED) {
-                    uint32_t rr = r < L ? r : 0, vb = 0;
-                    for (; rr >= S.L; rr -= S.L) vb += S.V;  // (a group of small items: which one)
-                    uint32_t o3[3];
-                    seg_wire_offsets(S.wire_kind, S.wire_n, rr, o3);
 #pragma unroll
-                    for (uint32_t w = 0; w < 3; w++) {
-                        var[u][w] = v0 + vb + o3[w];
-                        if (o3[w] == kWitnessWire) var[u][w] = X.C.w[w][g0 + (r < L ? r : 0)];
-                    }
-                } else {
-#pragma unroll
-                    for (uint32_t w = 0; w < 3; w++) var[u][w] = r < L ? X.C.w[w][g0 + r] : 0;
-                }
+                for (uint32_t w = 0; w < 3; w++) var[u][w] = r < L ? X.C.w[w][g0 + r] : 0;
             }
 #pragma unroll
             for (uint32_t u = 0; u < kPermRowsPerThread; u++) {
@@ -327,6 +312,199 @@ __global__ __launch_bounds__(kThreads, 7) void perm_item_kernel(const PermCtx X,
                 if (s < kPermDone) sigma[perm_encode(g0 + r, w, X.padded_n)] = perm_encode(g0 + (s >> 2), s & 3, X.padded_n);
             }
         __syncthreads();
+    }
+}
+
+// ---- sigma of a ladder gadget's rows in closed form --------------------------------------------------------------------------
+// For the uniform ladder gadgets (PermSeg::wire_kind) not only the wires of a row are a function of its place in its item
+// (seg_wire_offsets) -- so are the CYCLES: which positions hold one Variable, in recording order.  A bound block
+// (range_gadgets.hpp: rows jj = 0 .. 2n + 4 of max_bound / min_bound; Variables T, b_0.., A_0.., U, z, y):
+//     T    (0, o) -> (2n+2, r)                                   b - x, then the right wire of  u = A_n - T
+//     A_0  (1, l) -> (1, r) -> (1, o) -> (3, r)                  its constant row, then the first ladder step
+//     b_i  (2+2i, l) -> (2+2i, r) -> (2+2i, o) -> (3+2i, l)      boolean row, then its ladder step
+//     A_i  (1+2i, o) -> (3+2i, r)      (0 < i < n)               made by step i - 1, used by step i
+//     A_n  (2n+1, o) -> (2n+2, l)
+//     U    (2n+2, o) -> (2n+3, r) -> (2n+4, r) -> (2n+4, o)      z: (2n+3, l) alone      y: (2n+3, o) -> (2n+4, l) [-> the caller's row]
+//     x    (0, l) -> (0, r)            the witness: the item's own first Variable, or one from elsewhere (the sparse list)
+// and every position's successor is the next one of its line, the last one's the first.  The fourth wire of every such row holds
+// zero_var: its successor is the fourth wire of the next row.  One lane per row, nothing read, 32 bytes written per row: the
+// counting sort of perm_item_kernel (3.4 ms of the 4.8 a 270 M-row circuit took) is not needed for these rows.
+// successors of the three positions of block-row jj: (j2[w], w2[w]) in block rows.  Returned mask: bit w = the position is not linked
+// inside the block -- jj = 0: w = 0, 1 hold the witness x; jj = 2n + 2: w = 1 is the END of T's line; jj = 2n + 4: w = 0 the end of y's
+__device__ __forceinline__ uint32_t ladder_block_row(uint32_t jj, uint32_t n, uint32_t j2[3], uint32_t w2[3]) {
+    if (jj >= 2 && jj < 2 * n + 2) {  // the ladder: one classification, the rest is selects (odd and even rows alternate along a wave)
+        const uint32_t i = (jj - 2) >> 1;
+        const bool step = jj & 1, first = i == 0, last = i + 1 >= n;
+        // boolean row (b_i, b_i, b_i): (jj, r), (jj, o), (jj + 1, l)   |   step (b_i, A_i, A_{i+1}): b_i back to its boolean row; A_0's line
+        // ends here, A_i goes back to where it was made; A_{i+1} on to the next step's right wire, A_n to the left wire of u = A_n - T
+        j2[0] = step ? jj - 1 : jj;
+        w2[0] = step ? 0u : 1u;
+        j2[1] = step ? (first ? 1u : jj - 2) : jj;
+        w2[1] = step ? (first ? 0u : 2u) : 2u;
+        j2[2] = step ? (last ? 2 * n + 2 : jj + 2) : jj + 1;
+        w2[2] = step ? (last ? 0u : 1u) : 0u;
+        return 0;
+    }
+    j2[0] = j2[1] = j2[2] = jj;
+    w2[0] = 0; w2[1] = 1; w2[2] = 2;
+    if (jj == 0) {  // (x, x, T)
+        j2[2] = 2 * n + 2; w2[2] = 1;
+        return 3;
+    }
+    if (jj == 1) {  // (A_0, A_0, A_0)
+        w2[0] = 1; w2[1] = 2; j2[2] = 3; w2[2] = 1;
+        return 0;
+    }
+    if (jj == 2 * n + 2) {  // (A_n, T, U)
+        j2[0] = 2 * n + 1; w2[0] = 2; j2[2] = 2 * n + 3; w2[2] = 1;
+        return 2;
+    }
+    if (jj == 2 * n + 3) {  // (z, U, y): z alone on its line
+        j2[1] = 2 * n + 4; w2[1] = 1; j2[2] = 2 * n + 4; w2[2] = 0;
+        return 0;
+    }
+    // jj == 2n + 4: (y, U, U)
+    w2[1] = 2; j2[2] = 2 * n + 2; w2[2] = 2;
+    return 1;
+}
+// successors of the three positions of item-row j of an item of kind `kind`, in item rows; returned mask: bit w = the position holds a
+// Variable created elsewhere (the sparse list links it, or the zero chain if it is zero_var)
+__device__ __forceinline__ uint32_t ladder_row(uint32_t kind, uint32_t n, uint32_t j, uint32_t j2[3], uint32_t w2[3]) {
+    const uint32_t L = 2 * n + 5;
+    if (kind == WIRES_RANGE_CHECK || kind == WIRES_RANGE_CHECK_ALLOCATED) {
+        if (j == 2 * L) {  // (y1, y2, R): the end of either block's y line; R alone
+            j2[0] = 2 * n + 3; w2[0] = 2; j2[1] = L + 2 * n + 3; w2[1] = 2; j2[2] = j; w2[2] = 2;
+            return 0;
+        }
+        const uint32_t blk = j >= L ? 1u : 0u, base = blk * L, jj = j - base;
+        const uint32_t open = ladder_block_row(jj, n, j2, w2);
+#pragma unroll
+        for (int w = 0; w < 3; w++) j2[w] += base;
+        if (jj == 0) {  // x: (0, l) -> (0, r) -> (L, l) -> (L, r) -> (0, l), unless it comes from elsewhere
+            if (kind == WIRES_RANGE_CHECK_ALLOCATED) return 3;
+            j2[0] = j; w2[0] = 1; j2[1] = blk ? 0 : L; w2[1] = 0;
+        } else if (open == 2) { j2[1] = base; w2[1] = 2; }           // T's line closes
+        else if (open == 1) { j2[0] = 2 * L; w2[0] = blk; }          // y goes on to the product row
+        return 0;
+    }
+    if (kind == WIRES_DECOMPOSITION) {  // a block without its row 0, on a witness from elsewhere (T)
+        const uint32_t open = ladder_block_row(j + 1, n, j2, w2);
+#pragma unroll
+        for (int w = 0; w < 3; w++) j2[w] -= 1;
+        if (open == 2) return 2;
+        if (open == 1) { j2[0] = 2 * n + 2; w2[0] = 2; }
+        return 0;
+    }
+    const uint32_t open = ladder_block_row(j, n, j2, w2);  // max_bound
+    if (j == 0) {
+        if (kind == WIRES_MAX_BOUND_ALLOCATED) return 3;
+        j2[0] = 0; w2[0] = 1; j2[1] = 0; w2[1] = 0;
+    } else if (open == 2) { j2[1] = 0; w2[1] = 2; }
+    else if (open == 1) { j2[0] = 2 * n + 3; w2[0] = 2; }
+    return 0;
+}
+
+// wires (bits 0..2) of item-row j that hold a Variable from elsewhere: the witness of an `_allocated` call (x on both input wires of a
+// bound block's first row), the witness of a decomposition (T, the right wire of u = A_n - T)
+__device__ __forceinline__ uint32_t ladder_foreign_wires(uint32_t kind, uint32_t n, uint32_t j) {
+    if (kind == WIRES_RANGE_CHECK_ALLOCATED) return j == 0 || j == 2 * n + 5 ? 3u : 0u;
+    if (kind == WIRES_MAX_BOUND_ALLOCATED) return j == 0 ? 3u : 0u;
+    if (kind == WIRES_DECOMPOSITION) return j == 2 * n + 1 ? 2u : 0u;
+    return 0u;
+}
+
+constexpr uint32_t kPermLadderRows = 8192;  // rows per workgroup piece (a multiple of 2 * kThreads)
+__global__ __launch_bounds__(kThreads) void perm_ladder_kernel(const PermCtx X, const PermSeg S, const PermSparse Q, uint64_t *sigma) {
+    const uint32_t lane = threadIdx.x & 63, kind = S.wire_kind, n = S.wire_n;
+    // a lane takes the TWO gates 2k, 2k + 1 (16 bytes of each of sigma's four columns: one store each where sigma is 16-byte aligned)
+    const uint64_t first = S.gate_base & ~1ull, total = S.gate_end - first;  // (rows counted from the even gate at or before the segment's first)
+    const bool wide = (reinterpret_cast<uintptr_t>(sigma) & 15) == 0 && !(X.padded_n & 1);
+    // wire * padded_n + gate: a shift when padded_n is a power of two (it is for whoever pads as dusk-plonk does) -- the successor's
+    // wire is data, so the product cannot be hoisted, and a 64 x 64-bit multiplication per position is most of what a lane would do
+    const bool pow2 = (X.padded_n & (X.padded_n - 1)) == 0;
+    const uint32_t sh = 63u - (uint32_t)__clzll((long long)X.padded_n);
+    auto enc = [&](uint64_t gate, uint32_t wire) { return pow2 ? ((uint64_t)wire << sh) + gate : perm_encode(gate, wire, X.padded_n); };
+    // which of wires 0..2 of gate g (item-row j) hold zero_var: only a witness from elsewhere can
+    auto zero_wires = [&](uint64_t g, uint32_t j) {
+        uint32_t z = 0;
+        for (uint32_t m = ladder_foreign_wires(kind, n, j); m; m &= m - 1) {
+            const uint32_t w = (uint32_t)__ffs((int)m) - 1;
+            if (X.C.w[w][g] == X.zero_var) z |= 1u << w;
+        }
+        return z;
+    };
+    for (uint64_t base = (uint64_t)blockIdx.x * kPermLadderRows; base < total; base += (uint64_t)gridDim.x * kPermLadderRows) {
+        // item and item-row of the piece's first gate (one wide division per piece; the rows' own are 32-bit)
+        const uint64_t g_first = first + base, rel = g_first < S.gate_base ? 0 : g_first - S.gate_base;
+        const uint64_t item0 = rel / S.L;
+        const uint32_t j0 = (uint32_t)(rel - item0 * S.L), skip = (uint32_t)(g_first < S.gate_base ? S.gate_base - g_first : 0);
+        for (uint32_t t = 2 * threadIdx.x; t < kPermLadderRows; t += 2 * kThreads) {  // (whole waves: the ballot below)
+            uint64_t out[4][2];
+            uint32_t foreign[2] = {0, 0};
+            bool live[2];
+#pragma unroll
+            for (uint32_t h = 0; h < 2; h++) {
+                const uint64_t g = g_first + t + h;
+                live[h] = g >= S.gate_base && g < S.gate_end;
+                const uint32_t tt = t + h - skip;  // rows past the piece's first row of the segment
+                const uint32_t q = (j0 + tt) / S.L, j = (j0 + tt) - q * S.L;
+                const uint64_t g_item = S.gate_base + (item0 + q) * S.L;
+#pragma unroll
+                for (uint32_t w = 0; w < 4; w++) out[w][h] = 0;
+                if (!live[h]) continue;
+                uint32_t j2[3], w2[3];
+                const uint32_t fw = ladder_row(kind, n, j, j2, w2), zw = fw ? zero_wires(g, j) : 0u;
+                foreign[h] = fw & ~zw;
+#pragma unroll
+                for (uint32_t w = 0; w < 3; w++) {
+                    if (fw >> w & 1) {  // zero_var here: the next wire of this row that holds it (the fourth one at the latest)
+                        const uint32_t later = (zw | 8u) & ~((2u << w) - 1);
+                        out[w][h] = enc(g, (uint32_t)__ffs((int)later) - 1);
+                    } else {
+                        out[w][h] = enc(g_item + j2[w], w2[w]);
+                    }
+                }
+                // the fourth wire holds zero_var: on to the first wire of the next row that does
+                if (g + 1 < S.gate_end) {
+                    const uint32_t jn = j + 1 == S.L ? 0 : j + 1;
+                    const uint32_t zn = ladder_foreign_wires(kind, n, jn) ? zero_wires(g + 1, jn) : 0u;
+                    out[3][h] = enc(g + 1, (uint32_t)__ffs((int)(zn | 8u)) - 1);
+                } else {
+                    out[3][h] = perm_next_zero_from(X, S.gate_end);
+                }
+            }
+            const uint64_t g = g_first + t;
+#pragma unroll
+            for (uint32_t w = 0; w < 4; w++) {
+                const bool skip0 = !live[0] || (foreign[0] >> w & 1), skip1 = !live[1] || (foreign[1] >> w & 1);
+                uint64_t *dst = sigma + enc(g, w);
+                if (wide && !skip0 && !skip1)
+                    store16(reinterpret_cast<uint4 *>(dst), make_uint4((uint32_t)out[w][0], (uint32_t)(out[w][0] >> 32), (uint32_t)out[w][1],
+                                                                      (uint32_t)(out[w][1] >> 32)));
+                else {
+                    if (!skip0) dst[0] = out[w][0];
+                    if (!skip1) dst[1] = out[w][1];
+                }
+            }
+            // the positions that hold a Variable from elsewhere other than zero_var: one reservation per wave
+            const uint32_t mine = (uint32_t)__popc(foreign[0]) + (uint32_t)__popc(foreign[1]);
+            if (__ballot(mine != 0)) {
+                uint32_t before = 0, all = 0;
+                for (uint32_t k = 0; k < 64; k++) {  // (rare: two rows of an item)
+                    const uint32_t c = (uint32_t)__shfl((int)mine, (int)k, 64);
+                    if (k < lane) before += c;
+                    all += c;
+                }
+                unsigned long long at = 0;
+                if (lane == 0) at = atomicAdd(Q.count, (unsigned long long)all);
+                at = __shfl(at, 0, 64) + before;
+                for (uint32_t h = 0; h < 2; h++)
+                    for (uint32_t m = foreign[h]; m; m &= m - 1) {
+                        const uint32_t w = (uint32_t)__ffs((int)m) - 1;
+                        perm_sparse_put(X, Q, at++, X.C.w[w][g + h], g + h, w);
+                    }
+            }
+        }
     }
 }
 
