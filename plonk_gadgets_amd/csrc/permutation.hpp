@@ -328,7 +328,9 @@ __global__ __launch_bounds__(kThreads, 7) void perm_item_kernel(const PermCtx X,
 //     x    (0, l) -> (0, r)            the witness: the item's own first Variable, or one from elsewhere (the sparse list)
 // and every position's successor is the next one of its line, the last one's the first.  The fourth wire of every such row holds
 // zero_var: its successor is the fourth wire of the next row.  One lane per row, nothing read, 32 bytes written per row: the
-// counting sort of perm_item_kernel (3.4 ms of the 4.8 a 270 M-row circuit took) is not needed for these rows.
+// counting sort of perm_item_kernel (3.4 ms of the 4.8 a 270 M-row circuit took) is not needed for these rows: 1.9-2.4 ms by box, at
+// the rate four lock-step streams 4.3 GB apart take (sigma's columns are padded_n entries apart); one column per pass -- the successors
+// computed four times -- is slower (5.1 against 4.1 ms for the whole call: the arithmetic is not free).
 // successors of the three positions of block-row jj: (j2[w], w2[w]) in block rows.  Returned mask: bit w = the position is not linked
 // inside the block -- jj = 0: w = 0, 1 hold the witness x; jj = 2n + 2: w = 1 is the END of T's line; jj = 2n + 4: w = 0 the end of y's
 __device__ __forceinline__ uint32_t ladder_block_row(uint32_t jj, uint32_t n, uint32_t j2[3], uint32_t w2[3]) {
@@ -421,6 +423,7 @@ __global__ __launch_bounds__(kThreads) void perm_ladder_kernel(const PermCtx X, 
     const bool wide = (reinterpret_cast<uintptr_t>(sigma) & 15) == 0 && !(X.padded_n & 1);
     // wire * padded_n + gate: a shift when padded_n is a power of two (it is for whoever pads as dusk-plonk does) -- the successor's
     // wire is data, so the product cannot be hoisted, and a 64 x 64-bit multiplication per position is most of what a lane would do
+    const uint32_t recip = (uint32_t)(((1ull << 32) + S.L - 1) / S.L);  // floor(x / L) = umulhi(x, ceil(2^32 / L)) for x < 2^16 / ... (below)
     const bool pow2 = (X.padded_n & (X.padded_n - 1)) == 0;
     const uint32_t sh = 63u - (uint32_t)__clzll((long long)X.padded_n);
     auto enc = [&](uint64_t gate, uint32_t wire) { return pow2 ? ((uint64_t)wire << sh) + gate : perm_encode(gate, wire, X.padded_n); };
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(kThreads) void perm_ladder_kernel(const PermCtx X, 
                 const uint64_t g = g_first + t + h;
                 live[h] = g >= S.gate_base && g < S.gate_end;
                 const uint32_t tt = t + h - skip;  // rows past the piece's first row of the segment
-                const uint32_t q = (j0 + tt) / S.L, j = (j0 + tt) - q * S.L;
+                const uint32_t q = __umulhi(j0 + tt, recip), j = (j0 + tt) - q * S.L;  // (exact: j0 + tt < 2^14, L < 2^11)
                 const uint64_t g_item = S.gate_base + (item0 + q) * S.L;
 #pragma unroll
                 for (uint32_t w = 0; w < 4; w++) out[w][h] = 0;

@@ -991,3 +991,63 @@ def test_materialize_rows_of_batched_calls(engine):
     w4 = m["w_4"]
     assert int((w4 != 0).sum()) == 1 and int(w4[1]) == 2  # the dummy rows' live fourth wire
     assert torch.equal(m["w_4_value"], cols.var_values[w4])
+
+
+@pytest.mark.parametrize("bits", [1, 2, 3, 19, 128, 251, 252, 253, 254, 255])
+def test_ladder_sigma_closed_form_over_the_ladder_lengths(engine, bits):
+    """sigma of the ladder gadgets' rows is written in closed form (csrc/permutation.hpp, perm_ladder_kernel: which positions hold
+    one Variable is a function of a row's place in its item): every kind -- range_check and max_bound, allocating and on witnesses
+    allocated elsewhere, scalar_decomposition -- over ladder lengths from the shortest (n = 2) to the longest (255; 252 for a bound of
+    255 bits), with a witness Variable that IS zero_var (its positions belong to the zero chain, not to the sparse list), results used by
+    later rows (the sparse list splices them into the items' own cycles) and an odd first row.  == the oracle's bookkeeping."""
+    import ctypes as C
+    from oracle import pyoracle as po
+    mx = 2**bits if bits < 255 else Q - 1  # (bound - 1 of `bits` bits: n = bits + 1, and 252 for 255 bits)
+    mn = mx // 3
+    batch = 5
+    dev, ora = pg.StandardComposer(engine, 1 << 15, 1 << 15), po.Composer()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:0")
+    F = lambda x: po.fr(synth.mont(x))
+    ws = [0, mn, mx - 1, mx, Q - 1][:batch]
+    wit = synth.scalars_from_ints(ws)
+    dev.boolean_gate(dev.add_witness_to_circuit_description(S(1)))      # (an odd number of rows before the first batch)
+    ora.L.composer_boolean_gate(ora.c, ora.L.composer_add_witness_to_circuit_description(ora.c, F(1)))
+    first = dev.add_input_batch(t(wit))
+    allocs = [ora.allocate(w) for w in wit]
+    assert first == int(allocs[0].var)
+    # witnesses elsewhere: the allocated ones, and zero_var itself (value 0) in the middle
+    wv_list = [first, first + 1, 0, first + 3, first + 4]
+    wv = torch.tensor(wv_list, dtype=torch.int64, device="cuda:0")
+    wvals = synth.scalars_from_ints([ws[0], ws[1], 0, ws[3], ws[4]])
+    oallocs = [po.AllocatedScalar(v, po.fr(x)) for v, x in zip(wv_list, wvals)]
+    nb = C.c_uint64()
+    res = []
+    r = dev.range_check_batch(S(mn), S(mx), t(wit))
+    res += [int(ora.L.range_check(ora.c, F(mn), F(mx), ora.allocate(w))) for w in wit]
+    assert list(r.cpu().numpy().view(np.uint64)) == res[-batch:]
+    r = dev.range_check_allocated_batch(S(mn), S(mx), wv, t(wvals))
+    res += [int(ora.L.range_check(ora.c, F(mn), F(mx), a)) for a in oallocs]
+    assert list(r.cpu().numpy().view(np.uint64)) == res[-batch:]
+    r, n1 = dev.max_bound_batch(S(mx), t(wit))
+    res += [int(ora.L.max_bound(ora.c, F(mx), ora.allocate(w), C.byref(nb))) for w in wit]
+    assert list(r.cpu().numpy().view(np.uint64)) == res[-batch:] and n1 == nb.value
+    r, _ = dev.max_bound_allocated_batch(S(mx), wv, t(wvals))
+    res += [int(ora.L.max_bound(ora.c, F(mx), a, C.byref(nb))) for a in oallocs]
+    assert list(r.cpu().numpy().view(np.uint64)) == res[-batch:]
+    nd = min(bits + 1, 256)
+    r = dev.scalar_decomposition_batch(nd, wv, t(wvals))
+    res += [int(ora.L.scalar_decomposition_gadget(ora.c, nd, a, None)) for a in oallocs]
+    assert list(r.cpu().numpy().view(np.uint64)) == res[-batch:]
+    # later rows that use the items' results and an item's inner Variable
+    z = pg.conditionally_select_zero(dev, res[0], res[-1])
+    assert z == int(ora.L.conditionally_select_zero(ora.c, res[0], res[-1]))
+    dev.assert_equal(res[7], res[7])
+    ora.L.composer_assert_equal(ora.c, res[7], res[7])
+    same(dev, ora)
+    n = dev.circuit_size()
+    padded = 1 << (n - 1).bit_length()
+    got, exp = dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded)
+    if not np.array_equal(got, exp):
+        w, g = np.argwhere(got != exp)[0]
+        raise AssertionError(f"sigma differs first at wire {w}, gate {g}: {got[w, g]} != {exp[w, g]} (n = {n1})")
+    _sigma_properties(dev, padded)
