@@ -21,6 +21,7 @@ VARIANTS = {
     # round 5: row tiles per workgroup that the fused mix's arithmetic launch writes while it inverts (the library: 2)
     "fb": ["-DPG_EXP_FWD_BURST"], "fb_stamps": ["-DPG_EXP_FWD_BURST", "-DPG_MIX_STAMPS"],
     "et2": ["-DPG_MIX_EARLY_TILES=2"],
+    "sm": ["-DPG_MIX_EARLY_TILES=0", "-DPG_EXP_STEP_MAJOR"],  # (two-step form only) step m of all waves = one contiguous window
     "et0": ["-DPG_MIX_EARLY_TILES=0"], "et1": ["-DPG_MIX_EARLY_TILES=1"], "et3": ["-DPG_MIX_EARLY_TILES=3"], "et4": ["-DPG_MIX_EARLY_TILES=4"],
     # the fused mix (C3)
     "mix_stamps": ["-DPG_MIX_STAMPS"],  # timing build for tools/mix_phases.py
@@ -90,7 +91,7 @@ PATCHES = {  # builds that are NOT in the sources: a patch (tools/patches/) appl
     "f3_stamps": "r04_mix_experiments.patch", "stag50": "r04_mix_experiments.patch", "stag100": "r04_mix_experiments.patch",
     "rows128": "r04_mix_experiments.patch", "rows512": "r04_mix_experiments.patch", "rowsgrid8": "r04_mix_experiments.patch",
     "rowsgrid12": "r04_mix_experiments.patch", "gen_side": "r04_mix_experiments.patch",
-    "fb": "r05_fwd_burst.patch", "fb_stamps": "r05_fwd_burst.patch",  # round 5: four steps' elements per fetch in the forward pass
+    "fb": "r05_fwd_burst.patch", "fb_stamps": "r05_fwd_burst.patch", "sm": "r05_step_major.patch",  # round 5: four steps' elements per fetch in the forward pass
 }
 
 
