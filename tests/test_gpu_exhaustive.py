@@ -80,7 +80,7 @@ def describe_difference(name, got, exp, first_index):
             f"({int(d.numel())} differing words in this chunk)")
 
 
-def stream_compare(cols, offsets, produce, chunk_items, max_rows, max_vars, n_items=BATCH, only_chunk=None):
+def stream_compare(cols, offsets, produce, chunk_items, max_rows, max_vars, n_items=BATCH, only_chunk=None, names=NINE):
     """produce(lo, hi, pinned_numpy_views) fills the views with items [lo, hi) of the oracle's columns (rows relative to item
     lo's first row); offsets(i) -> (first row, first variable) of item i relative to the call.  Returns (chunks compared,
     words compared); raises AssertionError naming array / row / limb at the first difference."""
@@ -118,7 +118,7 @@ def stream_compare(cols, offsets, produce, chunk_items, max_rows, max_vars, n_it
             assert r1 - r0 <= max_rows and v1 - v0 <= max_vars, (lo, hi, r1 - r0, v1 - v0)
             bad = torch.zeros((), dtype=torch.bool, device=DEV)
             views = {}
-            for name in NINE:
+            for name in names:
                 per = 1 if name in WIRES else 4
                 n, first = (v1 - v0, v0) if name == "var_values" else (r1 - r0, r0)
                 stage[name][:n * per].copy_(sets[k % 2].t[name][:n * per], non_blocking=True)
@@ -128,7 +128,7 @@ def stream_compare(cols, offsets, produce, chunk_items, max_rows, max_vars, n_it
                 views[name] = (got, exp, first)
                 words += n * per
             if bool(bad):  # (one host synchronisation per chunk: the uploads from this set are complete as well)
-                for name in NINE:
+                for name in names:
                     got, exp, first = views[name]
                     if not torch.equal(got, exp):
                         failure.append(AssertionError(f"items [{lo}, {hi}): " + describe_difference(name, got, exp, first)))
@@ -379,4 +379,44 @@ def test_fused_mix_early_rows_every_limb(engine, batch, form):
         assert int(t[0]) == -1 and bool((t[1 + G:] == -1).all()), name
     assert bool((big.var_values[V:] == -1).all())
     del big, cols, produce
+    release_hbm()
+
+
+def test_config_c2_witness_refresh_every_limb(engine):
+    """the witness refresh of config 2's circuit (pg_range_check_values_batch: the assignments alone, the reference's prover flow after
+    clear_witness(), /root/reference/tests/scalar_gadgets_tests.rs:108-119) at full size through bench.Workload's launch: all
+    1 084 227 584 variables of the table, 34.7 GB, limb for limb against the oracle's var_values for the same witnesses -- into a table
+    that held OTHER witnesses' assignments before, with a guard behind it"""
+    import bench
+    import types
+    from oracle import pyoracle as po
+    G, V = 1031, 1034
+    release_hbm()
+    wl = bench.Workload("c2_values", engine, DEV, 0, 1, LOG2_BATCH, -1)
+    table = wl.cols
+    assert table.shape == (BATCH * V, 4)
+    guard = torch.full((64, 4), -1, dtype=torch.int64, device=DEV)
+    table.fill_(0x3C3C3C3C3C3C3C3C)
+    wl.launch(0)
+    torch.cuda.synchronize()
+    wit = synth.random_scalars(BATCH, seed=synth.SEED + 1)  # (bench.Workload's witnesses for this workload)
+    mn, mx = synth.mont(0), synth.mont(2**254)
+    threads = oracle_threads()
+    chunk = 1 << 12
+    cols = types.SimpleNamespace(var_values=table)
+
+    def produce(lo, hi, out):
+        po.range_check_fast(mn, mx, np.ascontiguousarray(wit[lo:hi]), threads=threads, var_base=5 + lo * V, out=out)
+
+    def run(only=None):
+        return stream_compare(cols, lambda i: (i * G, i * V), produce, chunk, chunk * G, chunk * V, only_chunk=only, names=("var_values",))
+
+    n_chunks, words = run()
+    assert n_chunks == BATCH // chunk and words * 8 == BATCH * V * 32 == 34_695_282_688
+    assert bool((guard == -1).all())
+    item = 200 * chunk + 77
+    flip_and_find(cols, "var_values", item * V + 1033, 0, lambda: run(only=200))   # the item's last variable: the outcome
+    flip_and_find(cols, "var_values", item * V + 259 + 255 + 1, 2, lambda: run(only=200))  # z of the first bound block
+    wl.release()
+    del wl, table, cols, run, produce
     release_hbm()
