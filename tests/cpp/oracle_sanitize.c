@@ -48,11 +48,42 @@ int main(void) {
     if (oracle_max_bound_batch(bounds, wit, B, 1, NULL, NULL, NULL, &gb, &vb, &ng, &nv)) return 5;
     c = alloc_cols(ng, nv);
     if (oracle_max_bound_batch(bounds, wit, B, 1, &c, res, nbits, &gb, &vb, &ng, &nv)) return 6;
+    {   /* the threaded ragged form, in two chunks at the numbering of the whole batch == the faithful loop */
+        uint64_t *nb2 = malloc(B * 8), *ro = malloc((B + 1) * 8), *vo = malloc((B + 1) * 8), *r2 = malloc(B * 8);
+        if (oracle_max_bound_plan(bounds, B, 3, nb2, ro, vo) || memcmp(nb2, nbits, B * 8) || ro[B] != ng || vo[B] != nv) return 20;
+        const size_t cut = B / 3;
+        for (int part = 0; part < 2; part++) {
+            const size_t lo = part ? cut : 0, hi = part ? B : cut;
+            oracle_columns_t g = alloc_cols(ro[hi] - ro[lo], vo[hi] - vo[lo]);
+            if (oracle_max_bound_fast(bounds, wit, nb2, ro, vo, lo, hi, vb, 3, &g, r2 + lo)) return 21;
+            if (memcmp(g.q_c, c.q_c + ro[lo], (ro[hi] - ro[lo]) * 32) || memcmp(g.w_r, c.w_r + ro[lo], (ro[hi] - ro[lo]) * 8) ||
+                memcmp(g.var_values, c.var_values + vo[lo], (vo[hi] - vo[lo]) * 32)) return 22;
+            free_cols(&g);
+        }
+        if (memcmp(r2, res, B * 8)) return 23;
+        free(nb2); free(ro); free(vo); free(r2);
+    }
     free_cols(&c);
     oracle_scalar_mix_batch(v, y, sel, a, b, B, 0, NULL, NULL, NULL, &gb, &vb, &ng, &nv);
     c = alloc_cols(ng, nv);
     oracle_scalar_mix_batch(v, y, sel, a, b, B, 0, &c, res, err, &gb, &vb, &ng, &nv);
     if (err[5] != 1) return 7;
+    {   /* the threaded fused mix (batch inversion per block of items), chunked */
+        uint64_t *ro = malloc((B + 1) * 8), *vo = malloc((B + 1) * 8), *r2 = malloc(2 * B * 8);
+        uint8_t *e2 = malloc(B);
+        if (oracle_scalar_mix_plan(v, B, ro, vo, e2) || memcmp(e2, err, B) || ro[B] != ng || vo[B] != nv) return 24;
+        const size_t cut = B / 2 + 1;
+        for (int part = 0; part < 2; part++) {
+            const size_t lo = part ? cut : 0, hi = part ? B : cut;
+            oracle_columns_t g = alloc_cols(ro[hi] - ro[lo], vo[hi] - vo[lo]);
+            if (oracle_scalar_mix_fast(v, y, sel, a, b, ro, vo, lo, hi, vb, 0, 2, &g, r2 + 2 * lo)) return 25;
+            if (memcmp(g.q_m, c.q_m + ro[lo], (ro[hi] - ro[lo]) * 32) || memcmp(g.w_o, c.w_o + ro[lo], (ro[hi] - ro[lo]) * 8) ||
+                memcmp(g.var_values, c.var_values + vo[lo], (vo[hi] - vo[lo]) * 32)) return 26;
+            free_cols(&g);
+        }
+        if (memcmp(r2, res, 2 * B * 8)) return 27;
+        free(ro); free(vo); free(r2); free(e2);
+    }
     free_cols(&c);
     /* one composer with everything, then sigma and the dense public inputs */
     composer_t *cs = composer_new();
