@@ -280,10 +280,13 @@ class Workload:
             lay, nerr = eng.scalar_mix_plan(ins[0][:chunk], roff, voff)
             assert nerr == 0 and (lay.n_gates, lay.n_vars) == (10 * chunk, 15 * chunk)
             self.rows_per_launch, self.vars_per_launch = lay.n_gates, lay.n_vars
-            # a circuit of 2.4 GB: its five selector columns, written in lock step, go 24 GiB apart in one slab (where nine
-            # allocations in a row happen to land decides 0.51 ... 0.59 ms per step otherwise: DESIGN.md section 2,
-            # tools/c3_instances.py, tools/placement_sweep.py); PG_BENCH_SPREAD_GIB=0 allocates them one after the other
-            self.spread_gib = float(os.environ.get("PG_BENCH_SPREAD_GIB", "24"))
+            # A circuit of 2.4 GB.  Round 4 put its five selector columns, written in lock step, 24 GiB apart in one slab (a 99-GiB
+            # allocation): with that round's kernels nine allocations in a row drew 0.51 ... 0.59 ms per step by where they landed and the
+            # slab 0.51-0.52.  With round 5's (a row tile per workgroup written by the arithmetic launch, no
+            # workgroup barriers) the two are level -- four boxes, slab / nine allocations: 0.595 / 0.585, 0.589 / 0.595, 0.595 / 0.577,
+            # 0.562 / 0.583 of peak -- so the plain layout is the default and the slab the alternative the line reports beside it
+            # (PG_BENCH_SPREAD_GIB=24 makes it the headline layout again)
+            self.spread_gib = float(os.environ.get("PG_BENCH_SPREAD_GIB", "0"))
             cols = self.allocate_columns(lay.n_gates, lay.n_vars, self.spread_gib)
             res = torch.empty((chunk, 2), dtype=torch.int64, device=dev)
             self.read_bytes = chunk * 160
@@ -754,16 +757,18 @@ def main():
                                    "config": {"workload": w2.desc, "items_per_gpu": w2.batch, "items_per_launch": w2.chunk,
                                               **(w2.layout_note() if name in ("c3", "c4") else {})},
                                    "roofline": roofline_with_fill(w2, ms2)}
-                if name in ("c3", "c4") and getattr(w2, "spread_gib", 0):
-                    # the same launches into nine plain allocations, wherever the driver puts them: what a caller who does not
-                    # lay its columns out gets (the placement effect, driver-observed: DESIGN.md section 2)
-                    w2.reallocate_columns(0)
-                    el3, ms3 = measure(w2, args.steps, args.warmup, sync_all)
-                    r3 = roofline_with_fill(w2, ms3)
-                    secondary[name]["nine_allocations"] = {
-                        "ms_per_step": el3 / args.steps * 1e3, "value": w2.rows_per_launch * w2.n_chunks * args.steps / el3,
-                        "frac": r3["achieved"] / HBM_PEAK_GBPS, "achieved": r3["achieved"], "launch_ms": r3["launch_ms"],
-                        "bare_fill": r3.get("bare_fill"), "frac_of_bare_fill": r3.get("frac_of_bare_fill")}
+                if name in ("c3", "c4"):
+                    # the same launches into the OTHER layout: nine plain allocations, wherever the driver puts them, against one slab
+                    # with the selector columns tens of GiB apart (the placement effect, driver-observed: DESIGN.md section 2)
+                    slab_first = bool(getattr(w2, "spread_gib", 0))
+                    w2.reallocate_columns(0 if slab_first else (24 if name == "c3" else 32))
+                    if slab_first or w2.spread_gib:  # (a card without the room for the slab: nothing to compare)
+                        el3, ms3 = measure(w2, args.steps, args.warmup, sync_all)
+                        r3 = roofline_with_fill(w2, ms3)
+                        secondary[name]["nine_allocations" if slab_first else "one_slab"] = {
+                            "ms_per_step": el3 / args.steps * 1e3, "value": w2.rows_per_launch * w2.n_chunks * args.steps / el3,
+                            "frac": r3["achieved"] / HBM_PEAK_GBPS, "achieved": r3["achieved"], "launch_ms": r3["launch_ms"],
+                            "bare_fill": r3.get("bare_fill"), "frac_of_bare_fill": r3.get("frac_of_bare_fill"), **w2.layout_note()}
                 w2.release()
                 del w2
                 torch.cuda.empty_cache()
