@@ -280,13 +280,12 @@ class Workload:
             lay, nerr = eng.scalar_mix_plan(ins[0][:chunk], roff, voff)
             assert nerr == 0 and (lay.n_gates, lay.n_vars) == (10 * chunk, 15 * chunk)
             self.rows_per_launch, self.vars_per_launch = lay.n_gates, lay.n_vars
-            # A circuit of 2.4 GB.  Round 4 put its five selector columns, written in lock step, 24 GiB apart in one slab (a 99-GiB
-            # allocation): with that round's kernels nine allocations in a row drew 0.51 ... 0.59 ms per step by where they landed and the
-            # slab 0.51-0.52.  With round 5's (a row tile per workgroup written by the arithmetic launch, no
-            # workgroup barriers) the two are level -- four boxes, slab / nine allocations: 0.595 / 0.585, 0.589 / 0.595, 0.595 / 0.577,
-            # 0.562 / 0.583 of peak -- so the plain layout is the default and the slab the alternative the line reports beside it
-            # (PG_BENCH_SPREAD_GIB=24 makes it the headline layout again)
-            self.spread_gib = float(os.environ.get("PG_BENCH_SPREAD_GIB", "0"))
+            # a circuit of 2.4 GB: its five selector columns, written in lock step, go 24 GiB apart in one slab -- a 99-GiB allocation.
+            # Where nine allocations in a row happen to land decides 0.51 ... 0.59 ms per step otherwise (DESIGN.md section 2,
+            # tools/c3_instances.py, tools/placement_sweep.py); round 5, five boxes, slab / nine allocations: 0.595 / 0.585, 0.589 /
+            # 0.595, 0.595 / 0.577, 0.562 / 0.583, 0.585 / 0.516 of peak -- level on most, but only the plain layout has the bad draws.
+            # The line reports both (`one_slab` / `nine_allocations`); PG_BENCH_SPREAD_GIB=0 makes the plain layout the headline one
+            self.spread_gib = float(os.environ.get("PG_BENCH_SPREAD_GIB", "24"))
             cols = self.allocate_columns(lay.n_gates, lay.n_vars, self.spread_gib)
             res = torch.empty((chunk, 2), dtype=torch.int64, device=dev)
             self.read_bytes = chunk * 160
