@@ -31,6 +31,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -740,6 +741,7 @@ def main():
     mn, mx = getattr(wl, "mn", None), getattr(wl, "mx", None)
     wl.release()
     torch.cuda.empty_cache()
+    headline_step_s = elapsed / args.steps
 
     # ---- N = 1: the other single-GPU BASELINE configs, same process, same steps ------------------------------
     secondary = None
@@ -749,10 +751,22 @@ def main():
             try:
                 w2 = Workload(name, eng, dev, rank, world, args.log2_batch, -1)
                 el2, ms2 = measure(w2, args.steps, args.warmup, sync_all)
+                # W steps of a 0.5-ms workload are 2.5 ms: the card is still on its way up from the idle of the set-up (C3: 0.54 ms
+                # per launch falling to 0.50 over the first 30, profiles/NOTES_r05.md section 5).  The headline's W steps last
+                # W x 36 ms; a secondary workload gets the same warm-up TIME, and its figure after W steps alone stays beside it
+                first = None
+                warm = max(args.warmup, min(2000, int(math.ceil(args.warmup * headline_step_s / max(el2 / args.steps, 1e-6)))))
+                if warm > args.warmup:
+                    r_first = roofline_of(w2, ms2)
+                    first = {"warmup": args.warmup, "ms_per_step": el2 / args.steps * 1e3, "frac": r_first["frac"],
+                             "launch_ms": r_first["launch_ms"]}
+                    el2, ms2 = measure(w2, args.steps, warm, sync_all)
                 secondary[name] = {"metric": f"gadget constraints/sec ({name})" if name != "c2_values" else
                                              "constraints whose witnesses are refreshed /sec (range_check 256-bit, values only)",
                                    "value": w2.rows_per_launch * w2.n_chunks * args.steps / el2, "unit": "constraints/s",
-                                   "ms_per_step": el2 / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
+                                   "ms_per_step": el2 / args.steps * 1e3, "steps": args.steps, "warmup": warm,
+                                   **({"warmup_note": "as long as the headline's %d steps (%.0f ms)" % (args.warmup, args.warmup * headline_step_s * 1e3),
+                                       "after_the_headlines_step_count_only": first} if first else {}),
                                    "config": {"workload": w2.desc, "items_per_gpu": w2.batch, "items_per_launch": w2.chunk,
                                               **(w2.layout_note() if name in ("c3", "c4") else {})},
                                    "roofline": roofline_with_fill(w2, ms2)}
@@ -762,7 +776,7 @@ def main():
                     slab_first = bool(getattr(w2, "spread_gib", 0))
                     w2.reallocate_columns(0 if slab_first else (24 if name == "c3" else 32))
                     if slab_first or w2.spread_gib:  # (a card without the room for the slab: nothing to compare)
-                        el3, ms3 = measure(w2, args.steps, args.warmup, sync_all)
+                        el3, ms3 = measure(w2, args.steps, warm, sync_all)
                         r3 = roofline_with_fill(w2, ms3)
                         secondary[name]["nine_allocations" if slab_first else "one_slab"] = {
                             "ms_per_step": el3 / args.steps * 1e3, "value": w2.rows_per_launch * w2.n_chunks * args.steps / el3,
