@@ -22,41 +22,129 @@ namespace pg {
 #ifndef PG_MAT_UNROLL
 #define PG_MAT_UNROLL 2
 #endif
-constexpr int kMatThreads = PG_MAT_THREADS;
-constexpr uint32_t kMatWindowVars = 1040;  // 33 280 B of LDS: four workgroups per CU; range_check's 1034 Variables per item fit
+#ifndef PG_MAT_LOADS
+#define PG_MAT_LOADS 8  // (4, 8 or 16)
+#endif
+// kMatStoreThreads lanes write; ONE more wave only reads: it fetches the NEXT group's window while the others write the current
+// group's rows.  A wave waits for a load with s_waitcnt vmcnt -- the counter its stores are counted on as well -- so a wave that
+// both loads and stores drains its own store stream at every wait, and a pass that only MIGHT load (behind a branch no lane takes)
+// still does: the compiler puts the wait where the paths meet.  That was the kernel up to round 5's first half: one drain per pass
+// and two per group (without its reads: 12.4-12.8 ms per 270 M rows, with them 15.2-15.7; the reads' share of the traffic is 1.2).
+// The loader's counter is its own.
+constexpr int kMatStoreThreads = PG_MAT_THREADS, kMatThreads = kMatStoreThreads + 64;
+constexpr uint32_t kMatWindowVars = 1040;  // two windows of 33 280 B: two workgroups per CU (fewer, fatter store streams: -3 %); range_check's 1034 Variables per item fit
+constexpr uint32_t kMatTailRows = 16;      // rows of the NEXT group that come along with a group's last line of w_4 (at most 15)
 
-// CLOSED: the segment's wires are known in closed form (PermSeg::wire_kind, a uniform ladder gadget): a row's three Variables are
-// computed from its position in its item, and only a reference to a witness allocated elsewhere is read from the wire column
-template <bool CLOSED>
+// how the store waves learn a row's three Variables
+enum : int {
+    MAT_READ_WIRES = 0,  // from the wire columns (any batched call)
+    MAT_CLOSED = 1,      // in closed form (PermSeg::wire_kind, a uniform ladder gadget), except a witness allocated elsewhere
+    MAT_SELF = 2,        // in closed form and all of them the item's own (range_check / max_bound that allocate their witness): the
+                         // store waves load NOTHING -- the rows that come along from the next group get their values from the loader
+};
+
+template <int MODE>
 __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const ComposerCols C, const MaterializeOut M, const PermSeg S,
                                                                         uint32_t group, uint64_t zero_var) {
-    __shared__ uint4 s_win[2 * kMatWindowVars];
+    constexpr bool CLOSED = MODE != MAT_READ_WIRES;
+    __shared__ uint4 s_win[2][2 * kMatWindowVars];
+    __shared__ uint4 s_tail[2][MODE == MAT_SELF ? kMatTailRows * 6 : 1];
     const uint32_t tid = threadIdx.x;
+    const bool loader = tid >= (uint32_t)kMatStoreThreads;
     FrVec one;
     one.f = fr_one();
     const uint4 v1 = (tid & 1) ? one.v[1] : one.v[0], v0 = make_uint4(0, 0, 0, 0);
     const uint64_t n_groups = (S.items + group - 1) / group;
-    for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    struct Group { uint64_t r0, r1, w0, ubeg, uend; uint32_t nv; };
+    auto group_of = [&](uint64_t g) {
+        Group G;
         const uint64_t i0 = g * group, i1 = i0 + group < S.items ? i0 + group : S.items;
-        const uint64_t r0 = S.gate_base + perm_rows_before(S, i0), r1 = S.gate_base + perm_rows_before(S, i1);
-        const uint64_t w0 = S.var_base + perm_vars_before(S, i0);
-        const uint32_t nv = (uint32_t)(S.var_base + perm_vars_before(S, i1) - w0);
-        for (uint32_t u = tid; u < 2 * nv; u += kMatThreads) s_win[u] = C.vars[2 * w0 + u];
-        __syncthreads();
+        if constexpr (CLOSED) {  // (uniform items: no prefix sums to fetch -- a load here is a drain of the store waves per group)
+            G.r0 = S.gate_base + i0 * S.L;
+            G.r1 = S.gate_base + i1 * S.L;
+            G.w0 = S.var_base + i0 * S.V;
+            G.nv = (uint32_t)(i1 - i0) * S.V;
+        } else {
+            G.r0 = S.gate_base + perm_rows_before(S, i0);
+            G.r1 = S.gate_base + perm_rows_before(S, i1);
+            G.w0 = S.var_base + perm_vars_before(S, i0);
+            G.nv = (uint32_t)(S.var_base + perm_vars_before(S, i1) - G.w0);
+        }
         // The group writes WHOLE LINES of every output column: its range of 16-byte units is cut at multiples of 32 (= 16 rows:
         // four lines of a scalar column, one line of w_4) instead of at its own first and last row, except at the two ends of
         // the call.  A line that two workgroups fill at different times reaches memory in pieces, which costs about twelve
-        // lines' worth -- with items of 1031 rows that would be two of every 258 lines.  The few rows
-        // of the next group that come along find their Variables outside the window and fetch them from memory.
-        const uint64_t ubeg = g == 0 ? 2 * r0 : (2 * r0 + 31) & ~31ull, uend = g + 1 == n_groups ? 2 * r1 : (2 * r1 + 31) & ~31ull;
-        constexpr int U = PG_MAT_UNROLL;  // units per lane and pass: the index loads of all of them are in flight together
-        for (uint64_t ub = (ubeg & ~7ull) + tid; ub < uend; ub += (uint64_t)U * kMatThreads) {
+        // lines' worth -- with items of 1031 rows that would be two of every 258 lines.
+        const uint64_t last = 2 * S.gate_end;
+        G.ubeg = g == 0 ? 2 * G.r0 : (2 * G.r0 + 31) & ~31ull;
+        G.uend = g + 1 == n_groups ? 2 * G.r1 : (2 * G.r1 + 31) & ~31ull;
+        G.ubeg = G.ubeg < last ? G.ubeg : last;  // (a last group of fewer than 16 rows: the call's own rows, no others)
+        G.uend = G.uend < last ? G.uend : last;
+        return G;
+    };
+    // the loader's part of group g: the Variables its items created -- a run of the table, read linearly -- and (MAT_SELF) the
+    // values of the rows that come along from the items after it
+    auto fetch = [&](uint64_t g, uint32_t buf) {
+        const Group G = group_of(g);
+        const uint32_t units = 2 * G.nv, lane = tid - kMatStoreThreads;
+        const uint4 *src = C.vars + 2 * G.w0;
+        uint4 *win = s_win[buf];
+        // PG_MAT_LOADS loads in flight per lane (named registers: as an array this staging area went through scratch memory in two of
+        // the three instantiations)
+        uint32_t u = lane;
+        for (; u + (PG_MAT_LOADS - 1) * 64 < units; u += PG_MAT_LOADS * 64) {
+            const uint4 *q = src + u;
+            uint4 *d = win + u;
+#if PG_MAT_LOADS >= 8
+            const uint4 t0 = q[0], t1 = q[64], t2 = q[128], t3 = q[192], t4 = q[256], t5 = q[320], t6 = q[384], t7 = q[448];
+#if PG_MAT_LOADS >= 16
+            const uint4 t8 = q[512], t9 = q[576], ta = q[640], tb = q[704], tc = q[768], td = q[832], te = q[896], tf = q[960];
+#endif
+            d[0] = t0; d[64] = t1; d[128] = t2; d[192] = t3; d[256] = t4; d[320] = t5; d[384] = t6; d[448] = t7;
+#if PG_MAT_LOADS >= 16
+            d[512] = t8; d[576] = t9; d[640] = ta; d[704] = tb; d[768] = tc; d[832] = td; d[896] = te; d[960] = tf;
+#endif
+#else
+            const uint4 t0 = q[0], t1 = q[64], t2 = q[128], t3 = q[192];
+            d[0] = t0; d[64] = t1; d[128] = t2; d[192] = t3;
+#endif
+        }
+        for (; u < units; u += 64) win[u] = src[u];
+        if constexpr (MODE == MAT_SELF) {
+            const uint32_t rows = (uint32_t)((G.uend - 2 * G.r1) >> 1);  // (2 r1 <= uend: whole rows, at most 15)
+            if (lane < 3 * rows) {
+                uint32_t rr = lane / 3, vb = 0;
+                const uint32_t k = lane - 3 * rr;
+                for (; rr >= S.L; rr -= S.L) vb += S.V;
+                uint32_t off[3];
+                seg_wire_offsets(S.wire_kind, S.wire_n, rr, off);
+                const uint64_t var = G.w0 + G.nv + vb + (k == 0 ? off[0] : k == 1 ? off[1] : off[2]);
+                s_tail[buf][2 * lane] = C.vars[2 * var];
+                s_tail[buf][2 * lane + 1] = C.vars[2 * var + 1];
+            }
+        }
+    };
+    uint64_t g = blockIdx.x;
+    if (loader && g < n_groups) fetch(g, 0);
+    __syncthreads();
+    for (uint32_t buf = 0; g < n_groups; g += gridDim.x, buf ^= 1) {
+        if (loader) {
+            if (g + gridDim.x < n_groups) fetch(g + gridDim.x, buf ^ 1);
+            lds_barrier();
+            continue;
+        }
+        const uint4 *win = s_win[buf];
+        const Group G = group_of(g);
+        const uint64_t r0 = G.r0, w0 = G.w0, ubeg = G.ubeg, uend = G.uend;
+        const uint32_t nv = G.nv;
+        constexpr int U = PG_MAT_UNROLL;  // units per lane and pass
+        for (uint64_t ub = (ubeg & ~7ull) + tid; ub < uend; ub += (uint64_t)U * kMatStoreThreads) {
             uint64_t idx[U][3];
             uint4 got[U][3];
 #pragma unroll
             for (int j = 0; j < U; j++) {
-                const uint64_t u = ub + (uint64_t)j * kMatThreads;
+                const uint64_t u = ub + (uint64_t)j * kMatStoreThreads;
                 const uint64_t r = (u < ubeg ? ubeg : (u < uend ? u : uend - 1)) >> 1;
+                const uint32_t half = (uint32_t)(u & 1);
                 if constexpr (CLOSED) {
                     // the row's item (of the group, or -- the rows that come along with the last line -- the one after it) and
                     // its place in it; Variables relative to the window's first
@@ -64,28 +152,40 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
                     for (; rr >= S.L; rr -= S.L) vb += S.V;
                     uint32_t off[3];
                     seg_wire_offsets(S.wire_kind, S.wire_n, rr, off);
+                    if constexpr (MODE == MAT_SELF) {
+                        const bool along = r >= G.r1;
+                        const uint32_t t = along ? (uint32_t)(r - G.r1) * 6 + half : 0;
 #pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        idx[j][k] = w0 + vb + off[k];
-                        if (off[k] == kWitnessWire) idx[j][k] = M.val[k] ? C.w[k][r] : w0;  // (an `_allocated` call's witness)
+                        for (int k = 0; k < 3; k++) {
+                            const uint32_t rel = vb + off[k];
+                            got[j][k] = along ? s_tail[buf][t + 2 * k] : win[2 * (rel < nv ? rel : 0) + half];
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            idx[j][k] = w0 + vb + off[k];
+                            if (off[k] == kWitnessWire) idx[j][k] = M.val[k] ? C.w[k][r] : w0;  // (an `_allocated` call's witness)
+                        }
                     }
                 } else {
 #pragma unroll
                     for (int k = 0; k < 3; k++) idx[j][k] = M.val[k] ? C.w[k][r] : w0;
                 }
             }
+            if constexpr (MODE != MAT_SELF) {
 #pragma unroll
-            for (int j = 0; j < U; j++) {
-                const uint32_t half = (uint32_t)((ub + (uint64_t)j * kMatThreads) & 1);
+                for (int j = 0; j < U; j++) {
+                    const uint32_t half = (uint32_t)((ub + (uint64_t)j * kMatStoreThreads) & 1);
 #pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const uint64_t rel = idx[j][k] - w0;
-                    got[j][k] = rel < nv ? s_win[2 * (uint32_t)rel + half] : C.vars[2 * idx[j][k] + half];
+                    for (int k = 0; k < 3; k++) {
+                        const uint64_t rel = idx[j][k] - w0;
+                        got[j][k] = rel < nv ? win[2 * (uint32_t)rel + half] : C.vars[2 * idx[j][k] + half];
+                    }
                 }
             }
 #pragma unroll
             for (int j = 0; j < U; j++) {
-                const uint64_t u = ub + (uint64_t)j * kMatThreads;
+                const uint64_t u = ub + (uint64_t)j * kMatStoreThreads;
                 if (u >= ubeg && u < uend) {
 #pragma unroll
                     for (int k = 0; k < 7; k++)
@@ -97,7 +197,7 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
                 }
             }
         }
-        __syncthreads();  // the window is the next group's
+        lds_barrier();  // this window is read, the next one written: they swap
     }
 }
 

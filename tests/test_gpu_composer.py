@@ -993,6 +993,50 @@ def test_materialize_rows_of_batched_calls(engine):
     assert torch.equal(m["w_4_value"], cols.var_values[w4])
 
 
+@pytest.mark.parametrize("lead", [0, 1, 5])
+@pytest.mark.parametrize("kind,extra", [("max_bound", 1), ("max_bound", 2), ("range_check", 1), ("range_check", 0)])
+def test_materialize_short_items_and_a_short_last_group(engine, kind, extra, lead):
+    """the windowed kernel writes whole lines: a group's range of rows is cut at multiples of 16 rows, so the first rows of the next
+    group come along with it (csrc/materialize.hpp: their values through the loader wave's side table).  The corner: items SHORTER
+    than 16 rows (several come along, over more than one item) and a LAST group of fewer rows than that, at the very end of the
+    circuit -- nothing past the circuit's last row may be touched (outputs 64 rows longer, sentinel-filled), whatever the first
+    row's alignment (`lead` single rows before the call)."""
+    import ctypes as C
+    from plonk_gadgets_amd import _lib
+    dev = pg.StandardComposer(engine, 1 << 15, 1 << 21)
+    for _ in range(lead):
+        dev.add_input(S(7))
+    bound = S(3) if kind == "max_bound" else S(2)
+    probe = pg.StandardComposer(engine, 1024, 1024)
+    v0, r0 = probe.num_variables(), probe.circuit_size()
+    one = torch.from_numpy(np.ascontiguousarray(synth.uniform_below(1, 2, seed=1)).view(np.int64)).to("cuda:0")
+    probe.max_bound_batch(bound, one) if kind == "max_bound" else probe.range_check_batch(S(0), bound, one)
+    V, L = probe.num_variables() - v0, probe.circuit_size() - r0
+    assert L < 16 or kind == "range_check"
+    group = 1040 // V
+    items = group * (4096 // (group * L) + 1) + extra
+    wit = torch.from_numpy(np.ascontiguousarray(synth.uniform_below(items, 2, seed=3)).view(np.int64)).to("cuda:0")
+    dev.max_bound_batch(bound, wit) if kind == "max_bound" else dev.range_check_batch(S(0), bound, wit)
+    assert dev.check() == -1
+    n, cols = dev.circuit_size(), dev.device_columns()
+    names = ("q_4", "q_arith", "q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add")
+    vals = ("w_l_value", "w_r_value", "w_o_value", "w_4_value")
+    t = {k: torch.full((n + 64, 4), 0x5A5A5A5A5A5A5A5A, dtype=torch.int64, device="cuda:0") for k in names + vals}
+    t["w_4"] = torch.full((n + 64,), 0x5A5A5A5A5A5A5A5A, dtype=torch.int64, device="cuda:0")
+    fc = _lib.FullColumnsC(**{k: v.data_ptr() for k, v in t.items()})
+    assert dev._lib.pg_composer_materialize(dev._h, C.byref(fc)) == 0
+    torch.cuda.synchronize()
+    for k, v in t.items():
+        assert bool((v[n:] == 0x5A5A5A5A5A5A5A5A).all()), f"{k}: rows past the circuit's last were written"
+    for wname in ("w_l", "w_r", "w_o"):
+        w = getattr(cols, wname)[:n]
+        exp, got = cols.var_values[w], t[wname + "_value"][:n]
+        if not torch.equal(got, exp):
+            bad = int((got != exp).any(dim=1).nonzero()[0])
+            raise AssertionError(f"{wname}_value differs first at row {bad} of {n} (Variable {int(w[bad])}; items of {L} rows, {V} Variables)")
+    assert torch.equal(t["w_4_value"][:n], cols.var_values[t["w_4"][:n]])
+
+
 @pytest.mark.parametrize("bits", [1, 2, 3, 19, 128, 251, 252, 253, 254, 255])
 def test_ladder_sigma_closed_form_over_the_ladder_lengths(engine, bits):
     """sigma of the ladder gadgets' rows is written in closed form (csrc/permutation.hpp, perm_ladder_kernel: which positions hold

@@ -39,6 +39,13 @@ VARIANTS = {
     "diag_3ld": ["-DPG_MIX_STAMPS", "-DPG_DIAG_FWD_3LOADS"],      # timing only: without the v side's second fetch of v
     "diag_split": ["-DPG_MIX_STAMPS", "-DPG_DIAG_FWD_SPLIT"],     # stamps inside the forward loop (they disturb it: vmcnt(0) waits)
     "spread64": ["-DPG_TILE_SPREAD=64"], "spread1024": ["-DPG_TILE_SPREAD=1024"], "spread4096": ["-DPG_TILE_SPREAD=4096"],  # tile order: consecutive workgroups far apart
+    # one tile per workgroup, started in address order by the dispatcher (no grid-stride loop): tools/probes/single_table_fill.hip
+    "ga": ["-DPG_GRID_BLOCKS_PER_CU=1000000"], "ga_w16": ["-DPG_GRID_BLOCKS_PER_CU=1000000", "-DPG_RC_W=16"],
+    "ga_w8": ["-DPG_GRID_BLOCKS_PER_CU=1000000", "-DPG_RC_W=8"], "ga_w4": ["-DPG_GRID_BLOCKS_PER_CU=1000000", "-DPG_RC_W=4"],
+    # pg_composer_materialize (tools/mat_variants.py): timing builds without its reads (wrong output) and residency / shape knobs
+    "mat_l16": ["-DPG_MAT_LOADS=16"], "mat_l4": ["-DPG_MAT_LOADS=4"], "mat_l16_u1": ["-DPG_MAT_LOADS=16", "-DPG_MAT_UNROLL=1"],
+    "mat_u1": ["-DPG_MAT_UNROLL=1"], "mat_u4": ["-DPG_MAT_UNROLL=4"], "mat_t256b": ["-DPG_MAT_THREADS=256"], "mat_t1024": ["-DPG_MAT_THREADS=960"],
+    "mat_noreads": ["-DPG_MAT_ABLATE_READS"], "mat_nowin": ["-DPG_MAT_ABLATE_WINDOW"], "mat_elsewhere": ["-DPG_MAT_READ_ELSEWHERE"],
     "rc_w4": ["-DPG_RC_W=4"], "rc_w8": ["-DPG_RC_W=8"], "rc_w64": ["-DPG_RC_W=64"],  # items per tile of range_check (rc_w16 below)
     "var_single": ["-DPG_VAR_SWEEP_SINGLE"],        # the variable sweep one scalar per lane everywhere (before round 4)
     "var_pairs_always": ["-DPG_VAR_SWEEP_PAIRS_ALWAYS"],  # the paired sweep in the full emission too
@@ -91,6 +98,7 @@ PATCHES = {  # builds that are NOT in the sources: a patch (tools/patches/) appl
     "f3_stamps": "r04_mix_experiments.patch", "stag50": "r04_mix_experiments.patch", "stag100": "r04_mix_experiments.patch",
     "rows128": "r04_mix_experiments.patch", "rows512": "r04_mix_experiments.patch", "rowsgrid8": "r04_mix_experiments.patch",
     "rowsgrid12": "r04_mix_experiments.patch", "gen_side": "r04_mix_experiments.patch",
+    "mat_noreads": "r05_materialize_ablations.patch", "mat_nowin": "r05_materialize_ablations.patch", "mat_elsewhere": "r05_materialize_ablations.patch",
     "fb": "r05_fwd_burst.patch", "fb_stamps": "r05_fwd_burst.patch", "sm": "r05_step_major.patch",  # round 5: four steps' elements per fetch in the forward pass
 }
 
