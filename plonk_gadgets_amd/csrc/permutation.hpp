@@ -415,9 +415,23 @@ __device__ __forceinline__ uint32_t ladder_foreign_wires(uint32_t kind, uint32_t
     return 0u;
 }
 
-constexpr uint32_t kPermLadderRows = 8192;  // rows per workgroup piece (a multiple of 2 * kThreads)
+#ifndef PG_PERM_LADDER_ROWS
+#define PG_PERM_LADDER_ROWS 512
+#endif
+#ifndef PG_PERM_LADDER_LDS
+#define PG_PERM_LADDER_LDS 39936
+#endif
+// Short-lived workgroups: ONE pass of 512 rows each (16 KiB written: 4 KiB of each of sigma's four columns), started in address order by
+// the dispatcher, four resident per CU (an unused dynamic LDS allocation bounds them) -- the same finding as perm_identity_kernel's: what is
+// under way at any moment should be a narrow window.  The whole call on a 270 M-row circuit, one process, same placement
+// (tools/perm_variants.py): pieces of 8192 rows walked by long-lived workgroups 3.77 ms; 512 rows, full residency 3.45; 512 rows, 4 per CU
+// 3.2; 3 per CU 3.55; 2 per CU 4.4 (too few waves for the arithmetic); 1024 rows, 4 per CU 3.26.
+constexpr uint32_t kPermLadderRows = PG_PERM_LADDER_ROWS;  // rows per workgroup piece (a multiple of 2 * kThreads)
+constexpr uint32_t kPermLadderLds = PG_PERM_LADDER_LDS;    // dynamic LDS per workgroup, unused: bounds how many are resident per CU
 __global__ __launch_bounds__(kThreads) void perm_ladder_kernel(const PermCtx X, const PermSeg S, const PermSparse Q, uint64_t *sigma) {
+    extern __shared__ uint4 perm_ladder_pad[];
     const uint32_t lane = threadIdx.x & 63, kind = S.wire_kind, n = S.wire_n;
+    if (X.padded_n == 1) perm_ladder_pad[threadIdx.x] = make_uint4(0, 0, 0, 0);  // (keeps the allocation)
     // a lane takes the TWO gates 2k, 2k + 1 (16 bytes of each of sigma's four columns: one store each where sigma is 16-byte aligned)
     const uint64_t first = S.gate_base & ~1ull, total = S.gate_end - first;  // (rows counted from the even gate at or before the segment's first)
     const bool wide = (reinterpret_cast<uintptr_t>(sigma) & 15) == 0 && !(X.padded_n & 1);
@@ -585,24 +599,32 @@ __global__ __launch_bounds__(kThreads) void perm_splice_kernel(const PermCtx X, 
     }
 }
 
-// rows >= circuit size keep the identity: 16-byte stores over the four runs [wire * padded_n + n, (wire + 1) * padded_n),
-// each workgroup writing contiguous 1 MiB pieces
+// rows >= circuit size keep the identity: 16-byte stores over the four runs [wire * padded_n + n, (wire + 1) * padded_n).
+// SHORT-LIVED workgroups of 8 KiB each (two stores per lane), block b -> run b % 4 (four fronts that advance together), started in
+// address order by the dispatcher, and only two of them resident per CU (kPermIdentityLds bytes of dynamic LDS each, unused): what is
+// under way at any moment is a window of a few MiB per run.  Long-lived workgroups walking 1-MiB pieces took 1.64-1.69 ms for the 8.5 GB
+// of a 270 M-row circuit padded to 2^29, this shape 1.37 (tools/probes/identity_fill.hip; single_table_fill.hip has the general finding:
+// a store stream whose window is small does not care where its array lies).
+constexpr uint32_t kPermIdentityLds = 160 * 1024 / 2 - 1024;
+constexpr uint32_t kPermIdentityUnits = 2 * kThreads;  // 16-byte units per workgroup
 __global__ __launch_bounds__(kThreads) void perm_identity_kernel(uint64_t *sigma, uint64_t n, uint64_t padded_n) {
     typedef unsigned long long __attribute__((ext_vector_type(2))) u64x2;
-    constexpr uint64_t kPiece = 131072;  // entries
-    for (uint32_t wire = 0; wire < 4; wire++) {
-        uint64_t lo = wire * padded_n + n, hi = (wire + 1) * padded_n;
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            if (lo & 1) sigma[lo] = lo;
-            if (hi & 1) sigma[hi - 1] = hi - 1;
-        }
-        lo += lo & 1;
-        hi -= hi & 1;
-        for (uint64_t base = lo + (uint64_t)blockIdx.x * kPiece; base < hi; base += (uint64_t)gridDim.x * kPiece) {
-            const uint64_t end = base + kPiece < hi ? base + kPiece : hi;
-            for (uint64_t i = base + 2 * threadIdx.x; i < end; i += 2 * kThreads) *reinterpret_cast<u64x2 *>(sigma + i) = u64x2{i, i + 1};
-        }
+    extern __shared__ uint4 perm_identity_pad[];
+    const uint32_t wire = blockIdx.x & 3, b = blockIdx.x >> 2;
+    uint64_t lo = wire * padded_n + n, hi = (wire + 1) * padded_n;
+    if (b == 0 && threadIdx.x == 0) {
+        if (lo & 1) sigma[lo] = lo;
+        if (hi & 1) sigma[hi - 1] = hi - 1;
     }
+    lo += lo & 1;
+    hi -= hi & 1;
+    const uint64_t base = lo + ((uint64_t)b * kPermIdentityUnits + threadIdx.x) * 2;
+#pragma unroll
+    for (uint32_t k = 0; k < kPermIdentityUnits / kThreads; k++) {
+        const uint64_t i = base + (uint64_t)k * 2 * kThreads;
+        if (i < hi) *reinterpret_cast<u64x2 *>(sigma + i) = u64x2{i, i + 1};
+    }
+    if (padded_n == 1) perm_identity_pad[threadIdx.x] = make_uint4(0, 0, 0, 0);  // (keeps the allocation; padded_n == 1 has no padding)
 }
 
 }  // namespace pg

@@ -43,6 +43,14 @@ VARIANTS = {
     "ga": ["-DPG_GRID_BLOCKS_PER_CU=1000000"], "ga_w16": ["-DPG_GRID_BLOCKS_PER_CU=1000000", "-DPG_RC_W=16"],
     "ga_w8": ["-DPG_GRID_BLOCKS_PER_CU=1000000", "-DPG_RC_W=8"], "ga_w4": ["-DPG_GRID_BLOCKS_PER_CU=1000000", "-DPG_RC_W=4"],
     # pg_composer_materialize (tools/mat_variants.py): timing builds without its reads (wrong output) and residency / shape knobs
+    # perm_ladder_kernel: rows per workgroup piece, dynamic LDS that bounds the residency (tools/mat_variants.py times the whole call)
+    "lr512": ["-DPG_PERM_LADDER_ROWS=512"], "lr512_l2": ["-DPG_PERM_LADDER_ROWS=512", "-DPG_PERM_LADDER_LDS=80896"],
+    "lr512_l4": ["-DPG_PERM_LADDER_ROWS=512", "-DPG_PERM_LADDER_LDS=39936"], "lr1024_l2": ["-DPG_PERM_LADDER_ROWS=1024", "-DPG_PERM_LADDER_LDS=80896"],
+    "lr2048_l2": ["-DPG_PERM_LADDER_ROWS=2048", "-DPG_PERM_LADDER_LDS=80896"], "lr1024_l4": ["-DPG_PERM_LADDER_ROWS=1024", "-DPG_PERM_LADDER_LDS=39936"],
+    "lr8192_l2": ["-DPG_PERM_LADDER_LDS=80896"], "lr512_l3": ["-DPG_PERM_LADDER_ROWS=512", "-DPG_PERM_LADDER_LDS=53248"],
+    "lr512_l5": ["-DPG_PERM_LADDER_ROWS=512", "-DPG_PERM_LADDER_LDS=31744"], "lr512_l6": ["-DPG_PERM_LADDER_ROWS=512", "-DPG_PERM_LADDER_LDS=26624"],
+    "lr1024_l3": ["-DPG_PERM_LADDER_ROWS=1024", "-DPG_PERM_LADDER_LDS=53248"], "lr8192_l4": ["-DPG_PERM_LADDER_LDS=39936"],
+    "mat_g1m": ["-DPG_MAT_GRID_PER_CU=1000000"], "mat_g8": ["-DPG_MAT_GRID_PER_CU=8"], "mat_g2": ["-DPG_MAT_GRID_PER_CU=2"], "mat_g256": ["-DPG_MAT_GRID_PER_CU=256"],
     "mat_l16": ["-DPG_MAT_LOADS=16"], "mat_l4": ["-DPG_MAT_LOADS=4"], "mat_l16_u1": ["-DPG_MAT_LOADS=16", "-DPG_MAT_UNROLL=1"],
     "mat_u1": ["-DPG_MAT_UNROLL=1"], "mat_u4": ["-DPG_MAT_UNROLL=4"], "mat_t256b": ["-DPG_MAT_THREADS=256"], "mat_t1024": ["-DPG_MAT_THREADS=960"],
     "mat_noreads": ["-DPG_MAT_ABLATE_READS"], "mat_nowin": ["-DPG_MAT_ABLATE_WINDOW"], "mat_elsewhere": ["-DPG_MAT_READ_ELSEWHERE"],
