@@ -31,6 +31,13 @@
 // 8-per-CU grid on the C2 shape, tools/ab_emit.py)
 #define PG_GRID_BLOCKS_PER_CU 64
 #endif
+#ifndef PG_EMIT_GRID_BLOCKS_PER_CU
+// the full emission of a big-item gadget: at most this many tiles' worth of workgroups, i.e. ONE tile per workgroup, in dispatch order,
+// up to 2^20 items of C4's shape (65536 tiles; with 64 per CU a workgroup walked four tiles 16384 apart): 17.45 -> 17.07 ms and
+// 18.34 -> 17.90 on two boxes; C2's shape (32768 tiles) 33.31 / 33.27, C3's unchanged.  The witness refresh keeps 64: one tile per
+// workgroup costs it 5.6 -> 6.15 ms on the tables that are fast (tools/ab_emit.py run_values, `ga`)
+#define PG_EMIT_GRID_BLOCKS_PER_CU 256
+#endif
 
 namespace {
 
@@ -397,7 +404,7 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
             PG_HIP_TRY(hipGetLastError());
             if (side) PG_HIP_TRY(hipEventRecord(e->ev_inv, e->side));
         }
-        const uint32_t max_blocks = (uint32_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
+        const uint32_t max_blocks = (uint32_t)e->num_cus * (values_only ? PG_GRID_BLOCKS_PER_CU : PG_EMIT_GRID_BLOCKS_PER_CU);
         const dim3 egrid(O.tiles < max_blocks ? O.tiles : max_blocks);
         if (values_only) {
             if constexpr (ValuesMode<GD>::ok) hipLaunchKernelGGL((pg::emit_kernel<GD, pg::EMIT_VALUES>), egrid, dim3(pg::kThreads), 0, st, A, O);

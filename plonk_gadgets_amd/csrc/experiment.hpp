@@ -14,6 +14,6 @@
      defined(PG_INV_GRP) || defined(PG_RC_W) || defined(PG_MB_W) || defined(PG_MIX_VARS_VGPRS) || defined(PG_MIX_STAMPS) ||     \
      defined(PG_QUEUE_MAX) || defined(PG_PERM_LDS_PAD) || defined(PG_GRID_BLOCKS_PER_CU) || defined(PG_PLAN_TWO_LAUNCHES) ||    \
      defined(PG_INV_LANES_PER_CU) || defined(PG_INV_MAX_PER_LANE) || defined(PG_SIDE_STREAM_NORMAL_PRIORITY) || defined(PG_VAR_SWEEP_SINGLE) || \
-     defined(PG_TILE_SPREAD) || defined(PG_MIX_EARLY_TILES) || defined(PG_MAT_THREADS) || defined(PG_MAT_UNROLL) || defined(PG_MAT_LOADS) || defined(PG_PERM_LADDER_ROWS) || defined(PG_PERM_LADDER_LDS) || defined(PG_MAT_GRID_PER_CU))
+     defined(PG_TILE_SPREAD) || defined(PG_MIX_EARLY_TILES) || defined(PG_MAT_THREADS) || defined(PG_MAT_UNROLL) || defined(PG_MAT_LOADS) || defined(PG_PERM_LADDER_ROWS) || defined(PG_PERM_LADDER_LDS) || defined(PG_MAT_GRID_PER_CU) || defined(PG_EMIT_GRID_BLOCKS_PER_CU))
 #error "a PG_... build option is defined without -DPG_EXPERIMENT: the shipped library is built with none of them (csrc/experiment.hpp)"
 #endif

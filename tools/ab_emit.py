@@ -50,6 +50,8 @@ VARIANTS = {
     "lr8192_l2": ["-DPG_PERM_LADDER_LDS=80896"], "lr512_l3": ["-DPG_PERM_LADDER_ROWS=512", "-DPG_PERM_LADDER_LDS=53248"],
     "lr512_l5": ["-DPG_PERM_LADDER_ROWS=512", "-DPG_PERM_LADDER_LDS=31744"], "lr512_l6": ["-DPG_PERM_LADDER_ROWS=512", "-DPG_PERM_LADDER_LDS=26624"],
     "lr1024_l3": ["-DPG_PERM_LADDER_ROWS=1024", "-DPG_PERM_LADDER_LDS=53248"], "lr8192_l4": ["-DPG_PERM_LADDER_LDS=39936"],
+    "ga_mbw8": ["-DPG_GRID_BLOCKS_PER_CU=1000000", "-DPG_MB_W=8"], "ga_mbw32": ["-DPG_GRID_BLOCKS_PER_CU=1000000", "-DPG_MB_W=32"],
+    "ga_mbw4": ["-DPG_GRID_BLOCKS_PER_CU=1000000", "-DPG_MB_W=4"], "g256": ["-DPG_GRID_BLOCKS_PER_CU=256"], "g128": ["-DPG_GRID_BLOCKS_PER_CU=128"],
     "mat_g1m": ["-DPG_MAT_GRID_PER_CU=1000000"], "mat_g8": ["-DPG_MAT_GRID_PER_CU=8"], "mat_g2": ["-DPG_MAT_GRID_PER_CU=2"], "mat_g256": ["-DPG_MAT_GRID_PER_CU=256"],
     "mat_l16": ["-DPG_MAT_LOADS=16"], "mat_l4": ["-DPG_MAT_LOADS=4"], "mat_l16_u1": ["-DPG_MAT_LOADS=16", "-DPG_MAT_UNROLL=1"],
     "mat_u1": ["-DPG_MAT_UNROLL=1"], "mat_u4": ["-DPG_MAT_UNROLL=4"], "mat_t256b": ["-DPG_MAT_THREADS=256"], "mat_t1024": ["-DPG_MAT_THREADS=960"],
