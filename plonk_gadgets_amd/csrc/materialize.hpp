@@ -38,10 +38,12 @@ constexpr uint32_t kMatTailRows = 16;      // rows of the NEXT group that come a
 // how the store waves learn a row's three Variables
 enum : int {
     MAT_READ_WIRES = 0,  // from the wire columns (any batched call)
-    MAT_CLOSED = 1,      // in closed form (PermSeg::wire_kind, a uniform ladder gadget), except a witness allocated elsewhere
-    MAT_SELF = 2,        // in closed form and all of them the item's own (range_check / max_bound that allocate their witness): the
-                         // store waves load NOTHING -- the rows that come along from the next group get their values from the loader
+    MAT_CLOSED = 1,      // in closed form (PermSeg::wire_kind, a uniform ladder gadget), except a witness allocated elsewhere: read back
+    MAT_SELF = 2,        // in closed form, and the store waves load NOTHING: the rows that come along from the next group and the ONE
+                         // Variable per item that may come from elsewhere (the witness of the `_allocated` kinds and of
+                         // scalar_decomposition) get their values from the loader; groups of at most kMatWitItems items
 };
+constexpr uint32_t kMatWitItems = 4;  // (these kinds create >= 257 Variables per item: a window holds at most four)
 
 template <int MODE>
 __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const ComposerCols C, const MaterializeOut M, const PermSeg S,
@@ -49,16 +51,22 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
     constexpr bool CLOSED = MODE != MAT_READ_WIRES;
     __shared__ uint4 s_win[2][2 * kMatWindowVars];
     __shared__ uint4 s_tail[2][MODE == MAT_SELF ? kMatTailRows * 6 : 1];
+    __shared__ uint4 s_wit[2][MODE == MAT_SELF ? kMatWitItems * 2 : 1];  // the items' witnesses, when they are Variables from elsewhere
     const uint32_t tid = threadIdx.x;
     const bool loader = tid >= (uint32_t)kMatStoreThreads;
     FrVec one;
     one.f = fr_one();
     const uint4 v1 = (tid & 1) ? one.v[1] : one.v[0], v0 = make_uint4(0, 0, 0, 0);
     const uint64_t n_groups = (S.items + group - 1) / group;
-    struct Group { uint64_t r0, r1, w0, ubeg, uend; uint32_t nv; };
+    struct Group { uint64_t r0, r1, w0, ubeg, uend; uint32_t nv, items; };
+    // where an item's witness stands when it is a Variable from elsewhere (kWitnessWire: this kind allocates it itself)
+    const uint32_t foreign_row = S.wire_kind == WIRES_DECOMPOSITION ? 2 * S.wire_n + 1
+                                 : S.wire_kind == WIRES_RANGE_CHECK_ALLOCATED || S.wire_kind == WIRES_MAX_BOUND_ALLOCATED ? 0u : kWitnessWire;
+    const uint32_t foreign_wire = S.wire_kind == WIRES_DECOMPOSITION ? 1u : 0u;
     auto group_of = [&](uint64_t g) {
         Group G;
         const uint64_t i0 = g * group, i1 = i0 + group < S.items ? i0 + group : S.items;
+        G.items = (uint32_t)(i1 - i0);
         if constexpr (CLOSED) {  // (uniform items: no prefix sums to fetch -- a load here is a drain of the store waves per group)
             G.r0 = S.gate_base + i0 * S.L;
             G.r1 = S.gate_base + i1 * S.L;
@@ -117,9 +125,16 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
                 for (; rr >= S.L; rr -= S.L) vb += S.V;
                 uint32_t off[3];
                 seg_wire_offsets(S.wire_kind, S.wire_n, rr, off);
-                const uint64_t var = G.w0 + G.nv + vb + (k == 0 ? off[0] : k == 1 ? off[1] : off[2]);
+                const uint32_t o = k == 0 ? off[0] : k == 1 ? off[1] : off[2];
+                const uint64_t var = o == kWitnessWire ? C.w[k][G.r1 + lane / 3] : G.w0 + G.nv + vb + o;
                 s_tail[buf][2 * lane] = C.vars[2 * var];
                 s_tail[buf][2 * lane + 1] = C.vars[2 * var + 1];
+            }
+            // lanes 48 ..: the witness of item (lane - 48) of the group, read from the row and wire that hold it
+            if (foreign_row != kWitnessWire && lane >= 48 && lane - 48 < G.items) {
+                const uint64_t var = C.w[foreign_wire][G.r0 + (uint64_t)(lane - 48) * S.L + foreign_row];
+                s_wit[buf][2 * (lane - 48)] = C.vars[2 * var];
+                s_wit[buf][2 * (lane - 48) + 1] = C.vars[2 * var + 1];
             }
         }
     };
@@ -148,8 +163,8 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
                 if constexpr (CLOSED) {
                     // the row's item (of the group, or -- the rows that come along with the last line -- the one after it) and
                     // its place in it; Variables relative to the window's first
-                    uint32_t rr = (uint32_t)(r - r0), vb = 0;
-                    for (; rr >= S.L; rr -= S.L) vb += S.V;
+                    uint32_t rr = (uint32_t)(r - r0), vb = 0, it = 0;
+                    for (; rr >= S.L; rr -= S.L) { vb += S.V; it++; }
                     uint32_t off[3];
                     seg_wire_offsets(S.wire_kind, S.wire_n, rr, off);
                     if constexpr (MODE == MAT_SELF) {
@@ -158,7 +173,9 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
 #pragma unroll
                         for (int k = 0; k < 3; k++) {
                             const uint32_t rel = vb + off[k];
-                            got[j][k] = along ? s_tail[buf][t + 2 * k] : win[2 * (rel < nv ? rel : 0) + half];
+                            got[j][k] = along ? s_tail[buf][t + 2 * k]
+                                        : off[k] == kWitnessWire ? s_wit[buf][2 * (it < kMatWitItems ? it : 0) + half]
+                                                                 : win[2 * (rel < nv ? rel : 0) + half];
                         }
                     } else {
 #pragma unroll

@@ -47,6 +47,9 @@ struct PermSeg {
     // what the emitter wrote them from), so whoever needs the Variables of a row -- the wire-value columns of
     // pg_composer_materialize -- can compute them instead of reading 24 bytes per row back.
     uint32_t wire_kind, wire_n;
+    // perm_ladder_kernel: the segment's slots on the sparse list -- ladder_foreign_per_item(wire_kind) per item, in closed form (set by
+    // pg_composer_permutation for the pass it launches)
+    uint64_t sparse_base;
 };
 enum : uint32_t { WIRES_UNKNOWN = 0, WIRES_RANGE_CHECK = 1, WIRES_MAX_BOUND = 2, WIRES_RANGE_CHECK_ALLOCATED = 3, WIRES_MAX_BOUND_ALLOCATED = 4,
                   WIRES_DECOMPOSITION = 5 };
@@ -93,6 +96,7 @@ struct PermCtx {
     uint32_t n_fw;
     uint64_t fw_lo, fw_span;  // live fourth wires only on gates [fw_lo, fw_lo + fw_span]
     uint32_t pos_bits;        // bits of a position 4 * gate + wire; sparse key = Variable << pos_bits | position
+    uint64_t hole_key;        // every sorted bit set (no Variable has that number): a reserved slot of the list that holds nothing
 };
 
 constexpr uint32_t kPermIters = 16;                               // gates per thread of the gap kernel
@@ -141,9 +145,15 @@ __device__ __forceinline__ int perm_home_seg(const PermCtx &X, uint64_t var) {
 
 struct PermSparse {
     uint64_t *keys;               // Variable << pos_bits | position, in any order
-    unsigned long long *count;    // entries wanted so far (may pass cap: the host then grows the list and runs again)
+    unsigned long long *count;    // entries wanted so far (may pass cap: the host then grows the list and runs again); count[1]: how many
+                                  // of them are holes (hole_key: they sort to the end and are not looked at)
     uint64_t cap;
 };
+
+__global__ void perm_count_init_kernel(unsigned long long *count, unsigned long long reserved) {
+    count[0] = reserved;  // (slots handed out in closed form, perm_ladder_kernel; the counter continues behind them)
+    count[1] = 0;
+}
 
 __device__ __forceinline__ void perm_sparse_put(const PermCtx &X, const PermSparse &Q, uint64_t at, uint64_t var, uint64_t gate,
                                                 uint32_t wire) {
@@ -415,6 +425,16 @@ __device__ __forceinline__ uint32_t ladder_foreign_wires(uint32_t kind, uint32_t
     return 0u;
 }
 
+// positions of an item that hold a witness allocated elsewhere, and the rank of (item-row j, wire w) among them in recording order:
+// every item owns that many consecutive slots of the sparse list, so a lane knows where its entry goes without asking anybody
+__host__ __device__ inline uint32_t ladder_foreign_per_item(uint32_t kind) {
+    return kind == WIRES_RANGE_CHECK_ALLOCATED ? 4u : kind == WIRES_MAX_BOUND_ALLOCATED ? 2u : kind == WIRES_DECOMPOSITION ? 1u : 0u;
+}
+__device__ __forceinline__ uint32_t ladder_foreign_rank(uint32_t kind, uint32_t j, uint32_t w) {
+    if (kind == WIRES_DECOMPOSITION) return 0u;
+    return (j ? 2u : 0u) + w;  // rows 0 (and 2n + 5 of range_check): wires 0 and 1
+}
+
 #ifndef PG_PERM_LADDER_ROWS
 #define PG_PERM_LADDER_ROWS 512
 #endif
@@ -456,8 +476,8 @@ __global__ __launch_bounds__(kThreads) void perm_ladder_kernel(const PermCtx X, 
         const uint64_t item0 = rel / S.L;
         const uint32_t j0 = (uint32_t)(rel - item0 * S.L), skip = (uint32_t)(g_first < S.gate_base ? S.gate_base - g_first : 0);
         for (uint32_t t = 2 * threadIdx.x; t < kPermLadderRows; t += 2 * kThreads) {  // (whole waves: the ballot below)
-            uint64_t out[4][2];
-            uint32_t foreign[2] = {0, 0};
+            uint64_t out[4][2], fitem[2] = {0, 0};
+            uint32_t foreign[2] = {0, 0}, fslots[2] = {0, 0}, fj[2] = {0, 0};
             bool live[2];
 #pragma unroll
             for (uint32_t h = 0; h < 2; h++) {
@@ -472,6 +492,9 @@ __global__ __launch_bounds__(kThreads) void perm_ladder_kernel(const PermCtx X, 
                 uint32_t j2[3], w2[3];
                 const uint32_t fw = ladder_row(kind, n, j, j2, w2), zw = fw ? zero_wires(g, j) : 0u;
                 foreign[h] = fw & ~zw;
+                fslots[h] = fw;
+                fitem[h] = item0 + q;
+                fj[h] = j;
 #pragma unroll
                 for (uint32_t w = 0; w < 3; w++) {
                     if (fw >> w & 1) {  // zero_var here: the next wire of this row that holds it (the fourth one at the latest)
@@ -503,22 +526,21 @@ __global__ __launch_bounds__(kThreads) void perm_ladder_kernel(const PermCtx X, 
                     if (!skip1) dst[1] = out[w][1];
                 }
             }
-            // the positions that hold a Variable from elsewhere other than zero_var: one reservation per wave
-            const uint32_t mine = (uint32_t)__popc(foreign[0]) + (uint32_t)__popc(foreign[1]);
-            if (__ballot(mine != 0)) {
-                uint32_t before = 0, all = 0;
-                for (uint32_t k = 0; k < 64; k++) {  // (rare: two rows of an item)
-                    const uint32_t c = (uint32_t)__shfl((int)mine, (int)k, 64);
-                    if (k < lane) before += c;
-                    all += c;
-                }
-                unsigned long long at = 0;
-                if (lane == 0) at = atomicAdd(Q.count, (unsigned long long)all);
-                at = __shfl(at, 0, 64) + before;
+            // the positions that hold a Variable from elsewhere go to the sparse list, each into its item's own slot (closed form: no
+            // counter, no shuffle -- a reservation per wave cost an agent-scope atomic's round trip in a quarter of all wave passes, 6.4 ms
+            // against 1.5 for 270 M rows); one that holds zero_var belongs to the zero chain and leaves a hole
+            if (fslots[0] | fslots[1]) {
+                const uint32_t F = ladder_foreign_per_item(kind);
+#pragma unroll
                 for (uint32_t h = 0; h < 2; h++)
-                    for (uint32_t m = foreign[h]; m; m &= m - 1) {
+                    for (uint32_t m = fslots[h]; m; m &= m - 1) {
                         const uint32_t w = (uint32_t)__ffs((int)m) - 1;
-                        perm_sparse_put(X, Q, at++, X.C.w[w][g + h], g + h, w);
+                        const uint64_t at = S.sparse_base + fitem[h] * F + ladder_foreign_rank(kind, fj[h], w);
+                        if (foreign[h] >> w & 1) perm_sparse_put(X, Q, at, X.C.w[w][g + h], g + h, w);
+                        else {
+                            if (at < Q.cap) Q.keys[at] = X.hole_key;
+                            atomicAdd(Q.count + 1, 1ull);
+                        }
                     }
             }
         }

@@ -994,7 +994,8 @@ def test_materialize_rows_of_batched_calls(engine):
 
 
 @pytest.mark.parametrize("lead", [0, 1, 5])
-@pytest.mark.parametrize("kind,extra", [("max_bound", 1), ("max_bound", 2), ("range_check", 1), ("range_check", 0)])
+@pytest.mark.parametrize("kind,extra", [("max_bound", 1), ("max_bound", 2), ("range_check", 1), ("range_check", 0),
+                                        ("max_bound_allocated", 1), ("range_check_allocated", 1), ("decomposition", 1), ("decomposition", 2)])
 def test_materialize_short_items_and_a_short_last_group(engine, kind, extra, lead):
     """the windowed kernel writes whole lines: a group's range of rows is cut at multiples of 16 rows, so the first rows of the next
     group come along with it (csrc/materialize.hpp: their values through the loader wave's side table).  The corner: items SHORTER
@@ -1006,19 +1007,36 @@ def test_materialize_short_items_and_a_short_last_group(engine, kind, extra, lea
     dev = pg.StandardComposer(engine, 1 << 15, 1 << 21)
     for _ in range(lead):
         dev.add_input(S(7))
-    bound = S(3) if kind == "max_bound" else S(2)
+    bound = S(3) if kind.startswith("max_bound") else S(2)
+
+    def append(comp, w):
+        """the call under test; the `_allocated` kinds and scalar_decomposition on Variables allocated by a call before it (their
+        values reach the rows through the loader wave's witness table, the rows that come along through its side table)"""
+        if kind == "max_bound":
+            return comp.max_bound_batch(bound, w)
+        if kind == "range_check":
+            return comp.range_check_batch(S(0), bound, w)
+        first = comp.add_input_batch(w)
+        vars_ = torch.arange(first, first + w.shape[0], dtype=torch.int64, device="cuda:0")
+        if kind == "max_bound_allocated":
+            return comp.max_bound_allocated_batch(bound, vars_, w)
+        if kind == "range_check_allocated":
+            return comp.range_check_allocated_batch(S(0), bound, vars_, w)
+        return comp.scalar_decomposition_batch(2, vars_, w)
+
     probe = pg.StandardComposer(engine, 1024, 1024)
-    v0, r0 = probe.num_variables(), probe.circuit_size()
     one = torch.from_numpy(np.ascontiguousarray(synth.uniform_below(1, 2, seed=1)).view(np.int64)).to("cuda:0")
-    probe.max_bound_batch(bound, one) if kind == "max_bound" else probe.range_check_batch(S(0), bound, one)
-    V, L = probe.num_variables() - v0, probe.circuit_size() - r0
-    assert L < 16 or kind == "range_check"
+    v0, r0 = probe.num_variables(), probe.circuit_size()
+    append(probe, one)
+    V, L = probe.num_variables() - v0 - (0 if kind in ("max_bound", "range_check") else 1), probe.circuit_size() - r0
+    assert L < 16 or kind.startswith("range_check")
     group = 1040 // V
     items = group * (4096 // (group * L) + 1) + extra
     wit = torch.from_numpy(np.ascontiguousarray(synth.uniform_below(items, 2, seed=3)).view(np.int64)).to("cuda:0")
-    dev.max_bound_batch(bound, wit) if kind == "max_bound" else dev.range_check_batch(S(0), bound, wit)
+    append(dev, wit)
     assert dev.check() == -1
     n, cols = dev.circuit_size(), dev.device_columns()
+    assert n >= 4096 + lead
     names = ("q_4", "q_arith", "q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add")
     vals = ("w_l_value", "w_r_value", "w_o_value", "w_4_value")
     t = {k: torch.full((n + 64, 4), 0x5A5A5A5A5A5A5A5A, dtype=torch.int64, device="cuda:0") for k in names + vals}
