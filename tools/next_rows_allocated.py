@@ -11,8 +11,23 @@ S = pg.BlsScalar.from_int
 batch = 1 << 18
 wit = torch.from_numpy(synth.random_scalars(batch, seed=1).view(np.int64)).to("cuda:0")
 for kind in (sys.argv[1:] or ["own", "allocated", "own", "allocated"]):
-    dev = pg.StandardComposer(eng, 3 + batch * 1031 + 8, 5 + batch * 1035 + 8)
-    if kind == "own":
+    if kind == "ragged":  # C4's shape: per-item public bounds (rows and Variables by prefix sums, wires read back)
+        import bench
+        mr, wt = bench.c4_inputs(1 << 19, seed=5)
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:0")
+        dev = pg.StandardComposer(eng, 3 + (1 << 19) * 516 + 8, 5 + (1 << 19) * 520 + 8)
+        dev.max_bound_ragged_batch(d(mr), d(wt))
+    elif kind == "mix":  # C3's shape: ten rows and fifteen Variables per item
+        import bench
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:0")
+        nmix = 1 << 23
+        dev = pg.StandardComposer(eng, 3 + nmix * 10 + 8, 5 + nmix * 15 + 8)
+        dev.scalar_mix_batch(*[d(x) for x in bench.mix_inputs(nmix, seed=6)])
+    else:
+        dev = pg.StandardComposer(eng, 3 + batch * 1031 + 8, 5 + batch * 1035 + 8)
+    if kind in ("ragged", "mix"):
+        pass
+    elif kind == "own":
         dev.range_check_batch(S(0), S(2**254), wit)
     else:
         first = dev.add_input_batch(wit)
