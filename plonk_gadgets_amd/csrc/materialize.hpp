@@ -38,20 +38,28 @@ constexpr uint32_t kMatTailRows = 16;      // rows of the NEXT group that come a
 // how the store waves learn a row's three Variables
 enum : int {
     MAT_READ_WIRES = 0,  // from the wire columns (any batched call)
-    MAT_CLOSED = 1,      // in closed form (PermSeg::wire_kind, a uniform ladder gadget), except a witness allocated elsewhere: read back
-    MAT_SELF = 2,        // in closed form, and the store waves load NOTHING: the rows that come along from the next group and the ONE
-                         // Variable per item that may come from elsewhere (the witness of the `_allocated` kinds and of
-                         // scalar_decomposition) get their values from the loader; groups of at most kMatWitItems items
+    MAT_SELF = 2,        // in closed form (PermSeg::wire_kind = KIND, compiled in: one instantiation per kind keeps the wire functions
+                         // of the others -- and their registers -- out), and the store waves load NOTHING: the rows that come along
+                         // from the next group and the ONE Variable per item that may come from elsewhere (the witness of the
+                         // `_allocated` kinds and of scalar_decomposition) get their values from the loader; such groups have at most
+                         // kMatWitItems items
 };
 constexpr uint32_t kMatWitItems = 4;  // (these kinds create >= 257 Variables per item: a window holds at most four)
 
-template <int MODE>
+// RAGGED (MAT_SELF, WIRES_MAX_BOUND only): per-item bounds -- rows and Variables by the call's prefix sums, the ladder length of an item
+// from its row count (L = 2 n + 5).  The loader reads the group's prefix sums and leaves them in LDS for the store waves.
+template <int MODE, uint32_t KIND, bool RAGGED = false>
 __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const ComposerCols C, const MaterializeOut M, const PermSeg S,
                                                                         uint32_t group, uint64_t zero_var) {
     constexpr bool CLOSED = MODE != MAT_READ_WIRES;
+    constexpr bool kForeign = KIND == WIRES_RANGE_CHECK_ALLOCATED || KIND == WIRES_MAX_BOUND_ALLOCATED || KIND == WIRES_DECOMPOSITION;
     __shared__ uint4 s_win[2][2 * kMatWindowVars];
     __shared__ uint4 s_tail[2][MODE == MAT_SELF ? kMatTailRows * 6 : 1];
     __shared__ uint4 s_wit[2][MODE == MAT_SELF ? kMatWitItems * 2 : 1];  // the items' witnesses, when they are Variables from elsewhere
+    constexpr uint32_t kOff = kMatWitItems + 1;                            // RAGGED: rows before item k of the group, k = 0 .. items,
+    __shared__ uint32_t s_off[2][RAGGED ? 2 * kOff : 1];                   // then Variables before it
+    __shared__ uint64_t s_base[2][RAGGED ? 2 : 1];                         // RAGGED: rows / Variables of the call before the group
+    static_assert(!RAGGED || (MODE == MAT_SELF && KIND == WIRES_MAX_BOUND), "ragged closed form: max_bound with per-item bounds only");
     const uint32_t tid = threadIdx.x;
     const bool loader = tid >= (uint32_t)kMatStoreThreads;
     FrVec one;
@@ -60,14 +68,29 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
     const uint64_t n_groups = (S.items + group - 1) / group;
     struct Group { uint64_t r0, r1, w0, ubeg, uend; uint32_t nv, items; };
     // where an item's witness stands when it is a Variable from elsewhere (kWitnessWire: this kind allocates it itself)
-    const uint32_t foreign_row = S.wire_kind == WIRES_DECOMPOSITION ? 2 * S.wire_n + 1
-                                 : S.wire_kind == WIRES_RANGE_CHECK_ALLOCATED || S.wire_kind == WIRES_MAX_BOUND_ALLOCATED ? 0u : kWitnessWire;
-    const uint32_t foreign_wire = S.wire_kind == WIRES_DECOMPOSITION ? 1u : 0u;
-    auto group_of = [&](uint64_t g) {
+    const uint32_t foreign_row = KIND == WIRES_DECOMPOSITION ? 2 * S.wire_n + 1
+                                 : KIND == WIRES_RANGE_CHECK_ALLOCATED || KIND == WIRES_MAX_BOUND_ALLOCATED ? 0u : kWitnessWire;
+    const uint32_t foreign_wire = KIND == WIRES_DECOMPOSITION ? 1u : 0u;
+    const uint32_t recip_L = (uint32_t)(((1ull << 32) + S.L - 1) / (S.L ? S.L : 1));
+    // lds_buf >= 0: a store wave asks (RAGGED: the loader has left the group's prefix sums in that buffer -- a load here would drain the
+    // wave's stores once per group); < 0: the loader asks
+    auto group_of = [&](uint64_t g, int lds_buf) {
         Group G;
         const uint64_t i0 = g * group, i1 = i0 + group < S.items ? i0 + group : S.items;
         G.items = (uint32_t)(i1 - i0);
-        if constexpr (CLOSED) {  // (uniform items: no prefix sums to fetch -- a load here is a drain of the store waves per group)
+        if constexpr (RAGGED) {
+            if (lds_buf >= 0) {
+                G.r0 = S.gate_base + s_base[lds_buf][0];
+                G.r1 = G.r0 + s_off[lds_buf][G.items];
+                G.w0 = S.var_base + s_base[lds_buf][1];
+                G.nv = s_off[lds_buf][kOff + G.items];
+            } else {
+                G.r0 = S.gate_base + S.row_off[i0];
+                G.r1 = S.gate_base + S.row_off[i1];
+                G.w0 = S.var_base + S.var_off[i0];
+                G.nv = (uint32_t)(S.var_off[i1] - S.var_off[i0]);
+            }
+        } else if constexpr (CLOSED) {  // (uniform items: no prefix sums to fetch)
             G.r0 = S.gate_base + i0 * S.L;
             G.r1 = S.gate_base + i1 * S.L;
             G.w0 = S.var_base + i0 * S.V;
@@ -92,7 +115,7 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
     // the loader's part of group g: the Variables its items created -- a run of the table, read linearly -- and (MAT_SELF) the
     // values of the rows that come along from the items after it
     auto fetch = [&](uint64_t g, uint32_t buf) {
-        const Group G = group_of(g);
+        const Group G = group_of(g, -1);
         const uint32_t units = 2 * G.nv, lane = tid - kMatStoreThreads;
         const uint4 *src = C.vars + 2 * G.w0;
         uint4 *win = s_win[buf];
@@ -120,15 +143,37 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
         if constexpr (MODE == MAT_SELF) {
             const uint32_t rows = (uint32_t)((G.uend - 2 * G.r1) >> 1);  // (2 r1 <= uend: whole rows, at most 15)
             if (lane < 3 * rows) {
-                uint32_t rr = lane / 3, vb = 0;
+                uint32_t rr = lane / 3, vb = 0, n = S.wire_n;
                 const uint32_t k = lane - 3 * rr;
-                for (; rr >= S.L; rr -= S.L) vb += S.V;
+                if constexpr (RAGGED) {  // the item of that row, from the prefix sums behind the group's last item
+                    uint64_t it = g * group + G.items;
+                    const uint64_t rows0 = S.row_off[it], vars0 = S.var_off[it];
+                    while (S.row_off[it + 1] - rows0 <= rr) it++;  // (the row lies inside the call: uend stops at its last row)
+                    const uint64_t first = S.row_off[it];
+                    n = (uint32_t)(S.row_off[it + 1] - first - 5) >> 1;
+                    rr -= (uint32_t)(first - rows0);
+                    vb = (uint32_t)(S.var_off[it] - vars0);
+                } else {
+                    for (; rr >= S.L; rr -= S.L) vb += S.V;
+                }
                 uint32_t off[3];
-                seg_wire_offsets(S.wire_kind, S.wire_n, rr, off);
+                seg_wire_offsets(KIND, n, rr, off);
                 const uint32_t o = k == 0 ? off[0] : k == 1 ? off[1] : off[2];
-                const uint64_t var = o == kWitnessWire ? C.w[k][G.r1 + lane / 3] : G.w0 + G.nv + vb + o;
+                const uint64_t var = o == kWitnessWire ? C.w[k][G.r1 + lane / 3] : o == kZeroWire ? zero_var : G.w0 + G.nv + vb + o;
                 s_tail[buf][2 * lane] = C.vars[2 * var];
                 s_tail[buf][2 * lane + 1] = C.vars[2 * var + 1];
+            }
+            if constexpr (RAGGED) {  // lanes 48 ..: the group's prefix sums for the store waves (entries behind the last item: never reached)
+                const uint64_t i0 = g * group;
+                if (lane >= 48 && lane - 48 < kOff) {
+                    const uint32_t e = lane - 48;
+                    s_off[buf][e] = e <= G.items ? (uint32_t)(S.row_off[i0 + e] - S.row_off[i0]) : 0xffffffffu;
+                    s_off[buf][kOff + e] = e <= G.items ? (uint32_t)(S.var_off[i0 + e] - S.var_off[i0]) : 0u;
+                }
+                if (lane == 47) {
+                    s_base[buf][0] = S.row_off[i0];
+                    s_base[buf][1] = S.var_off[i0];
+                }
             }
             // lanes 48 ..: the witness of item (lane - 48) of the group, read from the row and wire that hold it
             if (foreign_row != kWitnessWire && lane >= 48 && lane - 48 < G.items) {
@@ -148,7 +193,7 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
             continue;
         }
         const uint4 *win = s_win[buf];
-        const Group G = group_of(g);
+        const Group G = group_of(g, (int)buf);
         const uint64_t r0 = G.r0, w0 = G.w0, ubeg = G.ubeg, uend = G.uend;
         const uint32_t nv = G.nv;
         constexpr int U = PG_MAT_UNROLL;  // units per lane and pass
@@ -163,25 +208,37 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
                 if constexpr (CLOSED) {
                     // the row's item (of the group, or -- the rows that come along with the last line -- the one after it) and
                     // its place in it; Variables relative to the window's first
-                    uint32_t rr = (uint32_t)(r - r0), vb = 0, it = 0;
-                    for (; rr >= S.L; rr -= S.L) { vb += S.V; it++; }
+                    // (floor(x / L) = umulhi(x, ceil(2^32 / L)), exact while x * L < 2^32: a group has a few thousand rows at most)
+                    uint32_t rr = (uint32_t)(r - r0), it, vb, n = S.wire_n;
+                    if constexpr (RAGGED) {  // (at most kMatWitItems items: compare with the prefix sums the loader left)
+                        it = 0;
+#pragma unroll
+                        for (uint32_t e = 1; e < kMatWitItems; e++) it += rr >= s_off[buf][e] ? 1u : 0u;
+                        const uint32_t first = s_off[buf][it];
+                        n = (s_off[buf][it + 1] - first - 5) >> 1;
+                        vb = s_off[buf][kOff + it];
+                        rr -= first;
+                    } else {
+                        it = __umulhi(rr, recip_L);
+                        vb = it * S.V;
+                        rr -= it * S.L;
+                    }
                     uint32_t off[3];
-                    seg_wire_offsets(S.wire_kind, S.wire_n, rr, off);
-                    if constexpr (MODE == MAT_SELF) {
+                    seg_wire_offsets(KIND, n, rr, off);
+                    {
                         const bool along = r >= G.r1;
                         const uint32_t t = along ? (uint32_t)(r - G.r1) * 6 + half : 0;
 #pragma unroll
                         for (int k = 0; k < 3; k++) {
+                            // ONE LDS read per value: from the window, the witness table or the side table of the rows that came along
                             const uint32_t rel = vb + off[k];
-                            got[j][k] = along ? s_tail[buf][t + 2 * k]
-                                        : off[k] == kWitnessWire ? s_wit[buf][2 * (it < kMatWitItems ? it : 0) + half]
-                                                                 : win[2 * (rel < nv ? rel : 0) + half];
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 3; k++) {
-                            idx[j][k] = w0 + vb + off[k];
-                            if (off[k] == kWitnessWire) idx[j][k] = M.val[k] ? C.w[k][r] : w0;  // (an `_allocated` call's witness)
+                            const uint4 *src = win + 2 * (rel < nv ? rel : 0) + half;
+                            if constexpr (kForeign)
+                                if (off[k] == kWitnessWire) src = s_wit[buf] + 2 * (it < kMatWitItems ? it : 0) + half;
+                            if (along) src = s_tail[buf] + t + 2 * k;
+                            got[j][k] = *src;
+                            if constexpr (KIND == WIRES_MIX)
+                                if (off[k] == kZeroWire && !along) got[j][k] = make_uint4(0, 0, 0, 0);
                         }
                     }
                 } else {

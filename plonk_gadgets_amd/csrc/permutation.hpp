@@ -52,11 +52,29 @@ struct PermSeg {
     uint64_t sparse_base;
 };
 enum : uint32_t { WIRES_UNKNOWN = 0, WIRES_RANGE_CHECK = 1, WIRES_MAX_BOUND = 2, WIRES_RANGE_CHECK_ALLOCATED = 3, WIRES_MAX_BOUND_ALLOCATED = 4,
-                  WIRES_DECOMPOSITION = 5 };
+                  WIRES_DECOMPOSITION = 5,
+                  WIRES_MIX = 6 };  // the fused scalar mix, every item complete (ten rows, fifteen Variables: ScalarMixGD::row)
+constexpr uint32_t kZeroWire = 0xfffffffeu;  // "zero_var" (the composer's Variable with value 0: is_non_zero's first row has it)
 // offsets (from the item's first own Variable) of the three wires of item-row j; kWitnessWire: the witness, which is the item's
 // first Variable for the kinds that allocate it and a Variable from elsewhere (read it from the wire column) for the others
 __device__ __forceinline__ void seg_wire_offsets(uint32_t kind, uint32_t n, uint32_t j, uint32_t off[3]) {
     const uint32_t x0 = kind == WIRES_RANGE_CHECK || kind == WIRES_MAX_BOUND ? 1u : 0u;
+    if (kind == WIRES_MIX) {
+        // ScalarMixGD::row of an item whose v is not 0, as a table: Variables [v y s a b | va inv one | one' sy oms out | u z yeq] = 0 .. 14,
+        // 15 = zero_var; four bits per wire, rows 0 .. 4 in the first word and 5 .. 9 in the second (a RowOut here cost the caller a
+        // scratch array).  tests/test_gpu_composer.py compares what this yields with the wires the emitter wrote, row for row.
+        //   0: (v, va, 0)   1: (one, one, one)   2: (v, inv, one)   3: (one', one', one')   4: (y, s, sy)
+        //   5: (one', s, oms)   6: (sy, oms, out)   7: (a, b, u)   8: (z, u, yeq)   9: (yeq, u, u)
+        constexpr uint64_t lo = 0xF50ull | 0x777ull << 12 | 0x760ull << 24 | 0x888ull << 36 | 0x921ull << 48;
+        constexpr uint64_t hi = 0xA28ull | 0xBA9ull << 12 | 0xC43ull << 24 | 0xECDull << 36 | 0xCCEull << 48;
+        const uint32_t row = (uint32_t)((j < 5 ? lo : hi) >> (12 * (j < 5 ? j : j - 5))) & 0xFFFu;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const uint32_t o = row >> (4 * c) & 15u;
+            off[c] = o == 15u ? kZeroWire : o;
+        }
+        return;
+    }
     if (kind == WIRES_RANGE_CHECK || kind == WIRES_RANGE_CHECK_ALLOCATED) {  // RangeCheckGD::wires
         const uint32_t L = 2 * n + 5, VB = n + 261;
         if (j == 2 * L) {

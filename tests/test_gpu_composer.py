@@ -951,7 +951,7 @@ def test_materialize_rows_of_batched_calls(engine):
     n_items = 70
     dev = pg.StandardComposer(engine, 1 << 18, 1 << 18)
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:0")
-    wit = d(synth.random_scalars(n_items, 11))
+    wit = d(synth.random_scalars(n_items, 11))  # (the mix's inputs below are random field elements: none is 0)
     small = d(synth.uniform_below(n_items, 300_000, seed=12))
     x = dev.add_input(S(9))
     dev.range_check_batch(S(0), S(2**254), wit[:9])                    # n = 255: one item per window, lines shared with the next
@@ -970,6 +970,8 @@ def test_materialize_rows_of_batched_calls(engine):
     v, y, s, a, b = bench.mix_inputs(900, seed=6)
     v[[3, 500]] = 0
     assert dev.scalar_mix_batch(d(v), d(y), d(s), d(a), d(b))[2] == 2  # two items stop at is_non_zero's error: a ragged call
+    dev.boolean_gate(dev.add_witness_to_circuit_description(S(0)))       # (an odd row in between)
+    assert dev.scalar_mix_batch(*[d(t) for t in bench.mix_inputs(700, seed=16)])[2] == 0  # every item complete: its wires from the table
     big = torch.arange(first, first + n_items, dtype=torch.int64, device="cuda:0").repeat(70)
     dev.maybe_equal_batch(big, big.flip(0))
     dev.add_batch(S(3), big, S(5), big.flip(0), S(1))
