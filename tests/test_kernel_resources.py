@@ -12,6 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
+def code_object(tmp_path):
+    """path of the gfx950 code object unbundled from the built library"""
+    code_object_notes(tmp_path)
+    return str(tmp_path / "dev.co")
+
+
 def code_object_notes(tmp_path):
     from plonk_gadgets_amd import build as pg_build
     lib = pg_build.build()
@@ -56,3 +62,28 @@ def test_no_kernel_uses_scratch_and_residency_assumptions_hold(tmp_path):
         assert k["vgpr"] <= 128
     emit = [k for n, k in ks.items() if "emit_kernel" in n and "RangeCheckGDELi0E" in n]  # the full emission (EMIT_ALL): four waves per SIMD
     assert emit and all(k["vgpr"] <= 128 for k in emit)
+
+
+def test_the_writing_waves_of_materialize_wait_for_no_memory_operation(tmp_path):
+    """csrc/materialize.hpp: a wave's loads and stores share ONE counter (vmcnt), so a wait for a load -- or for a scratch reload, which is
+    a vector memory operation too -- between two stores drains the wave's store stream; the compiler places such waits where control flow
+    meets, taken or not.  In the closed-form instantiations (MAT_SELF, one per wire kind) the eight writing waves must execute none: in the
+    disassembly, no `s_waitcnt vmcnt` between the kernel's first and last global store (the loader wave's code comes before them).
+    Twice this round a build that computed the right values was 20 % slower for exactly this (NOTES_r05 section 8)."""
+    objdump = os.path.join(LLVM, "llvm-objdump")
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    asm = subprocess.run([objdump, "-d", code_object(tmp_path)], capture_output=True, text=True, check=True).stdout
+    bodies = re.split(r"\n[0-9a-f]+ <([^>]+)>:\n", asm)  # (every symbol: a body ends where the next one begins)
+    seen = 0
+    for name, body in zip(bodies[1::2], bodies[2::2]):
+        if "materialize_items_kernelILi2E" not in name:
+            continue
+        seen += 1
+        lines = body.split("\n")
+        stores = [i for i, l in enumerate(lines) if "global_store" in l]
+        assert len(stores) >= 11, (name, len(stores))
+        waits = [lines[i].strip() for i in range(stores[0], stores[-1]) if re.search(r"s_waitcnt.*vmcnt", lines[i])]
+        assert not waits, (name, waits[:3])
+        assert not any("scratch_" in l for l in lines), name
+    assert seen >= 7, seen  # six kinds + the per-item-bounds form
