@@ -1057,6 +1057,66 @@ def test_materialize_short_items_and_a_short_last_group(engine, kind, extra, lea
     assert torch.equal(t["w_4_value"][:n], cols.var_values[t["w_4"][:n]])
 
 
+def test_f_rows_of_runs_of_single_calls(engine):
+    """A circuit built the reference's way -- ONE allocate + range_check at a time (tests/range_gadgets_tests.rs:29-44), the command
+    queue on -- leaves runs of identical calls, which a flush sends out as one batched launch and (csrc/capi_composer.inc,
+    add_run_segment) registers with the batched append's footprint: the f-rows then take the closed forms.  Runs long enough to be
+    registered (>= 4096 rows) of all four shapes: allocate + range_check pairs, allocate + max_bound pairs, and both gadgets on
+    witnesses allocated beforehand, with gates between the runs, a run cut in two by a flush, and results used by later rows.
+    sigma == the oracle's bookkeeping; the wire-value columns == variables[w] gathered by torch; check() passes."""
+    import ctypes as C
+    from oracle import pyoracle as po
+    dev, ora = pg.StandardComposer(engine, 1 << 17, 1 << 17), po.Composer()
+    dev.queue(True)
+    F = lambda x: po.fr(synth.mont(x))
+    mn, mx, mb = 50_000, 250_000, 2**30
+    nb = C.c_uint64()
+    vals = [int(v) for v in synth.splitmix64(400, 77) % np.uint64(300_000)]
+    res = []
+    for k, v in enumerate(vals[:70]):       # 70 x (allocate, range_check): n = 18, 83 rows each
+        a = pg.AllocatedScalar.allocate(dev, S(v))
+        res.append(pg.range_check(dev, S(mn), S(mx), a))
+        assert res[-1] == int(ora.L.range_check(ora.c, F(mn), F(mx), ora.allocate(synth.scalars_from_ints([v])[0])))
+        if k == 40:
+            dev.flush()                      # (the run goes out in two launches: one footprint all the same)
+    dev.boolean_gate(dev.add_witness_to_circuit_description(S(1)))
+    ora.L.composer_boolean_gate(ora.c, ora.L.composer_add_witness_to_circuit_description(ora.c, F(1)))
+    for v in vals[70:140]:                  # 70 x (allocate, max_bound): n = 30, 65 rows each
+        a = pg.AllocatedScalar.allocate(dev, S(v))
+        r, _ = pg.max_bound(dev, S(mb), a)
+        res.append(r)
+        assert r == int(ora.L.max_bound(ora.c, F(mb), ora.allocate(synth.scalars_from_ints([v])[0]), C.byref(nb)))
+    allocs = [pg.AllocatedScalar.allocate(dev, S(v)) for v in vals[140:280]]
+    oallocs = [ora.allocate(synth.scalars_from_ints([v])[0]) for v in vals[140:280]]
+    for a, oa in zip(allocs[:70], oallocs[:70]):    # gadgets on witnesses allocated beforehand
+        res.append(pg.range_check(dev, S(mn), S(mx), a))
+        assert res[-1] == int(ora.L.range_check(ora.c, F(mn), F(mx), oa))
+    for a, oa in zip(allocs[70:], oallocs[70:]):
+        r, _ = pg.max_bound(dev, S(mb), a)
+        res.append(r)
+        assert r == int(ora.L.max_bound(ora.c, F(mb), oa, C.byref(nb)))
+    z = pg.conditionally_select_zero(dev, res[3], res[-1])
+    assert z == int(ora.L.conditionally_select_zero(ora.c, res[3], res[-1]))
+    dev.assert_equal(res[100], res[100])
+    ora.L.composer_assert_equal(ora.c, res[100], res[100])
+    same(dev, ora)
+    n = dev.circuit_size()
+    assert n > 4 * 4096
+    padded = 1 << (n - 1).bit_length()
+    got, exp = dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded)
+    if not np.array_equal(got, exp):
+        w, g = np.argwhere(got != exp)[0]
+        raise AssertionError(f"sigma differs first at wire {w}, gate {g}: {got[w, g]} != {exp[w, g]}")
+    _sigma_properties(dev, padded)
+    cols, m = dev.device_columns(), dev.materialize()
+    for wname in ("w_l", "w_r", "w_o"):
+        w = getattr(cols, wname)[:n]
+        expv, gotv = cols.var_values[w], m[wname + "_value"]
+        if not torch.equal(gotv, expv):
+            bad = int((gotv != expv).any(dim=1).nonzero()[0])
+            raise AssertionError(f"{wname}_value differs first at row {bad} (Variable {int(w[bad])})")
+
+
 @pytest.mark.parametrize("bits", [1, 2, 3, 19, 128, 251, 252, 253, 254, 255])
 def test_ladder_sigma_closed_form_over_the_ladder_lengths(engine, bits):
     """sigma of the ladder gadgets' rows is written in closed form (csrc/permutation.hpp, perm_ladder_kernel: which positions hold
