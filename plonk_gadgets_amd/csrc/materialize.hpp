@@ -6,10 +6,11 @@
 // batched call (PermSeg: `items` items of L rows that created V Variables each, one after the other) reference almost
 // nothing but their own item's Variables -- a run of V consecutive entries of the variable table.  So a workgroup takes a
 // GROUP of consecutive items whose Variables fit its LDS window, reads that run LINEARLY (coalesced 16-byte loads, every
-// byte of the table exactly once), and serves the rows' look-ups from LDS; the wire indices themselves are read linearly
-// too (they are what makes the kernel gadget-agnostic: any batched append, uniform or ragged, present or future).  What
-// is left for memory is three linear streams in and eleven out.  A reference outside the window (the allocated witness of
-// an `_allocated_batch` call, zero_var) goes to memory as before.
+// byte of the table exactly once), and serves the rows' look-ups from LDS.  Where the call's wires are known in closed form
+// (PermSeg::wire_kind: the five ladder kinds, per-item bounds, the complete scalar mix) the rows' Variables are computed from
+// their place in their item and nothing else is read: one linear stream in and eleven out (MAT_SELF).  Any other batched
+// append, present or future, has its wire indices read linearly too, and a reference outside the window fetched from memory
+// as before (MAT_READ_WIRES).
 #pragma once
 
 #include "permutation.hpp"
