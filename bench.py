@@ -558,8 +558,9 @@ def next_rows_secondary(eng, dev, log2_batch: int, steps: int):
                                        "frac": (wr + rd) / (med / 1e3) / 1e9 / HBM_PEAK_GBPS,
                                        "algorithmic_bytes": {"written": wr, "read": rd},
                                        "frac_counting_writes_only": wr / (med / 1e3) / 1e9 / HBM_PEAK_GBPS,
-                                       "kernel": "pg::materialize_items_kernel<true> (one launch per batched call: constant columns, w_4, three "
-                                                 "wire-value columns from an LDS window of the items' Variables, wires in closed form)"}}
+                                       "kernel": "pg::materialize_items_kernel<MAT_SELF, WIRES_RANGE_CHECK> (one launch per batched call: constant columns, "
+                                                 "w_4, three wire-value columns from an LDS window of the items' Variables that a wave of its own "
+                                                 "fetches ahead, wires in closed form)"}}
     med, lo, hi = timed(lambda: lib.pg_composer_permutation(comp._h, padded, sigma.data_ptr()))
     # algorithmic bytes: four sigma columns of 8 B per PADDED row written; the rows of a ladder gadget are linked in closed form (nothing
     # read: csrc/permutation.hpp, perm_ladder_kernel).  (Rounds 1-4 read the 24 B of wire indices per row and counted them.)
@@ -572,7 +573,52 @@ def next_rows_secondary(eng, dev, log2_batch: int, steps: int):
                                                  "(the padding) (+ perm_gap_kernel and the sparse list's sort for the rows of single calls)"}}
     del comp, t, sigma
     torch.cuda.empty_cache()
+    try:  # the same two calls on a circuit built the reference's way: ONE allocate + range_check at a time (tests/range_gadgets_tests.rs:29-44)
+        out["single_calls"] = next_rows_of_single_calls(eng, dev, 4096)
+    except Exception as ex:  # (a side figure)
+        out["single_calls"] = {"error": repr(ex)}
     return out
+
+
+def next_rows_of_single_calls(eng, dev, calls: int):
+    """f1 / f2 on a composer filled by `calls` x (AllocatedScalar::allocate, range_check(0, 2^254)) issued one by one through the command
+    queue: a flushed run of identical calls leaves the batched append's footprint, so both calls take the closed forms"""
+    import ctypes as C
+    import torch
+    import plonk_gadgets_amd as pg
+    from plonk_gadgets_amd import _lib
+    S = pg.BlsScalar.from_int
+    comp = pg.StandardComposer(eng, 3 + calls * 1031 + 8, 5 + calls * 1034 + 8)
+    comp.queue(True)
+    mn, mx = S(0), S(2**254)
+    scalars = [S(1000 + i) for i in range(calls)]
+    t0 = time.perf_counter()
+    for sc in scalars:
+        pg.range_check(comp, mn, mx, pg.AllocatedScalar.allocate(comp, sc))
+    comp.sync()
+    append_s = time.perf_counter() - t0
+    n = comp.circuit_size()
+    padded = 1 << (n - 1).bit_length()
+    t = comp.materialize()  # (allocates its outputs; timed below into the same arrays)
+    fc = _lib.FullColumnsC(**{k: v.data_ptr() for k, v in t.items()})
+    sigma = torch.empty((4, padded), dtype=torch.int64, device=dev)
+    lib = comp._lib
+
+    def med(fn):
+        fn()
+        ms = []
+        for _ in range(5):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            assert fn() == 0
+            torch.cuda.synchronize(dev)
+            ms.append((time.perf_counter() - t1) * 1e3)
+        return sorted(ms)[2]
+    m_ms = med(lambda: lib.pg_composer_materialize(comp._h, C.byref(fc)))
+    p_ms = med(lambda: lib.pg_composer_permutation(comp._h, padded, sigma.data_ptr()))
+    return {"workload": "%d x (allocate, range_check(0, 2^254)) one call at a time, command queue on: %d rows, sigma padded to %d" % (calls, n, padded),
+            "append_us_per_pair_from_python": append_s / calls * 1e6,
+            "materialize": {"ms": m_ms, "rows_per_s": n / (m_ms / 1e3)}, "permutation": {"ms": p_ms, "rows_per_s": n / (p_ms / 1e3)}}
 
 
 def kernel_sources_sha256() -> str:
