@@ -229,6 +229,7 @@ pg::EmitOut make_out(const pg_columns *c, uint64_t batch, int W, uint64_t gate_b
     O.var_off = var_off;
     O.batch = batch;
     O.tiles = (uint32_t)((batch + W - 1) / W);
+    O.stride_rows = 0;
     O.inv_dense = nullptr;
     O.inv_elems = 0;
     O.inv_in_place = 1;
@@ -359,8 +360,10 @@ template <class GD> struct ValuesMode { static constexpr bool ok = !pg::Split<GD
 template <class GD>
 pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, uint64_t batch, uint64_t gate_base,
                  uint64_t var_base, uint64_t zero_var, const uint64_t *row_off, const uint64_t *var_off, void *stream,
-                 const pg::MixPlan *planned = nullptr, bool values_only = false) {
+                 const pg::MixPlan *planned = nullptr, bool values_only = false, uint32_t stride_rows = 0) {
     if ((batch + GD::W - 1) / GD::W > 0xffffffffull) return fail(PG_ERR_INVALID_ARGUMENT, "batch too large for one call");
+    if (stride_rows && (batch > 0xffffffffull || pg::Split<GD>::ok || GD::kRagged))
+        return fail(PG_ERR_INVALID_ARGUMENT, "a row stride is for uniform one-launch gadgets of at most 2^32 - 1 items");
     hipStream_t st = static_cast<hipStream_t>(stream);
     PG_TRY(enter_stream(e, st));
     StreamScope scope{e, st};
@@ -368,6 +371,10 @@ pg_status launch(pg_engine *e, const typename GD::Args &A, const pg_columns *c, 
         return launch_mix(e, A, c, batch, gate_base, var_base, zero_var, row_off, var_off, st, planned, values_only);
     } else {
         pg::EmitOut O = make_out(c, batch, GD::W, gate_base, var_base, zero_var, row_off, var_off);
+        if (stride_rows) {  // rows of other calls between the items: one item per tile (emit.hpp)
+            O.stride_rows = stride_rows;
+            O.tiles = (uint32_t)batch;
+        }
         bool side = false;  // the inversion pre-pass runs on the engine's side stream
         SideJoin join{e, st};
         if constexpr (GD::kInv > 0) {
@@ -657,7 +664,7 @@ pg_status pg_range_check_layout(const pg_scalar *min_range, const pg_scalar *max
 static pg_status range_check_common(pg_engine *e, const pg_scalar *min_range, const pg_scalar *max_range,
                                     const pg_variable *d_witness_var, const pg_scalar *d_witness, uint64_t batch,
                                     uint64_t gate_base, uint64_t var_base, const pg_columns *out,
-                                    pg_variable *d_result_vars, void *stream, bool values_only = false) {
+                                    pg_variable *d_result_vars, void *stream, bool values_only = false, uint32_t stride_rows = 0) {
     if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
     pg_layout lay;
     PG_TRY(pg_range_check_layout(min_range, max_range, batch, &lay));
@@ -674,7 +681,7 @@ static pg_status range_check_common(pg_engine *e, const pg_scalar *min_range, co
     A.witness_vars = d_witness_var;
     A.result_vars = d_result_vars;
     A.pow2 = e->d_pow2;
-    return launch<pg::RangeCheckGD>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream, nullptr, values_only);
+    return launch<pg::RangeCheckGD>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream, nullptr, values_only, stride_rows);
 }
 
 // a witness refresh's `out`: only var_values is written (EMIT_VALUES); the row pointers merely have to pass the checks
@@ -786,7 +793,8 @@ pg_status pg_max_bound_layout(const pg_scalar *max_range, uint64_t batch, pg_lay
 
 static pg_status max_bound_common(pg_engine *e, const pg_scalar *max_range, const pg_variable *d_witness_var,
                                   const pg_scalar *d_witness, uint64_t batch, uint64_t gate_base, uint64_t var_base,
-                                  const pg_columns *out, pg_variable *d_result_vars, void *stream, bool values_only = false) {
+                                  const pg_columns *out, pg_variable *d_result_vars, void *stream, bool values_only = false,
+                                  uint32_t stride_rows = 0) {
     if (!e) return fail(PG_ERR_INVALID_ARGUMENT, "engine is NULL");
     pg_layout lay;
     PG_TRY(pg_max_bound_layout(max_range, batch, &lay));
@@ -801,7 +809,7 @@ static pg_status max_bound_common(pg_engine *e, const pg_scalar *max_range, cons
     A.witness_vars = d_witness_var;
     A.result_vars = d_result_vars;
     A.pow2 = e->d_pow2;
-    return launch<pg::MaxBoundGD<false>>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream, nullptr, values_only);
+    return launch<pg::MaxBoundGD<false>>(e, A, out, batch, gate_base, var_base, 0, nullptr, nullptr, stream, nullptr, values_only, stride_rows);
 }
 
 pg_status pg_max_bound_values_batch(pg_engine *e, const pg_scalar *max_range, const pg_scalar *d_witness, uint64_t batch,

@@ -44,6 +44,10 @@ struct EmitOut {
     const uint64_t *var_off;
     uint64_t batch;
     uint32_t tiles;
+    // Rows from one item's first to the next one's; 0: the items' rows follow one another.  With a stride (the composer's queue: a loop
+    // of allocate + gadget + a gate or two per witness leaves ROWS of other calls between the items -- never Variables) a tile is ONE
+    // item, whatever the gadget's W: tiles == batch.
+    uint32_t stride_rows;
     // The inverses of the call (invert.hpp).  inv_in_place: the pre-pass runs BESIDE the emitter and writes every inverse at
     // its final slot, which the emitter skips -- a 32-byte hole in a 128-byte line, i.e. two partial line writes to HBM: at
     // 2^20 x range_check that alone is 0.6 ms of a witness refresh's 7.4.  Big calls (and tiny ones) run the pre-pass to
@@ -318,8 +322,8 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
 #else
         const uint32_t tile = t;
 #endif
-        const uint64_t w0 = (uint64_t)tile * W;
-        const uint32_t Wt = (uint32_t)((O.batch - w0) < (uint64_t)W ? (O.batch - w0) : (uint64_t)W);
+        const uint64_t w0 = O.stride_rows ? (uint64_t)tile : (uint64_t)tile * W;
+        const uint32_t Wt = O.stride_rows ? 1u : (uint32_t)((O.batch - w0) < (uint64_t)W ? (O.batch - w0) : (uint64_t)W);
         if constexpr (MODE == EMIT_ROWS && Periodic<GD>::ok) {  // a tile of full-shape items: rows_periodic_kernel's
             if (O.row_off[w0 + Wt] - O.row_off[w0] == (uint64_t)Wt * UniformShape<GD>::rows) continue;
         }
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(kThreads, PG_EMIT_WAVES_PER_SIMD) void emit_kernel(
         } else {
             G = GD::rows_per_item(A);
             V = GD::vars_per_item(A);
-            row0 = w0 * G;
+            row0 = w0 * (O.stride_rows ? O.stride_rows : G);
             var0 = w0 * V;
         }
 

@@ -68,6 +68,70 @@ def test_reference_loop_is_one_launch(engine):
         assert np.array_equal(exports[0][k], exports[1][k]), k
 
 
+@pytest.mark.parametrize("gadget,gates", [("range_check", 1), ("range_check", 2), ("max_bound", 1), ("max_bound", 3)])
+def test_reference_loop_with_gates_behind_every_gadget_call(engine, gadget, gates):
+    """The loop the reference's tests actually run (tests/range_gadgets_tests.rs:29-44): allocate, range_check, then
+    constrain_to_constant on the result -- a gate between any two gadget calls.  A flush sends the gadget calls of such a loop out as ONE
+    launch whose items lie `gates` rows apart (csrc/emit.hpp, EmitOut::stride_rows) and the gates as one run behind it: a handful of
+    launches for 200 iterations instead of one per call.  Columns == the oracle's loop == the same loop with recording off; check()
+    passes; a body of another shape in the middle (one more gate) and a different bound at the end only cut the loop in pieces; and a
+    prove-twice pass (clear_witness, the same loop on other witnesses) finds the rows in place."""
+    from oracle import pyoracle as po
+    import ctypes
+    n_iter = 200
+    vals = [50_000 + 997 * i for i in range(n_iter)]
+    vals2 = [60_000 + 991 * i for i in range(n_iter)]
+    mn, mx, mx2 = 50_000, 250_000, 2**40
+    nb = ctypes.c_uint64()
+
+    def loop(comp, is_oracle, values):
+        res = []
+        for k, v in enumerate(values):
+            bound = mx2 if k >= n_iter - 20 else mx  # (the last twenty iterations: another ladder length)
+            if is_oracle:
+                a = comp.allocate(synth.mont(v))
+                r = int(comp.L.range_check(comp.c, f(mn), f(bound), a)) if gadget == "range_check" else \
+                    int(comp.L.max_bound(comp.c, f(bound), a, ctypes.byref(nb)))
+                exp = int(mn <= v < bound) if gadget == "range_check" else int(v < bound)
+                for _ in range(gates + (1 if k == 77 else 0)):
+                    comp.L.composer_constrain_to_constant(comp.c, r, f(exp), None)
+            else:
+                a = pg.AllocatedScalar.allocate(comp, S(v))
+                r = pg.range_check(comp, S(mn), S(bound), a) if gadget == "range_check" else pg.max_bound(comp, S(bound), a)[0]
+                exp = int(mn <= v < bound) if gadget == "range_check" else int(v < bound)
+                for _ in range(gates + (1 if k == 77 else 0)):
+                    comp.constrain_to_constant(r, S(exp), None)
+            res.append(r)
+        return res
+
+    ora = po.Composer()
+    ores = loop(ora, True, vals)
+    exports = []
+    for queued in (True, False):
+        dev = pg.StandardComposer(engine, 1 << 17, 1 << 18)
+        dev.queue(queued)
+        _, f0, l0 = dev.queue_stats()
+        res = loop(dev, False, vals)
+        assert res == ores
+        if queued:
+            dev.flush()
+            pending, f1, l1 = dev.queue_stats()
+            assert pending == 0 and l1 - l0 <= 16, (pending, f1 - f0, l1 - l0)  # (one launch per call would be > 400)
+        same(dev, ora)
+        assert dev.check() == -1 and ora.check() == -1
+        exports.append(dev.export())
+        if queued:  # prove twice: the same loop on other witnesses finds every row in place
+            dev.clear_witness()
+            ora2 = po.Composer()
+            assert loop(dev, False, vals2) == loop(ora2, True, vals2)
+            same(dev, ora2)
+            assert dev.check() == -1
+            in_place, rewritten, _ = dev.refresh_stats()
+            assert rewritten == 0 and in_place >= dev.circuit_size() - 8, (in_place, rewritten, dev.circuit_size())
+    for k in COLS:
+        assert np.array_equal(exports[0][k], exports[1][k]), k
+
+
 def test_dependent_gate_calls(engine):
     """a run of gate calls whose outputs feed later calls of the same run (a chain of add / mul over earlier results,
     1500 calls: more than one launch of the queue kernel): values are computed in command order, level by level"""
