@@ -329,7 +329,11 @@ pg_status pg_composer_sync(pg_composer *c);
  * _columns / _copy_out / _read_value / _check / _dense_pi / _materialize / _permutation, any batched append, any other
  * gadget call, a capacity change, a full queue (8192 entries), or pg_composer_flush.  A run of gate calls is ONE launch
  * (the outputs of add / mul computed in command order, level by level); a run of `allocate + range_check` (or
- * max_bound) pairs with the same public bounds -- the reference's loop -- is ONE batched emit launch.
+ * max_bound) pairs with the same public bounds -- the reference's loop -- is ONE batched emit launch, and leaves the
+ * batched append's footprint for pg_composer_materialize / _permutation (runs of >= 4096 rows).  The loop as the
+ * reference's tests write it -- the pair, then up to eight gate calls that create no Variable (constrain_to_constant on
+ * the result, assert_equal, ...), per witness -- is ONE emit launch too (its items that many rows apart) plus one run of
+ * gates: a row's place is assigned when its call is recorded, and a rows-only gate reads no assignment.
  *   pg_composer_queue(c, 0) flushes and turns recording off (one launch per call, as before); on by default. */
 pg_status pg_composer_queue(pg_composer *c, int on);
 pg_status pg_composer_flush(pg_composer *c);
