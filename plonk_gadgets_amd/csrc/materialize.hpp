@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
                     for (; rr >= S.L; rr -= S.L) vb += S.V;
                 }
                 uint32_t off[3];
-                seg_wire_offsets(KIND, n, rr, off);
+                seg_wire_offsets(KIND, n, rr, off, S.tail);
                 const uint32_t o = k == 0 ? off[0] : k == 1 ? off[1] : off[2];
                 const uint64_t var = o == kWitnessWire ? C.w[k][G.r1 + lane / 3] : o == kZeroWire ? zero_var : G.w0 + G.nv + vb + o;
                 s_tail[buf][2 * lane] = C.vars[2 * var];
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
                         rr -= it * S.L;
                     }
                     uint32_t off[3];
-                    seg_wire_offsets(KIND, n, rr, off);
+                    seg_wire_offsets(KIND, n, rr, off, S.tail);
                     {
                         const bool along = r >= G.r1;
                         const uint32_t t = along ? (uint32_t)(r - G.r1) * 6 + half : 0;

@@ -50,6 +50,11 @@ struct PermSeg {
     // perm_ladder_kernel: the segment's slots on the sparse list -- ladder_foreign_per_item(wire_kind) per item, in closed form (set by
     // pg_composer_permutation for the pass it launches)
     uint64_t sparse_base;
+    // Rows behind every item's own that hold its RESULT Variable on all three wires (constrain_to_constant / boolean_gate on the result:
+    // the loop of the reference's tests, recorded call by call and flushed as one launch -- capi_composer.inc, flush): they count as
+    // the item's rows (L includes them), their wires and their place in the result's cycle are closed forms like the others.  Kinds that
+    // allocate their witness only.
+    uint32_t tail;
 };
 enum : uint32_t { WIRES_UNKNOWN = 0, WIRES_RANGE_CHECK = 1, WIRES_MAX_BOUND = 2, WIRES_RANGE_CHECK_ALLOCATED = 3, WIRES_MAX_BOUND_ALLOCATED = 4,
                   WIRES_DECOMPOSITION = 5,
@@ -57,8 +62,15 @@ enum : uint32_t { WIRES_UNKNOWN = 0, WIRES_RANGE_CHECK = 1, WIRES_MAX_BOUND = 2,
 constexpr uint32_t kZeroWire = 0xfffffffeu;  // "zero_var" (the composer's Variable with value 0: is_non_zero's first row has it)
 // offsets (from the item's first own Variable) of the three wires of item-row j; kWitnessWire: the witness, which is the item's
 // first Variable for the kinds that allocate it and a Variable from elsewhere (read it from the wire column) for the others
-__device__ __forceinline__ void seg_wire_offsets(uint32_t kind, uint32_t n, uint32_t j, uint32_t off[3]) {
+__device__ __forceinline__ void seg_wire_offsets(uint32_t kind, uint32_t n, uint32_t j, uint32_t off[3], uint32_t tail = 0) {
     const uint32_t x0 = kind == WIRES_RANGE_CHECK || kind == WIRES_MAX_BOUND ? 1u : 0u;
+    if (tail && x0) {  // (PermSeg::tail) the rows behind the gadget's own: its result -- the item's last Variable -- three times
+        const uint32_t own = kind == WIRES_RANGE_CHECK ? 4 * n + 11 : 2 * n + 5, res = kind == WIRES_RANGE_CHECK ? 2 * n + 523 : n + 261;
+        if (j >= own) {
+            off[0] = off[1] = off[2] = res;
+            return;
+        }
+    }
     if (kind == WIRES_MIX) {
         // ScalarMixGD::row of an item whose v is not 0, as a table: Variables [v y s a b | va inv one | one' sy oms out | u z yeq] = 0 .. 14,
         // 15 = zero_var; four bits per wire, rows 0 .. 4 in the first word and 5 .. 9 in the second (a RowOut here cost the caller a
@@ -399,11 +411,20 @@ __device__ __forceinline__ uint32_t ladder_block_row(uint32_t jj, uint32_t n, ui
 }
 // successors of the three positions of item-row j of an item of kind `kind`, in item rows; returned mask: bit w = the position holds a
 // Variable created elsewhere (the sparse list links it, or the zero chain if it is zero_var)
-__device__ __forceinline__ uint32_t ladder_row(uint32_t kind, uint32_t n, uint32_t j, uint32_t j2[3], uint32_t w2[3]) {
+__device__ __forceinline__ uint32_t ladder_row(uint32_t kind, uint32_t n, uint32_t j, uint32_t j2[3], uint32_t w2[3], uint32_t tail = 0) {
     const uint32_t L = 2 * n + 5;
+    // PermSeg::tail rows (result, result, result) behind the item's own: the result's line runs on through them in recording order
+    // and closes from the last one back to where the result was made -- (2L, o) of range_check, (2n + 3, o) of max_bound
+    const uint32_t own = kind == WIRES_RANGE_CHECK ? 2 * L + 1 : L;
+    if (tail && j >= own) {
+        j2[0] = j; w2[0] = 1; j2[1] = j; w2[1] = 2;
+        if (j + 1 < own + tail) { j2[2] = j + 1; w2[2] = 0; }
+        else { j2[2] = kind == WIRES_RANGE_CHECK ? 2 * L : 2 * n + 3; w2[2] = 2; }
+        return 0;
+    }
     if (kind == WIRES_RANGE_CHECK || kind == WIRES_RANGE_CHECK_ALLOCATED) {
-        if (j == 2 * L) {  // (y1, y2, R): the end of either block's y line; R alone
-            j2[0] = 2 * n + 3; w2[0] = 2; j2[1] = L + 2 * n + 3; w2[1] = 2; j2[2] = j; w2[2] = 2;
+        if (j == 2 * L) {  // (y1, y2, R): the end of either block's y line; R alone (or on to the first of the tail rows)
+            j2[0] = 2 * n + 3; w2[0] = 2; j2[1] = L + 2 * n + 3; w2[1] = 2; j2[2] = tail ? j + 1 : j; w2[2] = tail ? 0 : 2;
             return 0;
         }
         const uint32_t blk = j >= L ? 1u : 0u, base = blk * L, jj = j - base;
@@ -430,7 +451,7 @@ __device__ __forceinline__ uint32_t ladder_row(uint32_t kind, uint32_t n, uint32
         if (kind == WIRES_MAX_BOUND_ALLOCATED) return 3;
         j2[0] = 0; w2[0] = 1; j2[1] = 0; w2[1] = 0;
     } else if (open == 2) { j2[1] = 0; w2[1] = 2; }
-    else if (open == 1) { j2[0] = 2 * n + 3; w2[0] = 2; }
+    else if (open == 1) { j2[0] = tail ? L : 2 * n + 3; w2[0] = tail ? 0 : 2; }  // y's line closes, or goes on to the first tail row
     return 0;
 }
 
@@ -508,7 +529,7 @@ __global__ __launch_bounds__(kThreads) void perm_ladder_kernel(const PermCtx X, 
                 for (uint32_t w = 0; w < 4; w++) out[w][h] = 0;
                 if (!live[h]) continue;
                 uint32_t j2[3], w2[3];
-                const uint32_t fw = ladder_row(kind, n, j, j2, w2), zw = fw ? zero_wires(g, j) : 0u;
+                const uint32_t fw = ladder_row(kind, n, j, j2, w2, S.tail), zw = fw ? zero_wires(g, j) : 0u;
                 foreign[h] = fw & ~zw;
                 fslots[h] = fw;
                 fitem[h] = item0 + q;

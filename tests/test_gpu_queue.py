@@ -120,6 +120,18 @@ def test_reference_loop_with_gates_behind_every_gadget_call(engine, gadget, gate
         same(dev, ora)
         assert dev.check() == -1 and ora.check() == -1
         exports.append(dev.export())
+        # the next rows: the loop's bodies are items of (gadget rows + gates rows) with closed-form wires and cycles (PermSeg::tail) where
+        # the runs are long enough, rows of single calls elsewhere -- sigma == the oracle's bookkeeping, wire values == variables[w]
+        n = dev.circuit_size()
+        padded = 1 << (n - 1).bit_length()
+        got, exp = dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded)
+        if not np.array_equal(got, exp):
+            w, g = np.argwhere(got != exp)[0]
+            raise AssertionError(f"sigma differs first at wire {w}, gate {g}: {got[w, g]} != {exp[w, g]}")
+        cols, m = dev.device_columns(), dev.materialize()
+        for wname in ("w_l", "w_r", "w_o"):
+            wv = getattr(cols, wname)[:n]
+            assert torch.equal(m[wname + "_value"], cols.var_values[wv]), wname
         if queued:  # prove twice: the same loop on other witnesses finds every row in place
             dev.clear_witness()
             ora2 = po.Composer()
