@@ -333,7 +333,8 @@ pg_status pg_composer_sync(pg_composer *c);
  * batched append's footprint for pg_composer_materialize / _permutation (runs of >= 4096 rows).  The loop as the
  * reference's tests write it -- the pair, then up to eight gate calls that create no Variable (constrain_to_constant on
  * the result, assert_equal, ...), per witness -- is ONE emit launch too (its items that many rows apart) plus one run of
- * gates: a row's place is assigned when its call is recorded, and a rows-only gate reads no assignment.
+ * gates: a row's place is assigned when its call is recorded, and a rows-only gate reads no assignment.  Where those
+ * gates constrain the gadget's own result (its Variable on all three wires) the loop leaves a footprint as well.
  *   pg_composer_queue(c, 0) flushes and turns recording off (one launch per call, as before); on by default. */
 pg_status pg_composer_queue(pg_composer *c, int on);
 pg_status pg_composer_flush(pg_composer *c);
