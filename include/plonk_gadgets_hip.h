@@ -324,10 +324,11 @@ pg_status pg_composer_sync(pg_composer *c);
 /* The command queue.  The reference's usage is ONE composer call at a time (tests/range_gadgets_tests.rs:29-44:
  * allocate, range_check, constrain_to_constant, ...); a launch per call would make that loop launch-bound.  Variables
  * are numbered on the host and their assignments live on the device, so the single calls -- the gate calls below,
- * pg_allocated_scalar_allocate, pg_range_check, pg_max_bound -- are RECORDED (arguments checked, numbering advanced,
+ * pg_allocated_scalar_allocate, pg_range_check, pg_max_bound, and the four scalar gadgets (which are sequences of those
+ * gate calls, src/scalar.rs, and are composed of them here) -- are RECORDED (arguments checked, numbering advanced,
  * results returned at once) and reach the composer's stream, in order, when anything needs them: pg_composer_sync /
- * _columns / _copy_out / _read_value / _check / _dense_pi / _materialize / _permutation, any batched append, any other
- * gadget call, a capacity change, a full queue (8192 entries), or pg_composer_flush.  A run of gate calls is ONE launch
+ * _columns / _copy_out / _read_value / _check / _dense_pi / _materialize / _permutation, any batched append,
+ * pg_scalar_decomposition_gadget, a capacity change, a full queue (8192 entries), or pg_composer_flush.  A run of gate calls is ONE launch
  * (the outputs of add / mul computed in command order, level by level); a run of `allocate + range_check` (or
  * max_bound) pairs with the same public bounds -- the reference's loop -- is ONE batched emit launch, and leaves the
  * batched append's footprint for pg_composer_materialize / _permutation (runs of >= 4096 rows).  The loop as the
