@@ -64,8 +64,10 @@ constexpr uint32_t kZeroWire = 0xfffffffeu;  // "zero_var" (the composer's Varia
 // first Variable for the kinds that allocate it and a Variable from elsewhere (read it from the wire column) for the others
 __device__ __forceinline__ void seg_wire_offsets(uint32_t kind, uint32_t n, uint32_t j, uint32_t off[3], uint32_t tail = 0) {
     const uint32_t x0 = kind == WIRES_RANGE_CHECK || kind == WIRES_MAX_BOUND ? 1u : 0u;
-    if (tail && x0) {  // (PermSeg::tail) the rows behind the gadget's own: its result -- the item's last Variable -- three times
-        const uint32_t own = kind == WIRES_RANGE_CHECK ? 4 * n + 11 : 2 * n + 5, res = kind == WIRES_RANGE_CHECK ? 2 * n + 523 : n + 261;
+    if (tail && kind >= WIRES_RANGE_CHECK && kind <= WIRES_MAX_BOUND_ALLOCATED) {
+        // (PermSeg::tail) the rows behind the gadget's own: its result -- the item's last Variable -- three times
+        const bool rc = kind == WIRES_RANGE_CHECK || kind == WIRES_RANGE_CHECK_ALLOCATED;
+        const uint32_t own = rc ? 4 * n + 11 : 2 * n + 5, res = x0 + (rc ? 2 * n + 522 : n + 260);
         if (j >= own) {
             off[0] = off[1] = off[2] = res;
             return;
@@ -415,11 +417,12 @@ __device__ __forceinline__ uint32_t ladder_row(uint32_t kind, uint32_t n, uint32
     const uint32_t L = 2 * n + 5;
     // PermSeg::tail rows (result, result, result) behind the item's own: the result's line runs on through them in recording order
     // and closes from the last one back to where the result was made -- (2L, o) of range_check, (2n + 3, o) of max_bound
-    const uint32_t own = kind == WIRES_RANGE_CHECK ? 2 * L + 1 : L;
+    const bool rc = kind == WIRES_RANGE_CHECK || kind == WIRES_RANGE_CHECK_ALLOCATED;
+    const uint32_t own = rc ? 2 * L + 1 : L;
     if (tail && j >= own) {
         j2[0] = j; w2[0] = 1; j2[1] = j; w2[1] = 2;
         if (j + 1 < own + tail) { j2[2] = j + 1; w2[2] = 0; }
-        else { j2[2] = kind == WIRES_RANGE_CHECK ? 2 * L : 2 * n + 3; w2[2] = 2; }
+        else { j2[2] = rc ? 2 * L : 2 * n + 3; w2[2] = 2; }
         return 0;
     }
     if (kind == WIRES_RANGE_CHECK || kind == WIRES_RANGE_CHECK_ALLOCATED) {

@@ -68,14 +68,16 @@ def test_reference_loop_is_one_launch(engine):
         assert np.array_equal(exports[0][k], exports[1][k]), k
 
 
+@pytest.mark.parametrize("prealloc", [False, True])
 @pytest.mark.parametrize("gadget,gates", [("range_check", 1), ("range_check", 2), ("max_bound", 1), ("max_bound", 3)])
-def test_reference_loop_with_gates_behind_every_gadget_call(engine, gadget, gates):
+def test_reference_loop_with_gates_behind_every_gadget_call(engine, gadget, gates, prealloc):
     """The loop the reference's tests actually run (tests/range_gadgets_tests.rs:29-44): allocate, range_check, then
     constrain_to_constant on the result -- a gate between any two gadget calls.  A flush sends the gadget calls of such a loop out as ONE
     launch whose items lie `gates` rows apart (csrc/emit.hpp, EmitOut::stride_rows) and the gates as one run behind it: a handful of
     launches for 200 iterations instead of one per call.  Columns == the oracle's loop == the same loop with recording off; check()
     passes; a body of another shape in the middle (one more gate) and a different bound at the end only cut the loop in pieces; and a
-    prove-twice pass (clear_witness, the same loop on other witnesses) finds the rows in place."""
+    prove-twice pass (clear_witness, the same loop on other witnesses) finds the rows in place.  prealloc: every witness allocated
+    before the loop (the gadget calls then run on Variables from elsewhere: the `_allocated` footprints)."""
     from oracle import pyoracle as po
     import ctypes
     n_iter = 200
@@ -86,17 +88,20 @@ def test_reference_loop_with_gates_behind_every_gadget_call(engine, gadget, gate
 
     def loop(comp, is_oracle, values):
         res = []
+        pre = None
+        if prealloc:
+            pre = [comp.allocate(synth.mont(v)) if is_oracle else pg.AllocatedScalar.allocate(comp, S(v)) for v in values]
         for k, v in enumerate(values):
             bound = mx2 if k >= n_iter - 20 else mx  # (the last twenty iterations: another ladder length)
             if is_oracle:
-                a = comp.allocate(synth.mont(v))
+                a = pre[k] if prealloc else comp.allocate(synth.mont(v))
                 r = int(comp.L.range_check(comp.c, f(mn), f(bound), a)) if gadget == "range_check" else \
                     int(comp.L.max_bound(comp.c, f(bound), a, ctypes.byref(nb)))
                 exp = int(mn <= v < bound) if gadget == "range_check" else int(v < bound)
                 for _ in range(gates + (1 if k == 77 else 0)):
                     comp.L.composer_constrain_to_constant(comp.c, r, f(exp), None)
             else:
-                a = pg.AllocatedScalar.allocate(comp, S(v))
+                a = pre[k] if prealloc else pg.AllocatedScalar.allocate(comp, S(v))
                 r = pg.range_check(comp, S(mn), S(bound), a) if gadget == "range_check" else pg.max_bound(comp, S(bound), a)[0]
                 exp = int(mn <= v < bound) if gadget == "range_check" else int(v < bound)
                 for _ in range(gates + (1 if k == 77 else 0)):
