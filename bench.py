@@ -461,7 +461,8 @@ def bare_fill(wl: Workload, reps: int = 5):
     """"a bare fill-kernel ceiling measured on the same box" -- in this process, on the very arrays the workload has
     just written.  `columns`: pg_fill_columns, the emitters' store stream with nothing behind it (five selector columns in lock
     step, the wires, the variable table; tiles of 32768 rows) = the workload's store ceiling ON THESE ARRAYS; `one_window` /
-    `one_stream`: pg_fill_bytes over the variable table alone (short-lived workgroups = one moving window; long-lived ones);
+    `one_stream`: pg_fill_bytes over the variable table alone (short-lived workgroups of 8 KiB, two per CU = one moving window of a few
+    MiB, the shape that does not care where the table lies; long-lived ones);
     `torch_fill`: torch's fill_ over every array in turn.  GB/s, medians of `reps` launches (HIP events on the launch stream)."""
     import ctypes as C
     import torch

@@ -1104,16 +1104,20 @@ pg_status pg_fill_bytes(pg_engine *e, void *d_dst, uint64_t bytes, uint32_t stre
     if (!d_dst || !aligned(d_dst, 16) || (bytes & 15)) return fail(PG_ERR_INVALID_ARGUMENT, "dst/bytes not 16-byte aligned");
     if (bytes == 0) return PG_OK;
     PG_HIP_TRY(hipSetDevice(e->device));
-    if (streams == 0) {  // short-lived workgroups, 16 KiB each
-        const uint64_t blocks = (bytes / 16 + 4 * pg::kThreads - 1) / (4 * pg::kThreads);
+    if (streams == 0) {  // short-lived workgroups, 8 KiB each, two resident per CU
+        const uint64_t blocks = (bytes / 16 + pg::kFillOneshotUnits - 1) / pg::kFillOneshotUnits;
         if (blocks > 0x7fffffffull) return fail(PG_ERR_INVALID_ARGUMENT, "buffer too large for one launch");
-        hipLaunchKernelGGL(pg::fill_oneshot_kernel, dim3((uint32_t)blocks), dim3(pg::kThreads), 0, static_cast<hipStream_t>(stream),
+        PG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pg::fill_oneshot_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)pg::kFillOneshotLds));
+        hipLaunchKernelGGL(pg::fill_oneshot_kernel, dim3((uint32_t)blocks), dim3(pg::kThreads), pg::kFillOneshotLds, static_cast<hipStream_t>(stream),
                            static_cast<uint4 *>(d_dst), bytes / 16, pattern);
         PG_HIP_TRY(hipGetLastError());
         return PG_OK;
     }
     if (streams < 1 || streams > 16) return fail(PG_ERR_INVALID_ARGUMENT, "streams must be in [0, 16]");
-    const uint64_t pieces = (bytes / 16 / streams + 65535) / 65536, cap = (uint64_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
+    uint64_t pieces = (bytes / 16 / streams + 65535) / 65536;
+    const uint64_t cap = (uint64_t)e->num_cus * PG_GRID_BLOCKS_PER_CU;
+    if (pieces < 1) pieces = 1;  // (fewer units than streams: the remainder loop of workgroup 0 writes them)
     hipLaunchKernelGGL(pg::fill_kernel, dim3((uint32_t)(pieces < cap ? pieces : cap)), dim3(pg::kThreads), 0,
                        static_cast<hipStream_t>(stream), static_cast<uint4 *>(d_dst), bytes / 16, streams, pattern);
     PG_HIP_TRY(hipGetLastError());

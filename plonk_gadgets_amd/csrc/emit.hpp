@@ -784,14 +784,21 @@ __global__ __launch_bounds__(kThreads) void fill_kernel(uint4 *dst, uint64_t n16
         for (uint64_t i = part * streams + threadIdx.x; i < n16; i += kThreads) store16(dst + i, v);
 }
 
-// the same fill as short-lived workgroups: one 16 KiB block per workgroup (four 16-byte stores per lane), no loop --
-// at any moment the resident workgroups cover one moving window of a few tens of MiB
+// the same fill as short-lived workgroups: one 8 KiB block per workgroup (two 16-byte stores per lane), no loop, started in address
+// order by the dispatcher, and only TWO resident per CU (kFillOneshotLds bytes of dynamic LDS each, unused): at any moment the chip writes
+// one moving window of a few MiB.  This is the shape that does not care where its array lies: 7.14-7.21 TB/s on every one of six 34.7-GB
+// tables where long-lived workgroups reach 5.6-7.1 by table (tools/probes/single_table_fill.hip; four stores per lane at full residency,
+// this kernel until the end of round 5: 5.9-6.5).
+constexpr uint32_t kFillOneshotLds = 160 * 1024 / 2 - 1024;
+constexpr uint32_t kFillOneshotUnits = 2 * kThreads;  // 16-byte units per workgroup
 __global__ __launch_bounds__(kThreads) void fill_oneshot_kernel(uint4 *dst, uint64_t n16, uint64_t pattern) {
+    extern __shared__ uint4 fill_oneshot_pad[];
     const uint4 v = make_uint4((uint32_t)pattern, (uint32_t)(pattern >> 32), (uint32_t)~pattern, (uint32_t)(~pattern >> 32));
-    const uint64_t base = (uint64_t)blockIdx.x * (4 * kThreads) + threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * kFillOneshotUnits + threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+    for (uint32_t k = 0; k < kFillOneshotUnits / kThreads; k++)
         if (base + k * kThreads < n16) store16(dst + base + k * kThreads, v);
+    if (n16 == ~0ull) fill_oneshot_pad[threadIdx.x] = v;  // (keeps the allocation)
 }
 
 // the emitters' store stream with nothing behind it: a workgroup owns a tile of consecutive rows (and the matching share of

@@ -784,3 +784,19 @@ def test_fused_mix_into_misaligned_wire_columns(engine, batch, zeros, shifted):
         lo = 1 if k in shifted else 2
         t = getattr(big, k)
         assert bool((t[:lo] == -1).all()) and bool((t[lo + G:] == -1).all()), k
+
+
+@pytest.mark.parametrize("streams", [0, 1, 5, 16])
+@pytest.mark.parametrize("units", [1, 511, 512, 513, 100_003])
+def test_fill_bytes_writes_its_buffer_and_nothing_else(engine, streams, units):
+    """pg_fill_bytes (the bare store streams bench.py times beside every workload): every 16-byte unit of the buffer gets the pattern
+    (low half, then its complement), the units behind it keep theirs -- for sizes around the one-shot form's 8 KiB block (512 units) and
+    one that is no multiple of anything"""
+    buf = torch.full((2 * (units + 8),), 0x5A5A5A5A5A5A5A5A, dtype=torch.int64, device="cuda:0")
+    pat = 0x0123456789ABCDEF
+    engine.fill_bytes(buf[: 2 * units], streams, pat)
+    torch.cuda.synchronize()
+    got = buf.cpu().numpy().view(np.uint64)
+    assert (got[2 * units:] == 0x5A5A5A5A5A5A5A5A).all()
+    body = got[: 2 * units].reshape(units, 2)
+    assert (body[:, 0] == pat).all() and (body[:, 1] == (~pat & 0xFFFFFFFFFFFFFFFF)).all()
