@@ -1057,6 +1057,39 @@ def test_materialize_short_items_and_a_short_last_group(engine, kind, extra, lea
     assert torch.equal(t["w_4_value"][:n], cols.var_values[t["w_4"][:n]])
 
 
+def test_sigma_when_the_sparse_list_is_reserved_too_small(engine):
+    """pg_composer_permutation_reserve with a figure far below what the circuit puts on the sparse list: the ladder segments' closed-form
+    slots alone (four per item of range_check on witnesses from elsewhere, csrc/permutation.hpp) exceed it, nothing may be written past
+    the list's end, the pass reports what it needs and runs once more -- sigma is the same as with room from the start, and as the
+    oracle's."""
+    import ctypes as C
+    from oracle import pyoracle as po
+    F = lambda x: po.fr(synth.mont(x))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:0")
+    n_items = 60
+    vals = [int(v) for v in synth.splitmix64(n_items, 5) % np.uint64(300_000)]
+    wit = synth.scalars_from_ints(vals)
+    sigmas = []
+    for reserve in (None, 8):
+        dev, ora = pg.StandardComposer(engine, 1 << 14, 1 << 17), po.Composer()
+        first = dev.add_input_batch(t(wit))
+        allocs = [ora.allocate(w) for w in wit]
+        wv = torch.arange(first, first + n_items, dtype=torch.int64, device="cuda:0")
+        r = dev.range_check_allocated_batch(S(50_000), S(250_000), wv, t(wit))
+        res = [int(ora.L.range_check(ora.c, F(50_000), F(250_000), a)) for a in allocs]
+        assert list(r.cpu().numpy().view(np.uint64)) == res
+        dev.assert_equal(res[0], res[1])  # (rows of a single call behind the batch: the counter continues behind the reserved slots)
+        ora.L.composer_assert_equal(ora.c, res[0], res[1])
+        n = dev.circuit_size()
+        padded = 1 << (n - 1).bit_length()
+        if reserve is not None:
+            dev.permutation_reserve(reserve)
+        got = dev.permutation(padded).cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, ora.sigma(padded))
+        sigmas.append(got)
+    assert np.array_equal(sigmas[0], sigmas[1])
+
+
 def test_f_rows_of_runs_of_single_calls(engine):
     """A circuit built the reference's way -- ONE allocate + range_check at a time (tests/range_gadgets_tests.rs:29-44), the command
     queue on -- leaves runs of identical calls, which a flush sends out as one batched launch and (csrc/capi_composer.inc,
