@@ -149,6 +149,41 @@ def test_reference_loop_with_gates_behind_every_gadget_call(engine, gadget, gate
         assert np.array_equal(exports[0][k], exports[1][k]), k
 
 
+def test_reference_loop_across_a_full_queue(engine):
+    """3000 iterations of allocate, range_check, constrain_to_constant = 9000 recorded calls: the queue (8192 entries) flushes itself in
+    the middle of a loop body, so one flush ends on a pair without its gate and the next begins with that gate.  Same columns, sigma and
+    wire values as the oracle's loop."""
+    from oracle import pyoracle as po
+    n_iter = 3000
+    vals = [50_000 + 67 * i for i in range(n_iter)]
+    mn, mx = 50_000, 250_000
+    ora = po.Composer()
+    dev = pg.StandardComposer(engine, 1 << 19, 1 << 21)
+    dev.queue(True)
+    _, f0, l0 = dev.queue_stats()
+    for v in vals:
+        r = pg.range_check(dev, S(mn), S(mx), pg.AllocatedScalar.allocate(dev, S(v)))
+        dev.constrain_to_constant(r, S(int(mn <= v < mx)), None)
+        ro = int(ora.L.range_check(ora.c, f(mn), f(mx), ora.allocate(synth.mont(v))))
+        ora.L.composer_constrain_to_constant(ora.c, ro, f(int(mn <= v < mx)), None)
+        assert r == ro
+    dev.flush()
+    pending, f1, l1 = dev.queue_stats()
+    assert pending == 0 and f1 - f0 >= 2 and l1 - l0 <= 24, (pending, f1 - f0, l1 - l0)
+    same(dev, ora)
+    assert dev.check() == -1
+    n = dev.circuit_size()
+    padded = 1 << (n - 1).bit_length()
+    got, exp = dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded)
+    if not np.array_equal(got, exp):
+        w, g = np.argwhere(got != exp)[0]
+        raise AssertionError(f"sigma differs first at wire {w}, gate {g}: {got[w, g]} != {exp[w, g]}")
+    cols, m = dev.device_columns(), dev.materialize()
+    for wname in ("w_l", "w_r", "w_o"):
+        wv = getattr(cols, wname)[:n]
+        assert torch.equal(m[wname + "_value"], cols.var_values[wv]), wname
+
+
 def test_dependent_gate_calls(engine):
     """a run of gate calls whose outputs feed later calls of the same run (a chain of add / mul over earlier results,
     1500 calls: more than one launch of the queue kernel): values are computed in command order, level by level"""
