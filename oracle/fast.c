@@ -27,6 +27,7 @@ typedef struct {
     fr_t qc_max, qc_min, neg_one, pow2[256];
     uint64_t n, gate_base, var_base;
     const fr_t *witness;
+    const uint64_t *witness_vars; /* NULL: the loop allocates its witness (allocated_scalar.rs:27); else the Variable it was given */
     oracle_columns_t out;
     uint64_t *result_vars;
     size_t lo, hi;
@@ -40,7 +41,9 @@ typedef struct {
 static void put_row(const job_t *J, uint64_t r, uint64_t a, uint64_t b, uint64_t c, fr_t qm, fr_t ql, fr_t qr, fr_t qo,
                     fr_t qc) {
     r -= J->row_rel;
-    J->out.q_m[r] = qm; J->out.q_l[r] = ql; J->out.q_r[r] = qr; J->out.q_o[r] = qo; J->out.q_c[r] = qc;
+    if (J->out.q_m) {   /* (NULL: the caller wants the wires and the assignments only -- tests/frows_oracle.py) */
+        J->out.q_m[r] = qm; J->out.q_l[r] = ql; J->out.q_r[r] = qr; J->out.q_o[r] = qo; J->out.q_c[r] = qc;
+    }
     J->out.w_l[r] = a; J->out.w_r[r] = b; J->out.w_o[r] = c;
 }
 
@@ -85,12 +88,16 @@ static uint64_t bound_block(const job_t *J, uint64_t n, uint64_t *row, uint64_t 
 
 static void *worker(void *p) {
     const job_t *J = (const job_t *)p;
-    const uint64_t n = J->n, G = 4 * n + 11, V = 2 * n + 524;
+    const uint64_t n = J->n, G = 4 * n + 11, V = 2 * n + 523 + (J->witness_vars ? 0 : 1);
     for (size_t i = J->lo; i < J->hi; i++) {
         uint64_t row = i * G, var = J->var_base + i * V;
         const fr_t xval = J->witness[i];
-        const uint64_t x = var++;
-        J->out.var_values[x - J->var_base] = xval;
+        uint64_t x;
+        if (J->witness_vars) x = J->witness_vars[i];   /* range_check(composer, min, max, witness) as the reference has it: range.rs:27-32 */
+        else {
+            x = var++;
+            J->out.var_values[x - J->var_base] = xval;
+        }
         int y1, y2;
         const uint64_t yv1 = bound_block(J, n, &row, &var, x, fr_sub(J->qc_max, xval), J->neg_one, J->qc_max, &y1);
         const uint64_t yv2 = bound_block(J, n, &row, &var, x, fr_add(xval, J->qc_min), FR_ONE, J->qc_min, &y2);
@@ -102,10 +109,11 @@ static void *worker(void *p) {
     return NULL;
 }
 
-int oracle_range_check_fast(fr_t min_range, fr_t max_range, const fr_t *witness, size_t batch, uint64_t var_base,
-                            int threads, oracle_columns_t *out, uint64_t *result_vars) {
+static int range_check_fast(fr_t min_range, fr_t max_range, const fr_t *witness, const uint64_t *witness_vars, size_t batch,
+                            uint64_t var_base, int threads, oracle_columns_t *out, uint64_t *result_vars) {
     job_t base;
     memset(&base, 0, sizeof base);
+    base.witness_vars = witness_vars;
     base.qc_max = fr_sub(max_range, FR_ONE);
     base.qc_min = fr_neg(min_range);
     base.neg_one = fr_neg(FR_ONE);
@@ -130,6 +138,20 @@ int oracle_range_check_fast(fr_t min_range, fr_t max_range, const fr_t *witness,
     free(th);
     free(jobs);
     return 0;
+}
+
+int oracle_range_check_fast(fr_t min_range, fr_t max_range, const fr_t *witness, size_t batch, uint64_t var_base,
+                            int threads, oracle_columns_t *out, uint64_t *result_vars) {
+    return range_check_fast(min_range, max_range, witness, NULL, batch, var_base, threads, out, result_vars);
+}
+
+/* for i: range_check(min, max, AllocatedScalar { var: witness_vars[i], scalar: witness[i] }) on witnesses allocated before the
+ * loop -- the reference's own signature (range.rs:27-32): 4n + 11 rows and 2n + 523 Variables per item, none for the witness */
+int oracle_range_check_allocated_fast(fr_t min_range, fr_t max_range, const fr_t *witness, const uint64_t *witness_vars,
+                                      size_t batch, uint64_t var_base, int threads, oracle_columns_t *out,
+                                      uint64_t *result_vars) {
+    if (!witness_vars) return -1;
+    return range_check_fast(min_range, max_range, witness, witness_vars, batch, var_base, threads, out, result_vars);
 }
 
 /* ---- shared driver: split [lo, hi) over threads ------------------------------------------------------------- */
@@ -339,4 +361,309 @@ int oracle_scalar_mix_fast(const fr_t *v, const fr_t *y, const fr_t *s, const fr
     base.result_vars = result_vars;
     run_threads(&base, lo, hi, threads, mix_worker);
     return 0;
+}
+
+/* ==== the f-rows of a WHOLE circuit, from its wire columns ================================================
+ *
+ * oracle/composer.c keeps, like dusk-plonk 0.8's Permutation, a Variable -> [WireData] map that every row updates, and
+ * composer_sigma() walks it; composer_values_dense() + the wire columns give the wire-VALUE columns the prover takes.
+ * Both are a function of the four wire columns (and the assignments) alone:
+ *   sigma[p]   = the next position, in recording order (gate by gate; left, right, output, fourth within a gate), that holds
+ *                the Variable of position p -- the Variable's first position when p is its last;
+ *   w_X_value  = values[w_X[row]];   q_arith = 1, q_range = q_logic = q_fixed = q_variable = 0 on every row push_arith_row
+ *                makes (all rows of this path), q_4 = 0 except where the caller lists it (the dummy rows of composer_new()).
+ * The forms below compute exactly that for row ranges of a circuit of hundreds of millions of rows, threaded, so that
+ * tests/test_gpu_frows_exhaustive.py can compare EVERY word of pg_composer_permutation / pg_composer_materialize at the sizes
+ * bench.py times them.  The wire columns they start from are assembled from the fast gadget forms above (tests/frows_oracle.py).
+ * Pinned by tests/test_oracle_fast.py: == composer_sigma / composer_selector / composer_wire / composer_values_dense of
+ * faithful composer.c programs (every gadget, foreign Variables, random gate programs), for any chunking and thread count.
+ */
+
+#include <stdio.h>
+
+typedef struct { uint64_t *k, *v; size_t cap, len; } u64map_t; /* open addressing; key stored + 1 (0 = empty) */
+
+static void map_init(u64map_t *m, size_t cap) {
+    m->cap = cap; m->len = 0;
+    m->k = (uint64_t *)calloc(cap, sizeof(uint64_t));
+    m->v = (uint64_t *)malloc(cap * sizeof(uint64_t));
+}
+static void map_free(u64map_t *m) { free(m->k); free(m->v); m->k = m->v = NULL; m->cap = m->len = 0; }
+static inline size_t map_hash(uint64_t key) { uint64_t x = key * 0x9e3779b97f4a7c15ull; return (size_t)(x ^ (x >> 31)); }
+static uint64_t *map_get(const u64map_t *m, uint64_t key) {
+    size_t i = map_hash(key) & (m->cap - 1);
+    while (m->k[i]) {
+        if (m->k[i] == key + 1) return &m->v[i];
+        i = (i + 1) & (m->cap - 1);
+    }
+    return NULL;
+}
+static void map_put(u64map_t *m, uint64_t key, uint64_t val);
+static void map_grow(u64map_t *m) {
+    u64map_t n;
+    map_init(&n, m->cap * 2);
+    for (size_t i = 0; i < m->cap; i++)
+        if (m->k[i]) map_put(&n, m->k[i] - 1, m->v[i]);
+    map_free(m);
+    *m = n;
+}
+static void map_put(u64map_t *m, uint64_t key, uint64_t val) {
+    if ((m->len + 1) * 2 > m->cap) map_grow(m);
+    size_t i = map_hash(key) & (m->cap - 1);
+    while (m->k[i]) {
+        if (m->k[i] == key + 1) { m->v[i] = val; return; }
+        i = (i + 1) & (m->cap - 1);
+    }
+    m->k[i] = key + 1; m->v[i] = val; m->len++;
+}
+
+enum { SIGMA_BLOCK = 1 << 14 };
+#define SIGMA_NONE UINT64_MAX
+
+struct oracle_sigma_plan {
+    const uint64_t *w[4];
+    size_t n, padded, n_vars;
+    int threads;
+    uint64_t *first; /* recording-order key 4 * gate + wire of a Variable's first position; SIGMA_NONE: never on a wire */
+    uint64_t *last;  /* key + 1 of its last position; 0: never */
+    uint64_t *seen_before; /* per block of SIGMA_BLOCK rows: 1 + the largest Variable on a wire of an EARLIER row (0: none) */
+    size_t n_blocks;
+    u64map_t carry;  /* Variable -> its first position (sigma encoding) in the rows the chunks so far have covered */
+    size_t next_r1;
+    int bad;
+};
+
+typedef struct {
+    struct oracle_sigma_plan *P;
+    size_t a, b;           /* rows */
+    uint64_t va, vb;       /* this range's own Variables: on no wire of an earlier row */
+    size_t r0;             /* first row of out */
+    uint64_t *const *out;
+    u64map_t foreign;      /* a Variable seen here that may be on earlier rows -> its first position in [a, b) */
+    uint64_t *tails; size_t n_tails, cap_tails; /* (Variable, wire, gate): last position in [a, b), but not the Variable's last */
+    int bad;
+} sigma_job_t;
+
+static inline void atomic_min_u64(uint64_t *p, uint64_t x) {
+    uint64_t cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (x < cur && !__atomic_compare_exchange_n(p, &cur, x, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+static inline void atomic_max_u64(uint64_t *p, uint64_t x) {
+    uint64_t cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (x > cur && !__atomic_compare_exchange_n(p, &cur, x, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+
+/* pass 1 over blocks [a, b): first / last position of every Variable, the largest Variable of every block */
+static void *sigma_scan_worker(void *p) {
+    sigma_job_t *J = (sigma_job_t *)p;
+    struct oracle_sigma_plan *P = J->P;
+    for (size_t blk = J->a; blk < J->b; blk++) {
+        const size_t g0 = blk * SIGMA_BLOCK, g1 = g0 + SIGMA_BLOCK < P->n ? g0 + SIGMA_BLOCK : P->n;
+        uint64_t top = 0;
+        for (size_t g = g0; g < g1; g++)
+            for (int w = 0; w < 4; w++) {
+                const uint64_t v = P->w[w][g];
+                if (v >= P->n_vars) { J->bad = 1; continue; }
+                if (v + 1 > top) top = v + 1;
+                atomic_min_u64(&P->first[v], 4 * (uint64_t)g + (uint64_t)w);
+            }
+        P->seen_before[blk + 1] = top; /* (made a running maximum by the caller) */
+    }
+    for (size_t blk = J->b; blk-- > J->a;) {
+        const size_t g0 = blk * SIGMA_BLOCK, g1 = g0 + SIGMA_BLOCK < P->n ? g0 + SIGMA_BLOCK : P->n;
+        for (size_t g = g1; g-- > g0;)
+            for (int w = 4; w-- > 0;) {
+                const uint64_t v = P->w[w][g];
+                if (v < P->n_vars) atomic_max_u64(&P->last[v], 4 * (uint64_t)g + (uint64_t)w + 1);
+            }
+    }
+    return NULL;
+}
+
+struct oracle_sigma_plan *oracle_sigma_fast_begin(const uint64_t *w_l, const uint64_t *w_r, const uint64_t *w_o,
+                                                  const uint64_t *w_4, size_t n, size_t padded_n, size_t n_vars, int threads) {
+    if (padded_n < n || threads < 1) return NULL;
+    struct oracle_sigma_plan *P = (struct oracle_sigma_plan *)calloc(1, sizeof *P);
+    P->w[0] = w_l; P->w[1] = w_r; P->w[2] = w_o; P->w[3] = w_4;
+    P->n = n; P->padded = padded_n; P->n_vars = n_vars; P->threads = threads;
+    P->n_blocks = (n + SIGMA_BLOCK - 1) / SIGMA_BLOCK;
+    P->first = (uint64_t *)malloc((n_vars ? n_vars : 1) * sizeof(uint64_t));
+    P->last = (uint64_t *)calloc(n_vars ? n_vars : 1, sizeof(uint64_t));
+    P->seen_before = (uint64_t *)calloc(P->n_blocks + 1, sizeof(uint64_t));
+    memset(P->first, 0xff, (n_vars ? n_vars : 1) * sizeof(uint64_t));
+    map_init(&P->carry, 1024);
+    P->next_r1 = padded_n;
+    int T = threads;
+    if ((size_t)T > P->n_blocks) T = P->n_blocks ? (int)P->n_blocks : 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)T);
+    sigma_job_t *jobs = (sigma_job_t *)calloc((size_t)T, sizeof(sigma_job_t));
+    for (int t = 0; t < T; t++) {
+        jobs[t].P = P;
+        jobs[t].a = P->n_blocks * (size_t)t / (size_t)T;
+        jobs[t].b = P->n_blocks * (size_t)(t + 1) / (size_t)T;
+        pthread_create(&th[t], NULL, sigma_scan_worker, &jobs[t]);
+    }
+    for (int t = 0; t < T; t++) { pthread_join(th[t], NULL); P->bad |= jobs[t].bad; }
+    free(th); free(jobs);
+    for (size_t k = 1; k <= P->n_blocks; k++)
+        if (P->seen_before[k] < P->seen_before[k - 1]) P->seen_before[k] = P->seen_before[k - 1];
+    if (P->bad) { fprintf(stderr, "oracle_sigma_fast: a wire holds a Variable >= n_vars\n"); }
+    return P;
+}
+
+void oracle_sigma_fast_end(struct oracle_sigma_plan *P) {
+    if (!P) return;
+    free(P->first); free(P->last); free(P->seen_before);
+    map_free(&P->carry);
+    free(P);
+}
+
+/* 1 + the largest Variable on a wire of rows [0, a) */
+static uint64_t sigma_seen_before(const struct oracle_sigma_plan *P, size_t a) {
+    const size_t blk = a / SIGMA_BLOCK;
+    uint64_t top = P->seen_before[blk];
+    for (size_t g = blk * SIGMA_BLOCK; g < a; g++)
+        for (int w = 0; w < 4; w++)
+            if (P->w[w][g] + 1 > top) top = P->w[w][g] + 1;
+    return top;
+}
+
+static void *sigma_chunk_worker(void *p) {
+    sigma_job_t *J = (sigma_job_t *)p;
+    const struct oracle_sigma_plan *P = J->P;
+    const size_t own = (size_t)(J->vb - J->va), padded = P->padded;
+    uint64_t *next = (uint64_t *)malloc((own ? own : 1) * sizeof(uint64_t));
+    memset(next, 0xff, (own ? own : 1) * sizeof(uint64_t));
+    for (size_t g = J->b; g-- > J->a;)
+        for (int w = 4; w-- > 0;) {
+            const uint64_t v = P->w[w][g], here = (uint64_t)w * padded + g, key = 4 * (uint64_t)g + (uint64_t)w;
+            uint64_t nx = SIGMA_NONE;
+            if (v >= J->va) {               /* (v < vb: every Variable of these rows is below seen_before(b)) */
+                nx = next[v - J->va];
+                next[v - J->va] = here;
+            } else {
+                uint64_t *s = map_get(&J->foreign, v);
+                if (s) { nx = *s; *s = here; } else map_put(&J->foreign, v, here);
+            }
+            if (nx == SIGMA_NONE) {
+                if (P->last[v] == key + 1) {            /* the Variable's last position: the cycle closes on its first */
+                    const uint64_t f = P->first[v];
+                    nx = (f & 3) * padded + (f >> 2);
+                } else {                                 /* it comes again after row b: the caller knows where */
+                    if (J->n_tails == J->cap_tails) {
+                        J->cap_tails = J->cap_tails ? 2 * J->cap_tails : 64;
+                        J->tails = (uint64_t *)realloc(J->tails, 3 * J->cap_tails * sizeof(uint64_t));
+                    }
+                    uint64_t *t = &J->tails[3 * J->n_tails++];
+                    t[0] = v; t[1] = (uint64_t)w; t[2] = g;
+                    continue;
+                }
+            }
+            J->out[w][g - J->r0] = nx;
+        }
+    free(next);
+    return NULL;
+}
+
+/* sigma[w][r0 .. r1) -> out[w][0 .. r1 - r0), w = 0..3.  Chunks are asked for from the LAST row to the first: the first call
+ * has r1 = padded_n, every later one r1 = the previous call's r0 (a position's successor lies at or after it -- or is the
+ * Variable's first position, which pass 1 has).  Returns 0; -1 on a call out of order or an inconsistency. */
+int oracle_sigma_fast_chunk(struct oracle_sigma_plan *P, size_t r0, size_t r1, uint64_t *const out[4]) {
+    if (!P || P->bad || r1 != P->next_r1 || r0 >= r1) return -1;
+    P->next_r1 = r0;
+    for (int w = 0; w < 4; w++)      /* rows past the circuit map to themselves */
+        for (size_t g = r0 > P->n ? r0 : P->n; g < r1; g++) out[w][g - r0] = (uint64_t)w * P->padded + g;
+    const size_t e = r1 < P->n ? r1 : P->n;
+    if (r0 >= e) return 0;
+    int T = P->threads;
+    if ((size_t)T > (e - r0 + 255) / 256) T = (int)((e - r0 + 255) / 256);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)T);
+    sigma_job_t *jobs = (sigma_job_t *)calloc((size_t)T, sizeof(sigma_job_t));
+    for (int t = 0; t < T; t++) {
+        jobs[t].P = P;
+        jobs[t].a = r0 + (e - r0) * (size_t)t / (size_t)T;
+        jobs[t].b = r0 + (e - r0) * (size_t)(t + 1) / (size_t)T;
+        jobs[t].r0 = r0;
+        jobs[t].out = out;
+    }
+    for (int t = 0; t < T; t++) {
+        jobs[t].va = sigma_seen_before(P, jobs[t].a);
+        jobs[t].vb = t + 1 < T ? 0 : sigma_seen_before(P, jobs[t].b);
+        if (t) jobs[t - 1].vb = jobs[t].va;
+        map_init(&jobs[t].foreign, 256);
+    }
+    for (int t = 0; t < T; t++) pthread_create(&th[t], NULL, sigma_chunk_worker, &jobs[t]);
+    for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
+    int rc = 0;
+    for (int t = T; t-- > 0;)        /* a range's open ends: the first position in a later range, else in a later chunk */
+        for (size_t k = 0; k < jobs[t].n_tails; k++) {
+            const uint64_t *tl = &jobs[t].tails[3 * k];
+            const uint64_t *s = NULL;
+            for (int u = t + 1; u < T && !s; u++) s = map_get(&jobs[u].foreign, tl[0]);
+            if (!s) s = map_get(&P->carry, tl[0]);
+            if (!s) { rc = -1; continue; }
+            out[tl[1]][tl[2] - r0] = *s;
+        }
+    for (int t = T; t-- > 0;) {      /* descending: the smallest position of a Variable is written last */
+        for (size_t i = 0; i < jobs[t].foreign.cap; i++)
+            if (jobs[t].foreign.k[i]) map_put(&P->carry, jobs[t].foreign.k[i] - 1, jobs[t].foreign.v[i]);
+        map_free(&jobs[t].foreign);
+        free(jobs[t].tails);
+    }
+    free(th); free(jobs);
+    if (rc) P->bad = 1;
+    return rc;
+}
+
+/* ---- materialised columns of rows [r0, r1) ------------------------------------------------------------------------------ */
+
+typedef struct {
+    const uint64_t *w[4];
+    const fr_t *values;
+    size_t n_vars, r0, a, b;
+    oracle_full_columns_t out;
+    int bad;
+} mat_job_t;
+
+static void *mat_worker(void *p) {
+    mat_job_t *J = (mat_job_t *)p;
+    fr_t *const vals[4] = {J->out.w_l_value, J->out.w_r_value, J->out.w_o_value, J->out.w_4_value};
+    for (size_t g = J->a; g < J->b; g++) {
+        const size_t k = g - J->r0;
+        J->out.q_4[k] = FR_ZERO;           /* composer.c:push_arith_row; the caller lists the rows whose q_4 is not 0 */
+        J->out.q_arith[k] = FR_ONE;
+        J->out.q_range[k] = FR_ZERO; J->out.q_logic[k] = FR_ZERO;
+        J->out.q_fixed_group_add[k] = FR_ZERO; J->out.q_variable_group_add[k] = FR_ZERO;
+        J->out.w_4[k] = J->w[3][g];
+        for (int w = 0; w < 4; w++) {
+            const uint64_t v = J->w[w][g];
+            if (v >= J->n_vars) { J->bad = 1; vals[w][k] = FR_ZERO; continue; }
+            vals[w][k] = J->values[v];
+        }
+    }
+    return NULL;
+}
+
+int oracle_materialize_fast(const uint64_t *w_l, const uint64_t *w_r, const uint64_t *w_o, const uint64_t *w_4,
+                            const fr_t *values, size_t n_vars, const uint64_t *q4_rows, const fr_t *q4_values, size_t n_q4,
+                            size_t r0, size_t r1, int threads, const oracle_full_columns_t *out) {
+    if (r1 < r0 || threads < 1) return -1;
+    int T = threads;
+    if ((size_t)T > (r1 - r0 + 255) / 256) T = r1 > r0 ? (int)((r1 - r0 + 255) / 256) : 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)T);
+    mat_job_t *jobs = (mat_job_t *)calloc((size_t)T, sizeof(mat_job_t));
+    for (int t = 0; t < T; t++) {
+        mat_job_t *J = &jobs[t];
+        J->w[0] = w_l; J->w[1] = w_r; J->w[2] = w_o; J->w[3] = w_4;
+        J->values = values; J->n_vars = n_vars; J->r0 = r0; J->out = *out;
+        J->a = r0 + (r1 - r0) * (size_t)t / (size_t)T;
+        J->b = r0 + (r1 - r0) * (size_t)(t + 1) / (size_t)T;
+        pthread_create(&th[t], NULL, mat_worker, J);
+    }
+    int bad = 0;
+    for (int t = 0; t < T; t++) { pthread_join(th[t], NULL); bad |= jobs[t].bad; }
+    free(th); free(jobs);
+    for (size_t i = 0; i < n_q4; i++)
+        if (q4_rows[i] >= r0 && q4_rows[i] < r1) out->q_4[q4_rows[i] - r0] = q4_values[i];
+    return bad ? -1 : 0;
 }

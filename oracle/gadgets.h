@@ -67,6 +67,12 @@ int oracle_range_check_batch(fr_t min_range, fr_t max_range, const fr_t *witness
 int oracle_range_check_fast(fr_t min_range, fr_t max_range, const fr_t *witness, size_t batch, uint64_t var_base,
                             int threads, oracle_columns_t *out, uint64_t *result_vars);
 
+/* the same loop on witnesses allocated BEFORE it (the reference's own signature, range.rs:27-32): item i's Variable is
+ * witness_vars[i]; 4n + 11 rows and 2n + 523 new Variables per item */
+int oracle_range_check_allocated_fast(fr_t min_range, fr_t max_range, const fr_t *witness, const uint64_t *witness_vars,
+                                      size_t batch, uint64_t var_base, int threads, oracle_columns_t *out,
+                                      uint64_t *result_vars);
+
 /* oracle/fast.c, ragged forms: the columns of oracle_max_bound_batch / oracle_scalar_mix_batch for items [lo, hi) of a
  * batch whose prefix sums (row_off / var_off, batch + 1 entries, from the *_plan calls) the caller holds: rows are
  * written at row_off[i] - row_off[lo], item i's first Variable is var_base + var_off[i] and its assignment lies at
@@ -94,6 +100,29 @@ int oracle_max_bound_batch(const fr_t *max_range, const fr_t *witness, size_t ba
 int oracle_scalar_mix_batch(const fr_t *v, const fr_t *y, const fr_t *s, const fr_t *a, const fr_t *b, size_t batch,
                             int check, oracle_columns_t *out, uint64_t *result_vars, uint8_t *err_mask,
                             uint64_t *gate_base, uint64_t *var_base, uint64_t *n_gates, uint64_t *n_vars);
+
+/* ---- the f-rows of a whole circuit from its wire columns (oracle/fast.c) -------------------------------
+ * What composer_sigma() and composer_selector / composer_wire / composer_values_dense give for a composer.c composer,
+ * computed from the four wire columns + the assignments, threaded, for row ranges -- so that circuits of hundreds of millions
+ * of rows (assembled from the fast gadget forms above) can be checked word for word. */
+typedef struct oracle_sigma_plan oracle_sigma_plan_t;
+/* pass 1 over all n rows (first / last position of every Variable); wires must stay alive until _end */
+oracle_sigma_plan_t *oracle_sigma_fast_begin(const uint64_t *w_l, const uint64_t *w_r, const uint64_t *w_o, const uint64_t *w_4,
+                                             size_t n, size_t padded_n, size_t n_vars, int threads);
+/* sigma[w][r0 .. r1) -> out[w][0 .. r1 - r0); chunks from the LAST row to the first: r1 = padded_n, then the previous r0 */
+int oracle_sigma_fast_chunk(oracle_sigma_plan_t *plan, size_t r0, size_t r1, uint64_t *const out[4]);
+void oracle_sigma_fast_end(oracle_sigma_plan_t *plan);
+
+/* the columns pg_composer_materialize produces beyond the eight live ones */
+typedef struct {
+    fr_t *q_4, *q_arith, *q_range, *q_logic, *q_fixed_group_add, *q_variable_group_add;
+    uint64_t *w_4;
+    fr_t *w_l_value, *w_r_value, *w_o_value, *w_4_value;
+} oracle_full_columns_t;
+/* rows [r0, r1) -> out[..][0 .. r1 - r0); q_4 is zero except on the n_q4 listed rows (the dummy rows of composer_new()) */
+int oracle_materialize_fast(const uint64_t *w_l, const uint64_t *w_r, const uint64_t *w_o, const uint64_t *w_4,
+                            const fr_t *values, size_t n_vars, const uint64_t *q4_rows, const fr_t *q4_values, size_t n_q4,
+                            size_t r0, size_t r1, int threads, const oracle_full_columns_t *out);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,15 @@ class Columns(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("q_m", "q_l", "q_r", "q_o", "q_c", "w_l", "w_r", "w_o", "var_values")]
 
 
+FULL_SCALAR_COLS = ("q_4", "q_arith", "q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add")
+FULL_VALUE_COLS = ("w_l_value", "w_r_value", "w_o_value", "w_4_value")
+
+
+class FullColumns(C.Structure):
+    """oracle_full_columns_t: what pg_composer_materialize produces beyond the eight live columns"""
+    _fields_ = [(n, C.c_void_p) for n in FULL_SCALAR_COLS + ("w_4",) + FULL_VALUE_COLS]
+
+
 def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, f) for f in ("fr.c", "composer.c", "gadgets.c", "fast.c", "fr.h", "composer.h", "gadgets.h")]
     stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
@@ -73,6 +82,10 @@ def lib():
         "is_non_zero": (C.c_int, [vp, u64, Fr]), "maybe_equal": (u64, [vp, AllocatedScalar, AllocatedScalar]),
         "oracle_range_check_batch": (C.c_int, [Fr, Fr, vp, sz, C.c_int, P(Columns), vp, P(u64), P(u64), P(u64), P(u64)]),
         "oracle_range_check_fast": (C.c_int, [Fr, Fr, vp, sz, u64, C.c_int, P(Columns), vp]),
+        "oracle_range_check_allocated_fast": (C.c_int, [Fr, Fr, vp, vp, sz, u64, C.c_int, P(Columns), vp]),
+        "oracle_sigma_fast_begin": (vp, [vp, vp, vp, vp, sz, sz, sz, C.c_int]),
+        "oracle_sigma_fast_chunk": (C.c_int, [vp, sz, sz, P(vp)]), "oracle_sigma_fast_end": (None, [vp]),
+        "oracle_materialize_fast": (C.c_int, [vp, vp, vp, vp, vp, sz, vp, vp, sz, sz, sz, C.c_int, P(FullColumns)]),
         "oracle_max_bound_plan": (C.c_int, [vp, sz, C.c_int, vp, vp, vp]),
         "oracle_max_bound_fast": (C.c_int, [vp, vp, vp, vp, vp, sz, sz, u64, C.c_int, P(Columns), vp]),
         "oracle_scalar_mix_plan": (C.c_int, [vp, sz, vp, vp, vp]),
@@ -134,7 +147,10 @@ def _columns_into(out: dict | None, n_gates: int, n_vars: int):
     if out is None:
         return _alloc_columns(n_gates, n_vars)
     arrs = {}
-    for k in ("q_m", "q_l", "q_r", "q_o", "q_c", "var_values"):
+    sel = ("q_m", "q_l", "q_r", "q_o", "q_c")
+    have_sel = [k in out for k in sel]
+    assert all(have_sel) or not any(have_sel), "all five selector columns or none (wires and assignments only)"
+    for k in (sel if all(have_sel) else ()) + ("var_values",):
         n = n_vars if k == "var_values" else n_gates
         a = out[k]
         assert a.dtype == np.uint64 and a.flags.c_contiguous and a.size >= 4 * n, k
@@ -143,7 +159,7 @@ def _columns_into(out: dict | None, n_gates: int, n_vars: int):
         a = out[k]
         assert a.dtype == np.uint64 and a.flags.c_contiguous and a.size >= n_gates, k
         arrs[k] = a.reshape(-1)[:n_gates]
-    return arrs, Columns(**{k: v.ctypes.data for k, v in arrs.items()})
+    return arrs, Columns(**{k: v.ctypes.data for k, v in arrs.items()})  # (absent selector columns: NULL, not written)
 
 
 def _as_fr_array(a) -> np.ndarray:
@@ -195,6 +211,109 @@ def range_check_fast(min_mont, max_mont, witness: np.ndarray, threads: int = 1, 
         seconds = time.perf_counter() - t0
         assert rc == 0
     arrs.update(result_vars=res, n_gates=G * batch, n_vars=V * batch, num_bits=n, var_base=var_base, seconds=seconds)
+    return arrs
+
+
+def range_check_allocated_fast(min_mont, max_mont, witness: np.ndarray, witness_vars: np.ndarray, threads: int = 1,
+                               var_base: int = 5, out: dict | None = None):
+    """oracle/fast.c: `for i: range_check(min, max, AllocatedScalar(witness_vars[i], witness[i]))` on witnesses allocated before
+    the loop (/root/reference/src/range.rs:27-32): 4n + 11 rows, 2n + 523 new Variables per item, from var_base"""
+    L = lib()
+    witness = _as_fr_array(witness)
+    witness_vars = np.ascontiguousarray(witness_vars, dtype=np.uint64)
+    batch = witness.shape[0]
+    assert witness_vars.shape == (batch,)
+    mn, mx = fr(min_mont), fr(max_mont)
+    n = int(L.num_bits_closest_power_of_two(L.fr_sub(mx, L.fr_from_u64(1))))
+    G, V = 4 * n + 11, 2 * n + 523
+    arrs, cols = _columns_into(out, G * batch, V * batch)
+    res = np.zeros(batch, dtype=np.uint64)
+    rc = L.oracle_range_check_allocated_fast(mn, mx, witness.ctypes.data, witness_vars.ctypes.data, batch, var_base, threads,
+                                             C.byref(cols), res.ctypes.data)
+    assert rc == 0
+    arrs.update(result_vars=res, n_gates=G * batch, n_vars=V * batch, num_bits=n, var_base=var_base)
+    return arrs
+
+
+class SigmaFast:
+    """oracle/fast.c: sigma of a whole circuit from its four wire columns (uint64[n] each), chunk by chunk from the LAST row
+    of the padded domain to the first.  == Composer.sigma(padded_n) (tests/test_oracle_fast.py)."""
+
+    def __init__(self, w_l, w_r, w_o, w_4, padded_n: int, n_vars: int, threads: int = 1):
+        self.L = lib()
+        self.wires = [np.ascontiguousarray(w, dtype=np.uint64) for w in (w_l, w_r, w_o, w_4)]  # (kept alive)
+        self.n = self.wires[0].shape[0]
+        assert all(w.shape == (self.n,) for w in self.wires) and padded_n >= self.n
+        self.padded_n = padded_n
+        self.plan = self.L.oracle_sigma_fast_begin(*[w.ctypes.data for w in self.wires], self.n, padded_n, n_vars, threads)
+        assert self.plan, "oracle_sigma_fast_begin"
+        self.next_r1 = padded_n
+
+    def chunk(self, r0: int, r1: int, out=None) -> np.ndarray:
+        """sigma[:, r0:r1] as uint64[4, r1 - r0] (or into `out`: four C-contiguous uint64 arrays at least that long)"""
+        assert r1 == self.next_r1 and 0 <= r0 < r1, (r0, r1, self.next_r1)
+        m = r1 - r0
+        if out is None:
+            res = np.empty((4, m), dtype=np.uint64)
+            out = [res[w] for w in range(4)]
+        else:
+            res = None
+            for a in out:
+                assert a.dtype == np.uint64 and a.flags.c_contiguous and a.size >= m
+        ptrs = (C.c_void_p * 4)(*[a.ctypes.data for a in out])
+        rc = self.L.oracle_sigma_fast_chunk(self.plan, r0, r1, ptrs)
+        assert rc == 0, "oracle_sigma_fast_chunk: inconsistent wires or a chunk out of order"
+        self.next_r1 = r0
+        return res
+
+    def whole(self, chunk_rows: int = 1 << 20) -> np.ndarray:
+        res = np.empty((4, self.padded_n), dtype=np.uint64)
+        r1 = self.padded_n
+        while r1 > 0:
+            r0 = max(0, r1 - chunk_rows)
+            res[:, r0:r1] = self.chunk(r0, r1)
+            r1 = r0
+        return res
+
+    def close(self):
+        if self.plan:
+            self.L.oracle_sigma_fast_end(self.plan)
+            self.plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def materialize_fast(w_l, w_r, w_o, w_4, values: np.ndarray, r0: int, r1: int, q4: dict | None = None, threads: int = 1,
+                     out: dict | None = None) -> dict:
+    """oracle/fast.c: rows [r0, r1) of the eleven arrays pg_composer_materialize produces, from the wire columns and the dense
+    assignment table; q4 = {row: limbs} lists the rows whose q_4 is not zero (composer_new()'s first dummy row)"""
+    wires = [np.ascontiguousarray(w, dtype=np.uint64) for w in (w_l, w_r, w_o, w_4)]
+    values = _as_fr_array(values)
+    m = r1 - r0
+    arrs = {}
+    for k in FULL_SCALAR_COLS + FULL_VALUE_COLS:
+        if out is None:
+            arrs[k] = np.empty((m, 4), dtype=np.uint64)
+        else:
+            a = out[k]
+            assert a.dtype == np.uint64 and a.flags.c_contiguous and a.size >= 4 * m, k
+            arrs[k] = a.reshape(-1)[:4 * m].reshape(m, 4)
+    if out is None:
+        arrs["w_4"] = np.empty(m, dtype=np.uint64)
+    else:
+        assert out["w_4"].dtype == np.uint64 and out["w_4"].flags.c_contiguous and out["w_4"].size >= m
+        arrs["w_4"] = out["w_4"].reshape(-1)[:m]
+    fc = FullColumns(**{k: v.ctypes.data for k, v in arrs.items()})
+    q4 = q4 or {}
+    rows = np.array(sorted(q4), dtype=np.uint64)
+    vals = np.array([q4[r] for r in sorted(q4)], dtype=np.uint64).reshape(-1, 4)
+    rc = lib().oracle_materialize_fast(*[w.ctypes.data for w in wires], values.ctypes.data, values.shape[0], rows.ctypes.data,
+                                       vals.ctypes.data, len(q4), r0, r1, threads, C.byref(fc))
+    assert rc == 0, "oracle_materialize_fast: a wire holds a Variable beyond the table"
     return arrs
 
 

@@ -107,6 +107,57 @@ int main(void) {
     composer_dense_pi(cs, dense);
     uint64_t acc = 0;
     for (size_t i = 0; i < 4 * padded; i++) acc ^= sigma[i] ^ i;   /* a permutation of 0..4*padded-1 */
+    {   /* the threaded f-row forms on this composer's own wire columns: sigma in ragged chunks from the last row down, and the
+         * materialised columns == composer_sigma / the composer's columns and table */
+        const size_t nvars = composer_num_variables(cs);
+        const uint64_t *w[4] = {composer_wire(cs, PG_W_L), composer_wire(cs, PG_W_R), composer_wire(cs, PG_W_O), composer_wire(cs, PG_W_4)};
+        fr_t *table = malloc(nvars * 32);
+        composer_values_dense(cs, table);
+        oracle_sigma_plan_t *sp = oracle_sigma_fast_begin(w[0], w[1], w[2], w[3], n, padded, nvars, 3);
+        if (!sp) return 30;
+        uint64_t *chunk = malloc(4 * 97 * 8);
+        for (size_t r1 = padded; r1 > 0;) {
+            const size_t r0 = r1 > 97 ? r1 - 97 : 0;
+            uint64_t *const out[4] = {chunk, chunk + 97, chunk + 2 * 97, chunk + 3 * 97};
+            if (oracle_sigma_fast_chunk(sp, r0, r1, out)) return 31;
+            for (int k = 0; k < 4; k++)
+                if (memcmp(out[k], sigma + (size_t)k * padded + r0, (r1 - r0) * 8)) return 32;
+            r1 = r0;
+        }
+        oracle_sigma_fast_end(sp);
+        free(chunk);
+        oracle_full_columns_t fc;
+        fr_t *buf = malloc(10 * n * 32);
+        fc.q_4 = buf; fc.q_arith = buf + n; fc.q_range = buf + 2 * n; fc.q_logic = buf + 3 * n; fc.q_fixed_group_add = buf + 4 * n;
+        fc.q_variable_group_add = buf + 5 * n; fc.w_l_value = buf + 6 * n; fc.w_r_value = buf + 7 * n; fc.w_o_value = buf + 8 * n;
+        fc.w_4_value = buf + 9 * n;
+        fc.w_4 = malloc(n * 8);
+        const uint64_t q4_row = 1;
+        const fr_t q4_val = composer_selector(cs, PG_Q_4)[1];
+        if (oracle_materialize_fast(w[0], w[1], w[2], w[3], table, nvars, &q4_row, &q4_val, 1, 0, n, 4, &fc)) return 33;
+        if (memcmp(fc.q_4, composer_selector(cs, PG_Q_4), n * 32) || memcmp(fc.q_arith, composer_selector(cs, PG_Q_ARITH), n * 32) ||
+            memcmp(fc.q_logic, composer_selector(cs, PG_Q_LOGIC), n * 32) || memcmp(fc.w_4, w[3], n * 8)) return 34;
+        for (size_t i = 0; i < n; i++)
+            if (memcmp(&fc.w_o_value[i], &table[w[2][i]], 32) || memcmp(&fc.w_4_value[i], &table[w[3][i]], 32)) return 35;
+        free(buf); free(fc.w_4); free(table);
+    }
+    {   /* range_check on witnesses allocated before the loop: the threaded form == the faithful calls */
+        composer_t *c2 = composer_new();
+        allocated_scalar_t al[B];
+        uint64_t wv[B], r1[B], r2[B];
+        for (int i = 0; i < B; i++) { al[i] = allocated_scalar_allocate(c2, wit[i]); wv[i] = al[i].var; }
+        const size_t g0 = composer_circuit_size(c2), v0 = composer_num_variables(c2);
+        for (int i = 0; i < B; i++) r1[i] = range_check(c2, mn, mx, al[i]);
+        const size_t g1 = composer_circuit_size(c2), v1 = composer_num_variables(c2);
+        oracle_columns_t g = alloc_cols(g1 - g0, v1 - v0);
+        if (oracle_range_check_allocated_fast(mn, mx, wit, wv, B, v0, 3, &g, r2)) return 36;
+        fr_t *t2 = malloc(v1 * 32);
+        composer_values_dense(c2, t2);
+        if (memcmp(g.w_l, composer_wire(c2, PG_W_L) + g0, (g1 - g0) * 8) || memcmp(g.q_c, composer_selector(c2, PG_Q_C) + g0, (g1 - g0) * 32) ||
+            memcmp(g.var_values, t2 + v0, (v1 - v0) * 32) || memcmp(r1, r2, B * 8)) return 37;
+        free(t2); free_cols(&g);
+        composer_free(c2);
+    }
     free(sigma); free(dense);
     composer_free(cs);
     printf("oracle under sanitizers: ok (%zu rows, xor %llu)\n", n, (unsigned long long)acc);

@@ -97,3 +97,175 @@ def test_range_check_fast_into_callers_buffers():
         assert np.array_equal(part[k], whole[k][lo * G:hi * G]), k
     assert np.array_equal(part["var_values"], whole["var_values"][lo * V:hi * V])
     assert part["q_m"].ctypes.data == bufs["q_m"].ctypes.data and int(bufs["q_m"][-1]) == 0xEE
+
+
+# ---- the f-rows of a whole circuit from its wire columns (oracle_sigma_fast_*, oracle_materialize_fast) ----------------------
+
+def _composer_full(ora):
+    """everything oracle/composer.c holds that the f-rows are made of: four wire columns, the dense table, all eleven selectors"""
+    import ctypes as C
+    n = ora.n
+    exp, full = ora.export(), ora.full_columns()
+    wires = [exp["w_l"], exp["w_r"], exp["w_o"], full["w_4"]]
+    sel = {}
+    for name, col in (("q_4", 5), ("q_arith", 6), ("q_range", 7), ("q_logic", 8), ("q_fixed_group_add", 9), ("q_variable_group_add", 10)):
+        p = ora.L.composer_selector(ora.c, col)
+        sel[name] = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(n, 4)).copy()
+    return wires, exp["var_values"], sel
+
+
+def _check_f_rows_fast(ora, chunkings=((1 << 20, 1), (97, 3), (1000, 8), (5, 2))):
+    """oracle_sigma_fast == composer_sigma and oracle_materialize_fast == the composer's own columns / table, for several
+    chunkings and thread counts, padded and unpadded"""
+    wires, values, sel = _composer_full(ora)
+    n = ora.n
+    q4 = {r: [int(x) for x in sel["q_4"][r]] for r in range(n) if sel["q_4"][r].any()}
+    for padded in (n, 1 << (n - 1).bit_length(), n + 3):
+        exp = ora.sigma(padded)
+        for chunk, threads in chunkings:
+            sf = po.SigmaFast(*wires, padded_n=padded, n_vars=ora.num_vars, threads=threads)
+            got = sf.whole(chunk)
+            sf.close()
+            if not np.array_equal(got, exp):
+                w, g = np.argwhere(got != exp)[0]
+                raise AssertionError(f"sigma (padded {padded}, chunk {chunk}, {threads} threads) differs first at wire {w}, gate {g}: "
+                                     f"{got[w, g]} != {exp[w, g]}")
+    for chunk, threads in chunkings:
+        for r0 in range(0, n, chunk):
+            r1 = min(n, r0 + chunk)
+            m = po.materialize_fast(*wires, values, r0, r1, q4=q4, threads=threads)
+            for k in po.FULL_SCALAR_COLS:
+                assert np.array_equal(m[k], sel[k][r0:r1]), (k, r0)
+            assert np.array_equal(m["w_4"], wires[3][r0:r1])
+            for k, w in zip(po.FULL_VALUE_COLS, wires):
+                assert np.array_equal(m[k], values[w[r0:r1].astype(np.int64)]), (k, r0)
+
+
+def _random_gate_program(ora, rng, steps, hot=()):
+    """composer calls on random EXISTING Variables (old ones, recent ones, a few hot ones again and again): every cycle shape
+    sigma has to get right -- Variables on several wires of one row, Variables never on a wire, zero_var on the other wires"""
+    L = ora.L
+    F = lambda x: po.fr(synth.mont(x))
+    for _ in range(steps):
+        nv = ora.num_vars
+        pick = lambda: (rng.choice(hot) if hot and rng.random() < 0.2 else
+                        rng.randrange(max(0, nv - 6), nv) if rng.random() < 0.5 else rng.randrange(nv))
+        op = rng.randrange(8)
+        if op == 0:
+            ora.add_input(synth.mont(rng.randrange(1000)))
+        elif op == 1:
+            L.composer_add(ora.c, F(rng.randrange(5)), pick(), F(rng.randrange(5)), pick(), F(rng.randrange(9)), None)
+        elif op == 2:
+            L.composer_mul(ora.c, F(rng.randrange(5)), pick(), pick(), F(rng.randrange(9)), None)
+        elif op == 3:
+            L.composer_boolean_gate(ora.c, pick())
+        elif op == 4:
+            L.composer_assert_equal(ora.c, pick(), pick())
+        elif op == 5:
+            L.composer_constrain_to_constant(ora.c, pick(), F(rng.randrange(9)), None)
+        elif op == 6:
+            L.composer_poly_gate(ora.c, pick(), pick(), pick(), F(1), F(2), F(3), F(4), F(5), None)
+        else:
+            L.composer_add_witness_to_circuit_description(ora.c, F(rng.randrange(3)))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_f_rows_fast_on_random_programs(seed):
+    import random
+    rng = random.Random(seed)
+    ora = po.Composer(dummy=bool(seed & 1))
+    _random_gate_program(ora, rng, 400, hot=(0,) if seed == 1 else (0, 1, 2))
+    _check_f_rows_fast(ora)
+
+
+def test_f_rows_fast_on_gadget_circuits():
+    """gadget loops as the reference's tests write them, witnesses allocated inside and before the loop, results used by later
+    rows (a Variable's cycle crosses chunk and thread ranges), a fused-mix loop with failing items: the fast forms == composer.c"""
+    import ctypes as C
+    import random
+    rng = random.Random(9)
+    ora = po.Composer()
+    L, F = ora.L, lambda x: po.fr(synth.mont(x))
+    x = ora.add_input(synth.mont(5))
+    res = [int(L.range_check(ora.c, F(50_000), F(250_000), ora.allocate(synth.mont(v)))) for v in (60_000, 7, 250_000, 123_456)]
+    allocs = [ora.allocate(synth.mont(v)) for v in (3, 1 << 20, 77)]
+    nb = C.c_uint64()
+    for a in allocs:
+        res.append(int(L.max_bound(ora.c, F(1 << 16), a, C.byref(nb))))
+        res.append(int(L.range_check(ora.c, F(0), F(1 << 7), a)))
+    L.is_non_zero(ora.c, x, F(5))
+    assert L.is_non_zero(ora.c, ora.add_input(synth.mont(0)), F(0)) == 1     # Err after the partial emission
+    for r in res[:3] + res[-2:]:
+        L.conditionally_select_one(ora.c, x, r)
+        L.composer_constrain_to_constant(ora.c, r, F(1), None)
+    L.maybe_equal(ora.c, allocs[0], allocs[1])
+    _random_gate_program(ora, rng, 120, hot=(0, x, res[0]))
+    _check_f_rows_fast(ora, chunkings=((1 << 20, 1), (211, 4), (64, 16)))
+
+
+def _same_circuit(host, ora):
+    """tests/frows_oracle.HostCircuit == the composer.c composer the same calls made"""
+    wires, values, sel = _composer_full(ora)
+    assert (host.n, host.nv) == (ora.n, ora.num_vars)
+    for k in range(4):
+        assert np.array_equal(host.wires()[k], wires[k]), ("w_l", "w_r", "w_o", "w_4")[k]
+    assert np.array_equal(host.table(), values)
+    assert host.q4 == {r: [int(x) for x in sel["q_4"][r]] for r in range(ora.n) if sel["q_4"][r].any()}
+
+
+@pytest.mark.parametrize("shape", ["range_check", "allocated", "ragged", "mix", "loop"])
+def test_host_circuit_equals_faithful_composer(shape):
+    """the five circuits of tests/test_gpu_frows_exhaustive.py at a size composer.c runs in seconds: the host assembly from the
+    threaded gadget forms == the same loop of reference calls on oracle/composer.c + oracle/gadgets.c, and the f-rows computed
+    from it == composer_sigma / the composer's own columns"""
+    import ctypes as C
+    import bench
+    from tests.frows_oracle import HostCircuit
+    ora = po.Composer()
+    L, F = ora.L, lambda x: po.fr(synth.mont(x))
+    host = HostCircuit(60_000, 60_000, threads=3)
+    if shape == "range_check":
+        wit = synth.uniform_below(21, 2**64 + 2**60, seed=3)
+        res = host.range_check_batch(0, 2**64, wit, chunk=8)
+        assert list(res) == [int(L.range_check(ora.c, F(0), F(2**64), ora.allocate(w))) for w in wit]
+    elif shape == "allocated":
+        wit = synth.uniform_below(19, 2**16 + 2**14, seed=4)
+        first = host.add_input_batch(wit)
+        allocs = [ora.allocate(w) for w in wit]
+        assert first == int(allocs[0].var)
+        wv = np.arange(first, first + 19, dtype=np.uint64)
+        for mn, mx in ((0, 2**16), (1000, 70_000)):   # (twice over the same Variables: their cycles run through both calls)
+            res = host.range_check_allocated_batch(mn, mx, wv, wit, chunk=7)
+            assert list(res) == [int(L.range_check(ora.c, F(mn), F(mx), a)) for a in allocs]
+    elif shape == "ragged":
+        mr, wt = _c4_like(24, seed=5)
+        res, nb = host.max_bound_ragged_batch(mr, wt, chunk=5)
+        n_out = C.c_uint64()
+        for i in range(24):
+            assert int(res[i]) == int(L.max_bound(ora.c, po.fr(mr[i]), ora.allocate(wt[i]), C.byref(n_out)))
+            assert int(nb[i]) == n_out.value
+    elif shape == "mix":
+        v, y, s, a, b = bench.mix_inputs(40, seed=6)
+        v[[0, 7, 8, 39]] = 0
+        res, err = host.scalar_mix_batch(v, y, s, a, b, chunk=9)
+        for i in range(40):
+            vs = [ora.add_input(x[i]) for x in (v, y, s, a, b)]
+            st = L.is_non_zero(ora.c, vs[0], po.fr(v[i]))
+            assert st == int(err[i])
+            assert int(res[i, 0]) == int(L.conditionally_select_one(ora.c, vs[1], vs[2]))
+            A, B = po.AllocatedScalar(vs[3], po.fr(a[i])), po.AllocatedScalar(vs[4], po.fr(b[i]))
+            assert int(res[i, 1]) == int(L.maybe_equal(ora.c, A, B))
+    else:
+        wit = synth.uniform_below(17, 300_000, seed=7)
+        res = host.range_check_loop_with_constrain(50_000, 250_000, wit)
+        for i, w in enumerate(wit):
+            r = int(L.range_check(ora.c, F(50_000), F(250_000), ora.allocate(w)))
+            assert r == int(res[i])
+            L.composer_constrain_to_constant(ora.c, r, F(1), None)
+    _same_circuit(host, ora)
+    n = host.n
+    padded = 1 << (n - 1).bit_length()
+    sf = host.sigma_plan(padded)
+    assert np.array_equal(sf.whole(1 << 10), ora.sigma(padded))
+    sf.close()
+    _check_f_rows_fast(ora, chunkings=((500, 3),))
