@@ -44,7 +44,9 @@ static void put_row(const job_t *J, uint64_t r, uint64_t a, uint64_t b, uint64_t
     if (J->out.q_m) {   /* (NULL: the caller wants the wires and the assignments only -- tests/frows_oracle.py) */
         J->out.q_m[r] = qm; J->out.q_l[r] = ql; J->out.q_r[r] = qr; J->out.q_o[r] = qo; J->out.q_c[r] = qc;
     }
-    J->out.w_l[r] = a; J->out.w_r[r] = b; J->out.w_o[r] = c;
+    if (J->out.w_l) {   /* (NULL: the assignments only -- the witness refresh) */
+        J->out.w_l[r] = a; J->out.w_r[r] = b; J->out.w_o[r] = c;
+    }
 }
 
 /* one bound block: add row + scalar_decomposition_gadget + maybe_equal; returns the Variable of y and its value */

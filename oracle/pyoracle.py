@@ -155,7 +155,9 @@ def _columns_into(out: dict | None, n_gates: int, n_vars: int):
         a = out[k]
         assert a.dtype == np.uint64 and a.flags.c_contiguous and a.size >= 4 * n, k
         arrs[k] = a.reshape(-1)[:4 * n].reshape(n, 4)
-    for k in ("w_l", "w_r", "w_o"):
+    have_w = [k in out for k in ("w_l", "w_r", "w_o")]
+    assert all(have_w) or not any(have_w), "all three wire columns or none (assignments only)"
+    for k in ("w_l", "w_r", "w_o") if all(have_w) else ():
         a = out[k]
         assert a.dtype == np.uint64 and a.flags.c_contiguous and a.size >= n_gates, k
         arrs[k] = a.reshape(-1)[:n_gates]

@@ -420,3 +420,49 @@ def test_config_c2_witness_refresh_every_limb(engine):
     wl.release()
     del wl, table, cols, run, produce
     release_hbm()
+
+
+def test_witness_refresh_beyond_2_pow_32_units(engine):
+    """ONE pg_range_check_values_batch call over 2^22 witnesses: 4 336 910 336 Variables = 8.67e9 sixteen-byte units, 138.8 GB -- a
+    call whose unit count (and every byte offset past the first quarter) does not fit 32 bits, where the sweeps' tile-relative 32-bit
+    counters feed 64-bit global offsets (csrc/emit.hpp).  Every limb of the table against the threaded oracle
+    (/root/reference/src/range.rs:119-158: the ladder's assignments), guard regions before and after the table."""
+    from oracle import pyoracle as po
+    import plonk_gadgets_amd as pg
+    import types
+    G, V, LOG2 = 1031, 1034, 22
+    batch = 1 << LOG2
+    release_hbm()
+    free, _ = torch.cuda.mem_get_info()
+    if free < batch * V * 32 + (16 << 30):
+        pytest.skip("not enough free HBM for a 139-GB table")
+    GUARD = 4096
+    big = torch.empty((batch * V + 2 * GUARD, 4), dtype=torch.int64, device=DEV)
+    big[:GUARD].fill_(-1)
+    big[GUARD + batch * V:].fill_(-1)
+    table = big[GUARD:GUARD + batch * V]
+    table.fill_(0x3C3C3C3C3C3C3C3C)
+    wit = synth.random_scalars(batch, seed=synth.SEED + 22)
+    mn, mx = synth.mont(0), synth.mont(2**254)
+    engine.range_check_values_batch(pg.BlsScalar.from_int(0), pg.BlsScalar.from_int(2**254), dev(wit), table)
+    torch.cuda.synchronize()
+    assert bool((big[:GUARD] == -1).all()) and bool((big[GUARD + batch * V:] == -1).all())
+    threads = oracle_threads()
+    chunk = 1 << 13
+    cols = types.SimpleNamespace(var_values=table)
+
+    def produce(lo, hi, out):
+        po.range_check_fast(mn, mx, np.ascontiguousarray(wit[lo:hi]), threads=threads, var_base=5 + lo * V,
+                            out={"var_values": out["var_values"]})   # (the assignments alone: no rows are made)
+
+    def run(only=None):
+        return stream_compare(cols, lambda i: (0, i * V), produce, chunk, 1, chunk * V, n_items=batch, only_chunk=only, names=("var_values",))
+
+    n_chunks, words = run()
+    assert n_chunks == batch // chunk and words * 8 == batch * V * 32 == 138_781_130_752
+    last = batch - 1                                       # (the very last Variable: unit 8.67e9)
+    flip_and_find(cols, "var_values", last * V + 1033, 3, lambda: run(only=n_chunks - 1))
+    item = (1 << 21) + 5                                   # (just past 2^32 units: Variable 2^31 + ...)
+    flip_and_find(cols, "var_values", item * V + 2, 0, lambda: run(only=item // chunk))
+    del big, table, cols, run, produce
+    release_hbm()

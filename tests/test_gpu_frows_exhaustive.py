@@ -202,7 +202,7 @@ def check_with_flips(stager, arrays, total, chunk, produce, flips, descending=Fa
     return words
 
 
-def check_f_rows(stager, comp, host, sigma_chunk=1 << 22, mat_chunk=1 << 20, flip_rows=()):
+def check_f_rows(stager, comp, host, sigma_chunk=1 << 22, mat_chunk=1 << 20, flip_rows=(), materialize=True):
     """every word of the composer's wire columns and table, of pg_composer_permutation over the padded domain and of the eleven
     pg_composer_materialize arrays against the host circuit's; flip_rows: rows at which the one-bit self-tests are made"""
     import ctypes as C
@@ -243,6 +243,8 @@ def check_f_rows(stager, comp, host, sigma_chunk=1 << 22, mat_chunk=1 << 20, fli
     assert words["sigma"] == 4 * padded and bool((guard == -1).all())
     del sigma
     release_hbm()
+    if not materialize:
+        return words
     # -- f1: the materialised columns
     m = {k: torch.full((n, 4), -1, dtype=torch.int64, device=DEV) for k in MAT_SCALARS}
     m["w_4"] = torch.full((n,), -1, dtype=torch.int64, device=DEV)
@@ -390,6 +392,31 @@ def test_reference_loop_through_the_queue_every_word(engine, stager):
     n = comp.circuit_size()
     assert n == host.n == 3 + (calls // 2) * (1032 + 1028)
     check_f_rows(stager, comp, host, sigma_chunk=1 << 20, mat_chunk=1 << 19, flip_rows=(3 + 1031, 3 + 1032 * 2000 + 1031, n - 1, 7))
+    comp.close()
+    del comp, host
+    release_hbm()
+
+
+def test_sigma_padded_to_2_pow_30(engine, stager):
+    """pg_composer_permutation over a padded domain of 2^30 rows: a composer of 2^19 + 2^12 x (allocate + range_check(0, 2^254)) =
+    544 763 779 rows; sigma's 4 x 2^30 entries (34.4 GB) hold positions up to 2^32 and lie at byte offsets up to 2^35 -- every
+    word against the oracle's (the materialised columns of a composer this size do not fit beside it: sigma and the circuit only)"""
+    from tests.frows_oracle import HostCircuit
+    release_hbm()
+    batch = (1 << 19) + (1 << 12)
+    free, _ = torch.cuda.mem_get_info()
+    if free < (190 << 30):
+        pytest.skip("not enough free HBM for a 545 M-row composer and a 34-GB sigma")
+    comp = pg.StandardComposer(engine, 3 + batch * 1031 + 8, 5 + batch * 1034 + 8)
+    wit = synth.random_scalars(batch, seed=synth.SEED + 30)
+    res = comp.range_check_batch(S(0), S(2**254), dev(wit))
+    host = HostCircuit(3 + batch * 1031, 5 + batch * 1034, threads=oracle_threads())
+    ores = host.range_check_batch(0, 2**254, wit)
+    assert torch.equal(res, dev(ores))
+    n = comp.circuit_size()
+    assert (1 << (n - 1).bit_length()) == 1 << 30
+    words = check_f_rows(stager, comp, host, flip_rows=(n - 1, (1 << 29) + 17, 3 + 1031 * 400_000 + 600, 1), materialize=False)
+    assert words["sigma"] == 1 << 32
     comp.close()
     del comp, host
     release_hbm()
