@@ -55,6 +55,9 @@ struct PermSeg {
     // the item's rows (L includes them), their wires and their place in the result's cycle are closed forms like the others.  Kinds that
     // allocate their witness only.
     uint32_t tail;
+    // perm_ladder_kernel<true> (per-item bounds): the item that holds the first row of every piece of kPermLadderRows rows (set by
+    // pg_composer_permutation for the pass it launches; perm_piece_items_kernel fills it from the call's prefix sums)
+    const uint32_t *piece_item;
 };
 enum : uint32_t { WIRES_UNKNOWN = 0, WIRES_RANGE_CHECK = 1, WIRES_MAX_BOUND = 2, WIRES_RANGE_CHECK_ALLOCATED = 3, WIRES_MAX_BOUND_ALLOCATED = 4,
                   WIRES_DECOMPOSITION = 5,
@@ -490,9 +493,29 @@ __device__ __forceinline__ uint32_t ladder_foreign_rank(uint32_t kind, uint32_t 
 // 3.2; 3 per CU 3.55; 2 per CU 4.4 (too few waves for the arithmetic); 1024 rows, 4 per CU 3.26.
 constexpr uint32_t kPermLadderRows = PG_PERM_LADDER_ROWS;  // rows per workgroup piece (a multiple of 2 * kThreads)
 constexpr uint32_t kPermLadderLds = PG_PERM_LADDER_LDS;    // dynamic LDS per workgroup, unused: bounds how many are resident per CU
+// RAGGED (max_bound with a bound per item, WIRES_MAX_BOUND: range.rs:82-113 with bound_i): an item's ladder length follows from its row
+// count, L_i = 2 n_i + 5, and its place from the call's prefix sums -- the piece's first item from S.piece_item, the <= 58 items a piece
+// of 512 rows can hold (an item has at least nine) from a window of the prefix sums in LDS that every lane searches (six steps).
+// Before round 6 such segments went through perm_item_kernel's counting sort in LDS: 3.9 against 3.2 ms per 268 M rows.
+constexpr uint32_t kPermRaggedWindow = 64;  // prefix sums per piece: kPermLadderRows / 9 + 2 items and one entry more, rounded up
+// the item that holds row `first + p * kPermLadderRows` of the segment, for every piece p (one thread per item: an item is shorter than a piece)
+__global__ __launch_bounds__(kThreads) void perm_piece_items_kernel(const PermSeg S, uint32_t rows_per_piece, uint32_t *piece_item) {
+    const uint64_t d = S.gate_base & 1;  // pieces are counted from the even gate at or before the segment's first
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < S.items; i += (uint64_t)gridDim.x * kThreads) {
+        const uint64_t r0 = S.row_off[i], r1 = S.row_off[i + 1];
+        if (i == 0) piece_item[0] = 0;
+        for (uint64_t p = (r0 + d + rows_per_piece - 1) / rows_per_piece; p * rows_per_piece < r1 + d; p++)
+            if (p) piece_item[p] = (uint32_t)i;
+    }
+}
+
+template <bool RAGGED>
 __global__ __launch_bounds__(kThreads) void perm_ladder_kernel(const PermCtx X, const PermSeg S, const PermSparse Q, uint64_t *sigma) {
     extern __shared__ uint4 perm_ladder_pad[];
-    const uint32_t lane = threadIdx.x & 63, kind = S.wire_kind, n = S.wire_n;
+    __shared__ uint32_t s_off[RAGGED ? kPermRaggedWindow : 1];  // RAGGED: rows before items item0 .. of the piece, from item0's first
+    static_assert(!RAGGED || kPermLadderRows / 9 + 3 <= kPermRaggedWindow, "a piece's items fit the window of prefix sums");
+    const uint32_t lane = threadIdx.x & 63, kind = S.wire_kind;
+    uint32_t n = S.wire_n;
     if (X.padded_n == 1) perm_ladder_pad[threadIdx.x] = make_uint4(0, 0, 0, 0);  // (keeps the allocation)
     // a lane takes the TWO gates 2k, 2k + 1 (16 bytes of each of sigma's four columns: one store each where sigma is 16-byte aligned)
     const uint64_t first = S.gate_base & ~1ull, total = S.gate_end - first;  // (rows counted from the even gate at or before the segment's first)
@@ -515,8 +538,21 @@ __global__ __launch_bounds__(kThreads) void perm_ladder_kernel(const PermCtx X, 
     for (uint64_t base = (uint64_t)blockIdx.x * kPermLadderRows; base < total; base += (uint64_t)gridDim.x * kPermLadderRows) {
         // item and item-row of the piece's first gate (one wide division per piece; the rows' own are 32-bit)
         const uint64_t g_first = first + base, rel = g_first < S.gate_base ? 0 : g_first - S.gate_base;
-        const uint64_t item0 = rel / S.L;
-        const uint32_t j0 = (uint32_t)(rel - item0 * S.L), skip = (uint32_t)(g_first < S.gate_base ? S.gate_base - g_first : 0);
+        uint64_t item0, rows0 = 0;  // the piece's first item, the rows of the call before it
+        if constexpr (RAGGED) {
+            item0 = S.piece_item[base / kPermLadderRows];
+            rows0 = S.row_off[item0];
+            __syncthreads();  // (a workgroup's previous piece is read out)
+            if (threadIdx.x < kPermRaggedWindow) {
+                const uint64_t i = item0 + threadIdx.x < S.items ? item0 + threadIdx.x : S.items;
+                s_off[threadIdx.x] = (uint32_t)(S.row_off[i] - rows0);
+            }
+            __syncthreads();
+        } else {
+            item0 = rel / S.L;
+            rows0 = item0 * S.L;
+        }
+        const uint32_t j0 = (uint32_t)(rel - rows0), skip = (uint32_t)(g_first < S.gate_base ? S.gate_base - g_first : 0);
         for (uint32_t t = 2 * threadIdx.x; t < kPermLadderRows; t += 2 * kThreads) {  // (whole waves: the ballot below)
             uint64_t out[4][2], fitem[2] = {0, 0};
             uint32_t foreign[2] = {0, 0}, fslots[2] = {0, 0}, fj[2] = {0, 0};
@@ -526,10 +562,26 @@ __global__ __launch_bounds__(kThreads) void perm_ladder_kernel(const PermCtx X, 
                 const uint64_t g = g_first + t + h;
                 live[h] = g >= S.gate_base && g < S.gate_end;
                 const uint32_t tt = t + h - skip;  // rows past the piece's first row of the segment
-                const uint32_t q = __umulhi(j0 + tt, recip), j = (j0 + tt) - q * S.L;  // (exact: j0 + tt < 2^14, L < 2^11)
-                const uint64_t g_item = S.gate_base + (item0 + q) * S.L;
+                uint32_t q, j;
+                uint64_t g_item;
 #pragma unroll
                 for (uint32_t w = 0; w < 4; w++) out[w][h] = 0;
+                if constexpr (RAGGED) {
+                    if (!live[h]) continue;
+                    const uint32_t x = j0 + tt;
+                    uint32_t lo = 0;  // the last entry of the window that is <= x
+#pragma unroll
+                    for (uint32_t step = kPermRaggedWindow / 2; step; step >>= 1)
+                        if (s_off[lo + step] <= x) lo += step;
+                    q = lo;
+                    j = x - s_off[lo];
+                    n = (s_off[lo + 1] - s_off[lo] - 5) >> 1;  // L_i = 2 n_i + 5 (range.rs:82-113: one bound block)
+                    g_item = S.gate_base + rows0 + s_off[lo];
+                } else {
+                    q = __umulhi(j0 + tt, recip);
+                    j = (j0 + tt) - q * S.L;  // (exact: j0 + tt < 2^14, L < 2^11)
+                    g_item = S.gate_base + (item0 + q) * S.L;
+                }
                 if (!live[h]) continue;
                 uint32_t j2[3], w2[3];
                 const uint32_t fw = ladder_row(kind, n, j, j2, w2, S.tail), zw = fw ? zero_wires(g, j) : 0u;
