@@ -365,6 +365,150 @@ int oracle_scalar_mix_fast(const fr_t *v, const fr_t *y, const fr_t *s, const fr
     return 0;
 }
 
+/* ---- the scalar gadgets and the gate calls over arrays of EXISTING Variables ---------------------------------------------------
+ * The loops `for i: gadget(composer, Variable a[i], Variable b[i])` of the batched appends on Variables allocated before the call
+ * (pg_composer_conditionally_select_zero_batch ... pg_composer_boolean_gate_batch): the same composer calls as oracle/gadgets.c makes of
+ * /root/reference/src/scalar.rs:21-140 (and composer.c's add / mul / poly_gate), threaded over the items.  `table` holds the
+ * assignments of every Variable that exists before the call ([0, var_base)); an item's rows and Variables lie at i * L / var_base + i * V,
+ * or -- is_non_zero, whose items stop after one row and one Variable where the value is 0 (scalar.rs:73-80) -- at the prefix sums of
+ * oracle_is_non_zero_plan.  Pinned by tests/test_oracle_fast.py against the faithful calls. */
+typedef struct {
+    int kind;
+    const uint64_t *a, *b, *c;
+    const fr_t *table;
+    fr_t q[5];   /* gate kinds: q_m, q_l, q_r, q_o, q_c of the batch */
+} small_args_t;
+
+static void *small_worker(void *p) {
+    const job_t *J = (const job_t *)p;
+    const small_args_t *S = (const small_args_t *)J->max_range; /* (carried in a spare pointer of the shared job record) */
+    fr_t *vals = J->out.var_values;
+    const uint64_t vrel = J->var_base, Z = J->zero_var;
+    const fr_t m1 = J->neg_one;
+    static const uint32_t rows_of[] = {1, 4, 3, 3, 1, 1, 1}, vars_of[] = {1, 4, 3, 3, 1, 1, 0};
+    for (size_t i = J->lo; i < J->hi; i++) {
+        uint64_t r, var;
+        if (J->row_off) { r = J->row_off[i]; var = J->var_base + (J->var_off[i] - J->var_off[J->first]); }
+        else { r = (uint64_t)i * rows_of[S->kind]; var = J->var_base + (uint64_t)(i - J->first) * vars_of[S->kind]; }
+        const uint64_t av = S->a[i], bv = S->b ? S->b[i] : 0;
+        const fr_t a = S->table[av], b = S->b ? S->table[bv] : FR_ZERO;
+        uint64_t res = 0;
+        switch (S->kind) {
+        case ORACLE_SELECT_ZERO: {   /* scalar.rs:21-27: composer.mul(1, x, select, 0) */
+            const uint64_t o = var++;
+            vals[o - vrel] = fr_mul(a, b);
+            put_row(J, r++, av, bv, o, FR_ONE, FR_ZERO, FR_ZERO, m1, FR_ZERO);
+            res = o;
+            break;
+        }
+        case ORACLE_SELECT_ONE: {    /* scalar.rs:36-59 */
+            const uint64_t one = var++, sy = var++, oms = var++, o = var++;
+            vals[one - vrel] = FR_ONE;
+            put_row(J, r++, one, one, one, FR_ZERO, FR_ONE, FR_ZERO, FR_ZERO, m1);           /* :41 */
+            const fr_t sy_val = fr_mul(a, b), oms_val = fr_sub(FR_ONE, b);
+            vals[sy - vrel] = sy_val;
+            put_row(J, r++, av, bv, sy, FR_ONE, FR_ZERO, FR_ZERO, m1, FR_ZERO);              /* :43 */
+            vals[oms - vrel] = oms_val;
+            put_row(J, r++, one, bv, oms, FR_ZERO, FR_ONE, m1, m1, FR_ZERO);                 /* :45-50 */
+            vals[o - vrel] = fr_add(sy_val, oms_val);
+            put_row(J, r++, sy, oms, o, FR_ZERO, FR_ONE, FR_ONE, m1, FR_ZERO);               /* :53-58 */
+            res = o;
+            break;
+        }
+        case ORACLE_MAYBE_EQUAL: {   /* scalar.rs:105-140 */
+            const uint64_t uv = var++, zv = var++, ev = var++;
+            const fr_t u = fr_sub(a, b);
+            fr_t z = FR_ZERO;
+            if (!fr_is_zero(u)) fr_invert(u, &z);                                            /* unwrap_or(zero) :121-122 */
+            vals[uv - vrel] = u;
+            put_row(J, r++, av, bv, uv, FR_ZERO, FR_ONE, m1, m1, FR_ZERO);                   /* :111-117 */
+            vals[zv - vrel] = z;
+            vals[ev - vrel] = fr_sub(FR_ONE, fr_mul(u, z));                                  /* :126 */
+            put_row(J, r++, zv, uv, ev, m1, FR_ZERO, FR_ZERO, m1, FR_ONE);
+            put_row(J, r++, ev, uv, uv, FR_ONE, FR_ZERO, FR_ZERO, FR_ZERO, FR_ZERO);         /* :129-138 */
+            res = ev;
+            break;
+        }
+        case ORACLE_IS_NON_ZERO: {   /* scalar.rs:63-97, value_assigned = the Variable's own assignment */
+            const uint64_t assigned = var++;
+            vals[assigned - vrel] = a;
+            put_row(J, r++, av, assigned, Z, FR_ZERO, FR_ONE, m1, FR_ZERO, FR_ZERO);         /* assert_equal :71 */
+            if (!fr_is_zero(a)) {                                                            /* else Err(NonExistingInverse) :79 */
+                const uint64_t iv = var++, one = var++;
+                fr_t inv;
+                fr_invert(a, &inv);
+                vals[iv - vrel] = inv;                                                       /* :77 */
+                vals[one - vrel] = FR_ONE;                                                   /* :83 */
+                put_row(J, r++, one, one, one, FR_ZERO, FR_ONE, FR_ZERO, FR_ZERO, m1);
+                put_row(J, r++, av, iv, one, FR_ONE, FR_ZERO, FR_ZERO, m1, FR_ZERO);         /* :84-94 */
+            }
+            break;
+        }
+        case ORACLE_GATE_ADD: {      /* composer.c:composer_add -- q_l a + q_r b + q_c */
+            const uint64_t o = var++;
+            vals[o - vrel] = fr_add(fr_add(fr_mul(S->q[1], a), fr_mul(S->q[2], b)), S->q[4]);
+            put_row(J, r++, av, bv, o, FR_ZERO, S->q[1], S->q[2], m1, S->q[4]);
+            res = o;
+            break;
+        }
+        case ORACLE_GATE_MUL: {      /* composer.c:composer_mul -- q_m a b + q_c */
+            const uint64_t o = var++;
+            vals[o - vrel] = fr_add(fr_mul(fr_mul(S->q[0], a), b), S->q[4]);
+            put_row(J, r++, av, bv, o, S->q[0], FR_ZERO, FR_ZERO, m1, S->q[4]);
+            res = o;
+            break;
+        }
+        default:                     /* composer.c:composer_poly_gate: a row on three existing Variables, nothing created */
+            put_row(J, r++, av, bv, S->c[i], S->q[0], S->q[1], S->q[2], S->q[3], S->q[4]);
+            break;
+        }
+        if (J->result_vars) J->result_vars[i - J->first] = res;
+    }
+    return NULL;
+}
+
+int oracle_is_non_zero_plan(const uint64_t *vars, const fr_t *table, size_t batch, uint64_t *row_off, uint64_t *var_off,
+                            uint8_t *err_mask) {
+    uint64_t r = 0, x = 0;
+    for (size_t i = 0; i < batch; i++) {
+        const int z = fr_is_zero(table[vars[i]]);
+        row_off[i] = r; var_off[i] = x;
+        r += z ? 1 : 3;
+        x += z ? 1 : 3;
+        if (err_mask) err_mask[i] = (uint8_t)z;
+    }
+    row_off[batch] = r; var_off[batch] = x;
+    return 0;
+}
+
+int oracle_small_batch_fast(int kind, const uint64_t *a, const uint64_t *b, const uint64_t *c, const fr_t *table,
+                            const fr_t *selectors /* gate kinds: q_m, q_l, q_r, q_o, q_c; else NULL */, const uint64_t *row_off,
+                            const uint64_t *var_off, size_t lo, size_t hi, uint64_t var_base, uint64_t zero_var, int threads,
+                            oracle_columns_t *out, uint64_t *result_vars) {
+    if (kind < 0 || kind > ORACLE_GATE_ROWS || !a || !table || (kind == ORACLE_IS_NON_ZERO) != (row_off != NULL)) return -1;
+    if (kind != ORACLE_IS_NON_ZERO && !b) return -1;
+    if (kind == ORACLE_GATE_ROWS && !c) return -1;
+    small_args_t S;
+    memset(&S, 0, sizeof S);
+    S.kind = kind; S.a = a; S.b = b; S.c = c; S.table = table;
+    if (selectors) memcpy(S.q, selectors, sizeof S.q);
+    static const uint32_t rows_of[] = {1, 4, 3, 3, 1, 1, 1}, vars_of[] = {1, 4, 3, 3, 1, 1, 0};
+    job_t base;
+    memset(&base, 0, sizeof base);
+    base.neg_one = fr_neg(FR_ONE);
+    base.max_range = (const fr_t *)&S;
+    base.row_off = row_off;
+    base.var_off = var_off;
+    base.first = lo;
+    base.row_rel = row_off ? row_off[lo] : (uint64_t)lo * rows_of[kind];
+    base.var_base = var_base + (var_off ? var_off[lo] : (uint64_t)lo * vars_of[kind]);
+    base.zero_var = zero_var;
+    base.out = *out;
+    base.result_vars = result_vars;
+    run_threads(&base, lo, hi, threads, small_worker);
+    return 0;
+}
+
 /* ==== the f-rows of a WHOLE circuit, from its wire columns ================================================
  *
  * oracle/composer.c keeps, like dusk-plonk 0.8's Permutation, a Variable -> [WireData] map that every row updates, and

@@ -101,6 +101,16 @@ int oracle_scalar_mix_batch(const fr_t *v, const fr_t *y, const fr_t *s, const f
                             int check, oracle_columns_t *out, uint64_t *result_vars, uint8_t *err_mask,
                             uint64_t *gate_base, uint64_t *var_base, uint64_t *n_gates, uint64_t *n_vars);
 
+/* oracle/fast.c: `for i: gadget(a[i], b[i])` on EXISTING Variables -- the scalar gadgets (scalar.rs:21-140) and the composer's add /
+ * mul / poly_gate over arrays -- items [lo, hi), threaded; `table`: the assignments of the Variables [0, var_base) that exist before
+ * the call.  is_non_zero is ragged (its plan gives the prefix sums), the others uniform. */
+enum { ORACLE_SELECT_ZERO = 0, ORACLE_SELECT_ONE, ORACLE_MAYBE_EQUAL, ORACLE_IS_NON_ZERO, ORACLE_GATE_ADD, ORACLE_GATE_MUL, ORACLE_GATE_ROWS };
+int oracle_is_non_zero_plan(const uint64_t *vars, const fr_t *table, size_t batch, uint64_t *row_off, uint64_t *var_off,
+                            uint8_t *err_mask);
+int oracle_small_batch_fast(int kind, const uint64_t *a, const uint64_t *b, const uint64_t *c, const fr_t *table,
+                            const fr_t *selectors, const uint64_t *row_off, const uint64_t *var_off, size_t lo, size_t hi,
+                            uint64_t var_base, uint64_t zero_var, int threads, oracle_columns_t *out, uint64_t *result_vars);
+
 /* ---- the f-rows of a whole circuit from its wire columns (oracle/fast.c) -------------------------------
  * What composer_sigma() and composer_selector / composer_wire / composer_values_dense give for a composer.c composer,
  * computed from the four wire columns + the assignments, threaded, for row ranges -- so that circuits of hundreds of millions

@@ -83,6 +83,8 @@ def lib():
         "oracle_range_check_batch": (C.c_int, [Fr, Fr, vp, sz, C.c_int, P(Columns), vp, P(u64), P(u64), P(u64), P(u64)]),
         "oracle_range_check_fast": (C.c_int, [Fr, Fr, vp, sz, u64, C.c_int, P(Columns), vp]),
         "oracle_range_check_allocated_fast": (C.c_int, [Fr, Fr, vp, vp, sz, u64, C.c_int, P(Columns), vp]),
+        "oracle_is_non_zero_plan": (C.c_int, [vp, vp, sz, vp, vp, vp]),
+        "oracle_small_batch_fast": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, sz, sz, u64, u64, C.c_int, P(Columns), vp]),
         "oracle_sigma_fast_begin": (vp, [vp, vp, vp, vp, sz, sz, sz, C.c_int]),
         "oracle_sigma_fast_chunk": (C.c_int, [vp, sz, sz, P(vp)]), "oracle_sigma_fast_end": (None, [vp]),
         "oracle_materialize_fast": (C.c_int, [vp, vp, vp, vp, vp, sz, vp, vp, sz, sz, sz, C.c_int, P(FullColumns)]),
@@ -234,6 +236,48 @@ def range_check_allocated_fast(min_mont, max_mont, witness: np.ndarray, witness_
                                              C.byref(cols), res.ctypes.data)
     assert rc == 0
     arrs.update(result_vars=res, n_gates=G * batch, n_vars=V * batch, num_bits=n, var_base=var_base)
+    return arrs
+
+
+SMALL_KINDS = {"select_zero": (0, 1, 1), "select_one": (1, 4, 4), "maybe_equal": (2, 3, 3), "is_non_zero": (3, 3, 3), "add": (4, 1, 1),
+               "mul": (5, 1, 1), "rows": (6, 1, 0)}   # name -> (ORACLE_* kind, rows, Variables of a full item)
+
+
+def is_non_zero_plan(vars_: np.ndarray, table: np.ndarray):
+    """prefix sums of rows / Variables of `for v in vars: is_non_zero(v, value of v)` and its error mask (scalar.rs:73-80)"""
+    vars_ = np.ascontiguousarray(vars_, dtype=np.uint64)
+    table = _as_fr_array(table)
+    batch = vars_.shape[0]
+    roff, voff = np.zeros(batch + 1, dtype=np.uint64), np.zeros(batch + 1, dtype=np.uint64)
+    err = np.zeros(batch, dtype=np.uint8)
+    lib().oracle_is_non_zero_plan(vars_.ctypes.data, table.ctypes.data, batch, roff.ctypes.data, voff.ctypes.data, err.ctypes.data)
+    return roff, voff, err
+
+
+def small_batch_fast(kind: str, a, b, c, table: np.ndarray, lo: int, hi: int, var_base: int, zero_var: int = 0, selectors=None,
+                     plan=None, threads: int = 1, out: dict | None = None):
+    """oracle/fast.c: items [lo, hi) of `for i: gadget(a[i], b[i])` on existing Variables (kind: SMALL_KINDS; selectors: the five
+    Montgomery scalars q_m, q_l, q_r, q_o, q_c of a gate batch; plan: is_non_zero_plan's, for is_non_zero)"""
+    k, rows, nvars = SMALL_KINDS[kind]
+    arr = [None if x is None else np.ascontiguousarray(x, dtype=np.uint64) for x in (a, b, c)]
+    table = _as_fr_array(table)
+    if plan is not None:
+        roff, voff = plan[0], plan[1]
+        G, V = int(roff[hi] - roff[lo]), int(voff[hi] - voff[lo])
+    else:
+        roff = voff = None
+        G, V = rows * (hi - lo), nvars * (hi - lo)
+    if out is not None and "var_values" not in out:
+        out = dict(out, var_values=np.zeros((0, 4), dtype=np.uint64))
+    arrs, cols = _columns_into(out, G, V)
+    res = np.zeros(hi - lo, dtype=np.uint64)
+    sel = None if selectors is None else np.ascontiguousarray(selectors, dtype=np.uint64).reshape(5, 4)
+    rc = lib().oracle_small_batch_fast(k, *[None if x is None else x.ctypes.data for x in arr], table.ctypes.data,
+                                       None if sel is None else sel.ctypes.data, None if roff is None else roff.ctypes.data,
+                                       None if voff is None else voff.ctypes.data, lo, hi, var_base, zero_var, threads, C.byref(cols),
+                                       res.ctypes.data)
+    assert rc == 0, "oracle_small_batch_fast: bad arguments"
+    arrs.update(result_vars=res, n_gates=G, n_vars=V)
     return arrs
 
 

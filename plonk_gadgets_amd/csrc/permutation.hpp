@@ -61,7 +61,10 @@ struct PermSeg {
 };
 enum : uint32_t { WIRES_UNKNOWN = 0, WIRES_RANGE_CHECK = 1, WIRES_MAX_BOUND = 2, WIRES_RANGE_CHECK_ALLOCATED = 3, WIRES_MAX_BOUND_ALLOCATED = 4,
                   WIRES_DECOMPOSITION = 5,
-                  WIRES_MIX = 6 };  // the fused scalar mix, every item complete (ten rows, fifteen Variables: ScalarMixGD::row)
+                  WIRES_MIX = 6,    // the fused scalar mix (ten rows, fifteen Variables: ScalarMixGD::row; eight / thirteen where v = 0)
+                  // the small gadgets on Variables from elsewhere (scalar_gadgets.hpp) and the gate batches (composer.hpp): SegTemplate below
+                  WIRES_SELECT_ZERO = 7, WIRES_SELECT_ONE = 8, WIRES_MAYBE_EQUAL = 9, WIRES_IS_NON_ZERO = 10, WIRES_GATE_OUT = 11,
+                  WIRES_GATE_ROWS = 12, WIRES_KINDS = 13 };
 constexpr uint32_t kZeroWire = 0xfffffffeu;  // "zero_var" (the composer's Variable with value 0: is_non_zero's first row has it)
 // offsets (from the item's first own Variable) of the three wires of item-row j; kWitnessWire: the witness, which is the item's
 // first Variable for the kinds that allocate it and a Variable from elsewhere (read it from the wire column) for the others
@@ -636,6 +639,231 @@ __global__ __launch_bounds__(kThreads) void perm_ladder_kernel(const PermCtx X, 
                             atomicAdd(Q.count + 1, 1ull);
                         }
                     }
+            }
+        }
+    }
+}
+
+// ---- sigma of the small gadgets' rows in closed form ---------------------------------------------------------------------------
+// The scalar gadgets (/root/reference/src/scalar.rs) and the gate batches leave items of one to ten rows whose wires are, row by row,
+// one of the item's OWN Variables (an offset from its first), one of the call's INPUT Variables (foreign: a Variable from elsewhere,
+// read back from the wire column) or zero_var.  SegTemplate says which, per kind, for the full item and for the SHORT one that
+// is_non_zero leaves when it stops at its error (scalar.rs:73-80: one row, one Variable -- in the fused mix eight rows, thirteen
+// Variables).  Everything sigma needs follows from that table: an own Variable's positions are the table's entries that name it, in
+// row-major order, so a position's successor is the next such entry (the first, from the last) -- derived once per workgroup into LDS;
+// a foreign position goes to the sparse list at a slot that is a function of (item, rank of the position in its item); a zero_var
+// position -- the table's, or a foreign Variable that IS zero_var -- links to the next one of its row, the fourth wire's to the first
+// of the next row.  One lane per two gates, like perm_ladder_kernel; ragged segments (failing items) find a row's item in a window of
+// the call's prefix sums.  This replaces perm_item_kernel's counting sort in LDS for every batched append that is not a ladder.
+constexpr uint8_t kTmplForeign = 0xF0, kTmplZero = 0xFE, kTmplNone = 0xFF;  // wire codes (0 .. 14: the item's own Variable)
+constexpr uint32_t kTmplRows = 10;
+struct SegTemplate {
+    uint8_t L[2], V[2];            // rows / Variables of a full item, of a short one (0: the kind has none)
+    uint8_t wire[2][kTmplRows][3];
+};
+#define PG_T3(a, b, c) {a, b, c}
+#define PG_TF0 0xF0
+#define PG_TF1 0xF1
+#define PG_TF2 0xF2
+#define PG_TZ 0xFE
+#define PG_TX PG_T3(0xFF, 0xFF, 0xFF)
+__device__ const SegTemplate g_seg_templates[WIRES_KINDS - WIRES_MIX] = {
+    // WIRES_MIX: [v y s a b | va inv one | one' sy oms out | u z yeq] (ScalarMixGD::row); short: [v y s a b | va | one' sy oms out | u z yeq]
+    {{10, 8}, {15, 13},
+     {{PG_T3(0, 5, PG_TZ), PG_T3(7, 7, 7), PG_T3(0, 6, 7), PG_T3(8, 8, 8), PG_T3(1, 2, 9), PG_T3(8, 2, 10), PG_T3(9, 10, 11), PG_T3(3, 4, 12),
+       PG_T3(13, 12, 14), PG_T3(14, 12, 12)},
+      {PG_T3(0, 5, PG_TZ), PG_T3(6, 6, 6), PG_T3(1, 2, 7), PG_T3(6, 2, 8), PG_T3(7, 8, 9), PG_T3(3, 4, 10), PG_T3(11, 10, 12), PG_T3(12, 10, 10),
+       PG_TX, PG_TX}}},
+    // WIRES_SELECT_ZERO: (x, select, out)                                                         scalar.rs:21-27
+    {{1, 0}, {1, 0}, {{PG_T3(PG_TF0, PG_TF1, 0), PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX}, {PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX}}},
+    // WIRES_SELECT_ONE: [one sy oms out]: (one,one,one) (y,sel,sy) (one,sel,oms) (sy,oms,out)      scalar.rs:36-59
+    {{4, 0}, {4, 0}, {{PG_T3(0, 0, 0), PG_T3(PG_TF0, PG_TF1, 1), PG_T3(0, PG_TF1, 2), PG_T3(1, 2, 3), PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX}, {PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX}}},
+    // WIRES_MAYBE_EQUAL: [u z y]: (a,b,u) (z,u,y) (y,u,u)                                          scalar.rs:105-140
+    {{3, 0}, {3, 0}, {{PG_T3(PG_TF0, PG_TF1, 0), PG_T3(1, 0, 2), PG_T3(2, 0, 0), PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX}, {PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX}}},
+    // WIRES_IS_NON_ZERO: [va inv one]: (var,va,zero) (one,one,one) (var,inv,one); short: [va]: (var,va,zero)   scalar.rs:63-97
+    {{3, 1}, {3, 1}, {{PG_T3(PG_TF0, 0, PG_TZ), PG_T3(2, 2, 2), PG_T3(PG_TF0, 1, 2), PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX}, {PG_T3(PG_TF0, 0, PG_TZ), PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX}}},
+    // WIRES_GATE_OUT: add / mul over arrays of Variables: (a, b, out)
+    {{1, 0}, {1, 0}, {{PG_T3(PG_TF0, PG_TF1, 0), PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX}, {PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX}}},
+    // WIRES_GATE_ROWS: poly_gate / constrain_to_constant / boolean_gate over arrays: (a, b, c), no Variable
+    {{1, 0}, {0, 0}, {{PG_T3(PG_TF0, PG_TF1, PG_TF2), PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX}, {PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX, PG_TX}}},
+};
+#undef PG_T3
+#undef PG_TF0
+#undef PG_TF1
+#undef PG_TF2
+#undef PG_TZ
+#undef PG_TX
+// positions of a full item that hold a Variable from elsewhere (= its slots on the sparse list; a short item leaves the rest as holes)
+__host__ __device__ inline uint32_t template_foreign_per_item(uint32_t kind) {
+    return kind == WIRES_SELECT_ZERO || kind == WIRES_MAYBE_EQUAL || kind == WIRES_IS_NON_ZERO || kind == WIRES_GATE_OUT ? 2u
+           : kind == WIRES_SELECT_ONE || kind == WIRES_GATE_ROWS ? 3u : 0u;
+}
+__host__ __device__ inline bool is_template_kind(uint32_t kind) { return kind >= WIRES_MIX && kind < WIRES_KINDS; }
+
+constexpr uint32_t kTmplWindow = 1024;  // ragged: prefix sums per piece (a piece of 512 rows holds at most 513 items; a power of two)
+template <bool RAGGED>
+__global__ __launch_bounds__(kThreads) void perm_template_kernel(const PermCtx X, const PermSeg S, const PermSparse Q, uint64_t *sigma) {
+    extern __shared__ uint4 perm_template_pad[];
+    __shared__ uint8_t s_wire[2][kTmplRows][4], s_succ[2][kTmplRows][4], s_rank[2][kTmplRows][4];
+    __shared__ uint32_t s_foreign[2];                           // foreign positions of a full / short item
+    __shared__ uint32_t s_off[RAGGED ? kTmplWindow : 1];        // RAGGED: rows before items item0 .. of the piece, from item0's first
+    static_assert(kPermLadderRows + 2 <= kTmplWindow, "a piece's items fit the window of prefix sums");
+    if (X.padded_n == 1) perm_template_pad[threadIdx.x] = make_uint4(0, 0, 0, 0);  // (keeps the allocation)
+    const SegTemplate &T = g_seg_templates[S.wire_kind - WIRES_MIX];
+    const uint32_t Lf = T.L[0], Ls = T.L[1], Fmax = template_foreign_per_item(S.wire_kind);
+    // ---- the table, and what follows from it: successors of own Variables' positions, ranks of the foreign ones ----
+    if (threadIdx.x < 2 * kTmplRows * 3) {
+        const uint32_t sh = threadIdx.x / (kTmplRows * 3), p = threadIdx.x % (kTmplRows * 3), row = p / 3, w = p % 3, rows = T.L[sh];
+        const uint8_t code = row < rows ? T.wire[sh][row][w] : kTmplNone;
+        s_wire[sh][row][w] = code;
+        uint32_t succ = 4 * row + w, rank = 0;
+        if (code < kTmplForeign) {  // an own Variable: the next entry that names it, or -- from the last -- the first
+            uint32_t first = 0xff, next = 0xff;
+            for (uint32_t q = 0; q < rows * 3; q++)
+                if (T.wire[sh][q / 3][q % 3] == code) {
+                    if (first == 0xff) first = q;
+                    if (q > p && next == 0xff) next = q;
+                }
+            const uint32_t z = next != 0xff ? next : first;
+            succ = 4 * (z / 3) + z % 3;
+        } else if (code < kTmplZero) {  // foreign: its rank among the item's foreign positions, in recording order
+            for (uint32_t q = 0; q < p; q++) {
+                const uint8_t c2 = T.wire[sh][q / 3][q % 3];
+                rank += c2 >= kTmplForeign && c2 < kTmplZero ? 1u : 0u;
+            }
+        }
+        s_succ[sh][row][w] = (uint8_t)succ;
+        s_rank[sh][row][w] = (uint8_t)rank;
+    }
+    if (threadIdx.x < 2) {
+        uint32_t f = 0;
+        for (uint32_t q = 0; q < (uint32_t)T.L[threadIdx.x] * 3; q++) {
+            const uint8_t c2 = T.wire[threadIdx.x][q / 3][q % 3];
+            f += c2 >= kTmplForeign && c2 < kTmplZero ? 1u : 0u;
+        }
+        s_foreign[threadIdx.x] = f;
+    }
+    __syncthreads();
+    const uint64_t first = S.gate_base & ~1ull, total = S.gate_end - first;  // (rows counted from the even gate at or before the segment's first)
+    const bool wide = (reinterpret_cast<uintptr_t>(sigma) & 15) == 0 && !(X.padded_n & 1);
+    const uint32_t recip = (uint32_t)(((1ull << 32) + Lf - 1) / Lf);
+    const bool pow2 = (X.padded_n & (X.padded_n - 1)) == 0;
+    const uint32_t sh_bits = 63u - (uint32_t)__clzll((long long)X.padded_n);
+    auto enc = [&](uint64_t gate, uint32_t wire) { return pow2 ? ((uint64_t)wire << sh_bits) + gate : perm_encode(gate, wire, X.padded_n); };
+    for (uint64_t base = (uint64_t)blockIdx.x * kPermLadderRows; base < total; base += (uint64_t)gridDim.x * kPermLadderRows) {
+        const uint64_t g_first = first + base, rel = g_first < S.gate_base ? 0 : g_first - S.gate_base;
+        uint64_t item0, rows0;
+        if constexpr (RAGGED) {
+            item0 = S.piece_item[base / kPermLadderRows];
+            rows0 = S.row_off[item0];
+            __syncthreads();  // (a workgroup's previous piece is read out)
+            for (uint32_t e = threadIdx.x; e < kTmplWindow; e += kThreads) {
+                const uint64_t i = item0 + e < S.items ? item0 + e : S.items;
+                s_off[e] = (uint32_t)(S.row_off[i] - rows0);
+            }
+            __syncthreads();
+        } else {
+            item0 = rel / Lf;
+            rows0 = item0 * Lf;
+        }
+        const uint32_t j0 = (uint32_t)(rel - rows0), skip = (uint32_t)(g_first < S.gate_base ? S.gate_base - g_first : 0);
+        // where row x (counted from the piece's first item's first row) lies: item (from item0), row in it, shape; false past the segment
+        struct Row { uint32_t item, j, sh; uint64_t g_item; };
+        auto locate = [&](uint32_t x, Row &R) {
+            if constexpr (RAGGED) {
+                uint32_t lo = 0;  // the last entry of the window that is <= x
+#pragma unroll
+                for (uint32_t step = kTmplWindow / 2; step; step >>= 1)
+                    if (s_off[lo + step] <= x) lo += step;
+                R.item = lo;
+                R.j = x - s_off[lo];
+                R.sh = s_off[lo + 1] - s_off[lo] == Lf ? 0u : 1u;
+                R.g_item = S.gate_base + rows0 + s_off[lo];
+            } else {
+                R.item = Lf == 1 ? x : __umulhi(x, recip);   // (exact: x < 2^14, 2 <= L <= 10; ceil(2^32 / 1) does not fit)
+                R.j = x - R.item * Lf;
+                R.sh = 0;
+                R.g_item = S.gate_base + rows0 + (uint64_t)R.item * Lf;
+            }
+        };
+        // wires 0..2 of gate g that hold zero_var: the table's, and a Variable from elsewhere that is zero_var
+        auto zero_mask = [&](uint64_t g, const Row &R) {
+            uint32_t z = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 3; w++) {
+                const uint8_t code = s_wire[R.sh][R.j][w];
+                if (code == kTmplZero) z |= 1u << w;
+                else if (code >= kTmplForeign && X.C.w[w][g] == X.zero_var) z |= 1u << w;
+            }
+            return z;
+        };
+        for (uint32_t t = 2 * threadIdx.x; t < kPermLadderRows; t += 2 * kThreads) {
+            uint64_t out[4][2];
+            uint32_t keep[2] = {0, 0};  // wires whose sigma entry is written here (the others are the sparse list's)
+            bool live[2];
+            Row R[3];
+            uint32_t zm[3] = {0, 0, 0};
+#pragma unroll
+            for (uint32_t h = 0; h < 3; h++) {  // the lane's two gates and the one behind them (whose zero wires the second one's chain needs)
+                const uint64_t g = g_first + t + h;
+                const bool in = g >= S.gate_base && g < S.gate_end;
+                if (h < 2) live[h] = in;
+                R[h] = Row{0, 0, 0, 0};
+                if (in) {
+                    locate(j0 + t + h - skip, R[h]);
+                    zm[h] = zero_mask(g, R[h]);
+                }
+            }
+#pragma unroll
+            for (uint32_t h = 0; h < 2; h++) {
+                const uint64_t g = g_first + t + h;
+#pragma unroll
+                for (uint32_t w = 0; w < 4; w++) out[w][h] = 0;
+                if (!live[h]) continue;
+                const uint32_t sh = R[h].sh, j = R[h].j, zw = zm[h];
+                const uint64_t slot0 = S.sparse_base + (item0 + R[h].item) * Fmax;
+#pragma unroll
+                for (uint32_t w = 0; w < 3; w++) {
+                    const uint8_t code = s_wire[sh][j][w];
+                    if (zw >> w & 1) {  // zero_var: on to the next wire of this row that holds it (the fourth at the latest)
+                        const uint32_t later = (zw | 8u) & ~((2u << w) - 1);
+                        out[w][h] = enc(g, (uint32_t)__ffs((int)later) - 1);
+                        keep[h] |= 1u << w;
+                        if (code >= kTmplForeign && code < kTmplZero) {  // a foreign Variable that is zero_var: its slot stays a hole
+                            const uint64_t at = slot0 + s_rank[sh][j][w];
+                            if (at < Q.cap) Q.keys[at] = X.hole_key;
+                            atomicAdd(Q.count + 1, 1ull);
+                        }
+                    } else if (code < kTmplForeign) {
+                        const uint32_t sc = s_succ[sh][j][w];
+                        out[w][h] = enc(R[h].g_item + (sc >> 2), sc & 3);
+                        keep[h] |= 1u << w;
+                    } else {
+                        perm_sparse_put(X, Q, slot0 + s_rank[sh][j][w], X.C.w[w][g], g, w);
+                    }
+                }
+                if (j == 0)  // a short item uses fewer slots than it owns: the rest are holes
+                    for (uint32_t k = s_foreign[sh]; k < Fmax; k++) {
+                        if (slot0 + k < Q.cap) Q.keys[slot0 + k] = X.hole_key;
+                        atomicAdd(Q.count + 1, 1ull);
+                    }
+                // the fourth wire holds zero_var: on to the first wire of the next row that does
+                if (g + 1 < S.gate_end) out[3][h] = enc(g + 1, (uint32_t)__ffs((int)(zm[h + 1] | 8u)) - 1);
+                else out[3][h] = perm_next_zero_from(X, S.gate_end);
+                keep[h] |= 8u;
+            }
+            const uint64_t g = g_first + t;
+#pragma unroll
+            for (uint32_t w = 0; w < 4; w++) {
+                const bool k0 = live[0] && (keep[0] >> w & 1), k1 = live[1] && (keep[1] >> w & 1);
+                uint64_t *dst = sigma + enc(g, w);
+                if (wide && k0 && k1)
+                    store16(reinterpret_cast<uint4 *>(dst), make_uint4((uint32_t)out[w][0], (uint32_t)(out[w][0] >> 32), (uint32_t)out[w][1],
+                                                                      (uint32_t)(out[w][1] >> 32)));
+                else {
+                    if (k0) dst[0] = out[w][0];
+                    if (k1) dst[1] = out[w][1];
+                }
             }
         }
     }

@@ -135,6 +135,28 @@ class HostCircuit:
         self.nv += batch * V
         return tmp["result_vars"]
 
+    def small_batch(self, kind: str, a, b=None, c=None, selectors=None, chunk: int = 1 << 16):
+        """for i: gadget(a[i], b[i]) on existing Variables -- kind: select_zero / select_one / maybe_equal / is_non_zero (-> error
+        mask as well) / add / mul / rows (poly_gate and its special cases: selectors = q_m, q_l, q_r, q_o, q_c as ints)"""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        batch, res = a.shape[0], []
+        sel = None if selectors is None else synth.scalars_from_ints(list(selectors))
+        plan = po.is_non_zero_plan(a, self.table()) if kind == "is_non_zero" else None
+        _, rows, nvars = po.SMALL_KINDS[kind]
+        base, table = self.nv, self.table()
+        for lo in range(0, batch, chunk):
+            hi = min(batch, lo + chunk)
+            G = int(plan[0][hi] - plan[0][lo]) if plan else rows * (hi - lo)
+            V = int(plan[1][hi] - plan[1][lo]) if plan else nvars * (hi - lo)
+            out = self._out(G, V)
+            r = po.small_batch_fast(kind, a, b, c, table, lo, hi, var_base=base, zero_var=self.zero_var, selectors=sel, plan=plan,
+                                    threads=self.threads, out=out)
+            res.append(r["result_vars"])
+            self.n += G
+            self.nv += V
+        res = np.concatenate(res) if res else np.zeros(0, np.uint64)
+        return (res, plan[2]) if plan else res
+
     # -- the f-rows -------------------------------------------------------------------------------------------------------
     def sigma_plan(self, padded_n: int) -> po.SigmaFast:
         return po.SigmaFast(*self.wires(), padded_n=padded_n, n_vars=self.nv, threads=self.threads)

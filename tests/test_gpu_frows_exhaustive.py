@@ -420,3 +420,68 @@ def test_sigma_padded_to_2_pow_30(engine, stager):
     comp.close()
     del comp, host
     release_hbm()
+
+
+def test_small_gadgets_and_gate_batches_every_word(engine, stager):
+    """the batched appends on EXISTING Variables -- conditionally_select_zero / _one, maybe_equal, is_non_zero (with items that stop at
+    their error: ragged; and without: uniform) (/root/reference/src/scalar.rs:21-140) and the composer's add / mul / poly_gate /
+    constrain_to_constant / boolean_gate over arrays -- 2^18 items each, every batch's inputs drawn from ALL Variables that exist by
+    then (the allocated inputs, zero_var, results of the earlier batches).  Their sigma comes from the kinds' wire tables
+    (csrc/permutation.hpp, perm_template_kernel: own Variables' cycles in closed form, Variables from elsewhere through the sorted
+    list at closed-form slots); the wires, the assignments, sigma and the materialised columns, every word."""
+    from tests.frows_oracle import HostCircuit
+    release_hbm()
+    batch = 1 << 18
+    rng = np.random.default_rng(0x5A11)
+    Q = synth.Q
+    ints = [0, 0, 1, 1, 7, 7] + [int(x) for x in synth.splitmix64(batch - 6, 0xB00)]
+    scal = synth.scalars_from_ints([x % (1 << 200) for x in ints])
+    scal[100:batch:97] = 0                                   # zeros sprinkled in: is_non_zero stops there
+    comp = pg.StandardComposer(engine, 3 + 20 * batch, 5 + 18 * batch)
+    host = HostCircuit(3 + 20 * batch, 5 + 18 * batch, threads=oracle_threads())
+    first = comp.add_input_batch(dev(scal))
+    assert host.add_input_batch(scal) == first
+    tv = lambda a: torch.from_numpy(a.astype(np.int64)).to(DEV)
+    pick = lambda: rng.integers(0, host.nv, size=batch, dtype=np.uint64)
+
+    def same(dev_res, host_res):
+        assert torch.equal(dev_res, dev(host_res))
+    a = pick()
+    a[:4] = [first, 0, first + 1, first + 100]               # value 0 four times, once zero_var itself
+    err, nerr = comp.is_non_zero_batch(tv(a))
+    _, oerr = host.small_batch("is_non_zero", a)
+    assert nerr == int(oerr.sum()) > batch // 200 and torch.equal(err, torch.from_numpy(oerr).to(DEV))
+    nz = np.flatnonzero(host.table()[:first + batch].any(axis=1)).astype(np.uint64)   # Variables whose value is not 0: no item fails
+    a = nz[rng.integers(0, len(nz), size=batch)]
+    err, nerr = comp.is_non_zero_batch(tv(a))
+    _, oerr = host.small_batch("is_non_zero", a)
+    assert nerr == 0 and not oerr.any()
+    a, b = pick(), pick()
+    a[:2], b[:2] = [0, first + 2], [first + 3, 0]
+    same(comp.conditionally_select_zero_batch(tv(a), tv(b)), host.small_batch("select_zero", a, b))
+    a, b = pick(), pick()
+    same(comp.conditionally_select_one_batch(tv(a), tv(b)), host.small_batch("select_one", a, b))
+    a, b = pick(), pick()
+    a[:3], b[:3] = [first + 4, first, 0], [first + 5, first + 1, 0]        # equal assignments on different Variables; zero_var twice
+    b[1000:2000] = a[1000:2000]                                               # the same Variable on both inputs
+    same(comp.maybe_equal_batch(tv(a), tv(b)), host.small_batch("maybe_equal", a, b))
+    q = [int(x) % Q for x in synth.splitmix64(5, 0xC0FFEE)]
+    a, b = pick(), pick()
+    same(comp.add_batch(S(q[1]), tv(a), S(q[2]), tv(b), S(q[4])), host.small_batch("add", a, b, selectors=(0, q[1], q[2], Q - 1, q[4])))
+    a, b = pick(), pick()
+    same(comp.mul_batch(S(q[0]), tv(a), tv(b), S(q[4])), host.small_batch("mul", a, b, selectors=(q[0], 0, 0, Q - 1, q[4])))
+    a, b, c3 = pick(), pick(), pick()
+    comp.poly_gate_batch(tv(a), tv(b), tv(c3), *[S(x) for x in q])
+    host.small_batch("rows", a, b, c3, selectors=q)
+    a = pick()
+    comp.constrain_to_constant_batch(tv(a), S(7))
+    host.small_batch("rows", a, a, a, selectors=(0, 1, 0, 0, Q - 7))
+    a = pick()
+    comp.boolean_gate_batch(tv(a))
+    host.small_batch("rows", a, a, a, selectors=(1, 0, 0, Q - 1, 0))
+    n = comp.circuit_size()
+    assert n == host.n > 17 * batch
+    check_f_rows(stager, comp, host, sigma_chunk=1 << 21, mat_chunk=1 << 19, flip_rows=(3, n // 2, n - 1, 3 + 3 * batch // 2))
+    comp.close()
+    del comp, host
+    release_hbm()

@@ -269,3 +269,75 @@ def test_host_circuit_equals_faithful_composer(shape):
     assert np.array_equal(sf.whole(1 << 10), ora.sigma(padded))
     sf.close()
     _check_f_rows_fast(ora, chunkings=((500, 3),))
+
+
+def test_small_batch_fast_equals_faithful():
+    """oracle_small_batch_fast (the scalar gadgets and the gate calls over arrays of existing Variables, threaded) == the same
+    calls one by one on oracle/composer.c + oracle/gadgets.c (src/scalar.rs:21-140): every kind, all nine arrays; inputs that are
+    zero, equal, zero_var itself, results of earlier batches as inputs of later ones, is_non_zero items that stop at their error"""
+    import random
+    from tests.frows_oracle import HostCircuit
+    rng = random.Random(12)
+    Q = synth.Q
+    ora = po.Composer()
+    L, F = ora.L, lambda x: po.fr(synth.mont(x))
+    host = HostCircuit(20_000, 20_000, threads=3)
+    vals = [0, 0, 1, 1, 5, 5, Q - 1] + [rng.randrange(Q) for _ in range(40)]
+    scal = synth.scalars_from_ints(vals)
+    first = host.add_input_batch(scal)
+    assert first == int(ora.allocate(scal[0]).var)
+    for x in scal[1:]:
+        ora.allocate(x)
+    pick = lambda k: np.array([rng.randrange(ora.num_vars) for _ in range(k)], dtype=np.uint64)
+    value = lambda v: L.composer_value(ora.c, int(v))
+    full_checks = []
+
+    def both(kind, faithful, a, b=None, c=None, selectors=None, chunk=7):
+        """the batch on the host circuit (wires and assignments, chunked) and call by call on composer.c; the same batch once more with
+        all nine arrays, compared with composer.c's rows at the end"""
+        g0, v0, table = host.n, host.nv, host.table().copy()
+        sel = None if selectors is None else synth.scalars_from_ints(list(selectors))
+        plan = po.is_non_zero_plan(a, table) if kind == "is_non_zero" else None
+        full = po.small_batch_fast(kind, a, b, c, table, 0, len(a), var_base=v0, zero_var=0, selectors=sel, plan=plan, threads=2)
+        res = host.small_batch(kind, a, b, c, selectors=selectors, chunk=chunk)
+        exp = [faithful(*[int(x[i]) for x in (a, b, c) if x is not None]) for i in range(len(a))]
+        full_checks.append((g0, v0, full))
+        return res, exp
+
+    for rnd in range(2):   # (the second round's inputs include the first round's results)
+        a, b = pick(37), pick(37)
+        a[:3], b[:3] = [0, first, first + 2], [first + 1, 0, first + 3]
+        res, exp = both("select_zero", lambda x, y: int(L.conditionally_select_zero(ora.c, x, y)), a, b)
+        assert list(res) == exp
+        res, exp = both("select_one", lambda x, y: int(L.conditionally_select_one(ora.c, x, y)), pick(29), pick(29), chunk=11)
+        assert list(res) == exp
+        a, b = pick(33), pick(33)
+        a[:4], b[:4] = [first + 4, first, first + 2, 0], [first + 5, first + 1, first + 6, 0]   # equal pairs, a zero difference of zeros
+        res, exp = both("maybe_equal", lambda x, y: int(L.maybe_equal(ora.c, po.AllocatedScalar(x, value(x)), po.AllocatedScalar(y, value(y)))), a, b)
+        assert list(res) == exp
+        a = pick(41)
+        a[:3] = [first, 0, first + 1]                                  # values 0 (once: zero_var itself) -> Err after one row
+        (res, err), exp = both("is_non_zero", lambda x: int(L.is_non_zero(ora.c, x, value(x))), a, chunk=9)
+        assert list(err) == exp and err[:3].all() and not err.all()
+        q = [rng.randrange(Q) for _ in range(5)]
+        res, exp = both("add", lambda x, y: int(L.composer_add(ora.c, F(q[1]), x, F(q[2]), y, F(q[4]), None)), pick(25), pick(25),
+                        selectors=(0, q[1], q[2], Q - 1, q[4]), chunk=8)
+        assert list(res) == exp
+        res, exp = both("mul", lambda x, y: int(L.composer_mul(ora.c, F(q[0]), x, y, F(q[4]), None)), pick(25), pick(25),
+                        selectors=(q[0], 0, 0, Q - 1, q[4]), chunk=8)
+        assert list(res) == exp
+        both("rows", lambda x, y, z: L.composer_poly_gate(ora.c, x, y, z, *[F(v) for v in q], None), pick(19), pick(19), pick(19), selectors=q, chunk=6)
+        a = pick(13)
+        both("rows", lambda x, y, z: L.composer_boolean_gate(ora.c, x), a, a, a, selectors=(1, 0, 0, Q - 1, 0))   # boolean_gate over an array
+    _same_circuit(host, ora)
+    exp = ora.export()
+    for g0, v0, full in full_checks:
+        G, V = full["n_gates"], full["n_vars"]
+        for k in COLS[:8]:
+            assert np.array_equal(full[k], exp[k][g0:g0 + G]), (k, g0)
+        assert np.array_equal(full["var_values"], exp["var_values"][v0:v0 + V]), g0
+    n = host.n
+    padded = 1 << (n - 1).bit_length()
+    sf = host.sigma_plan(padded)
+    assert np.array_equal(sf.whole(1 << 9), ora.sigma(padded))
+    sf.close()
