@@ -667,7 +667,7 @@ struct SegTemplate {
 #define PG_TF2 0xF2
 #define PG_TZ 0xFE
 #define PG_TX PG_T3(0xFF, 0xFF, 0xFF)
-__device__ const SegTemplate g_seg_templates[WIRES_KINDS - WIRES_MIX] = {
+constexpr SegTemplate kSegTemplates[WIRES_KINDS - WIRES_MIX] = {
     // WIRES_MIX: [v y s a b | va inv one | one' sy oms out | u z yeq] (ScalarMixGD::row); short: [v y s a b | va | one' sy oms out | u z yeq]
     {{10, 8}, {15, 13},
      {{PG_T3(0, 5, PG_TZ), PG_T3(7, 7, 7), PG_T3(0, 6, 7), PG_T3(8, 8, 8), PG_T3(1, 2, 9), PG_T3(8, 2, 10), PG_T3(9, 10, 11), PG_T3(3, 4, 12),
@@ -700,49 +700,61 @@ __host__ __device__ inline uint32_t template_foreign_per_item(uint32_t kind) {
 }
 __host__ __device__ inline bool is_template_kind(uint32_t kind) { return kind >= WIRES_MIX && kind < WIRES_KINDS; }
 
+// What the kernels take: the table and what follows from it, one 64-bit word per (shape, row) -- 16 bits per wire:
+//   bits 0-1  type   0 none, 1 an own Variable, 2 a Variable from elsewhere, 3 zero_var
+//   bits 2-5  own    the Variable's offset from the item's first                                (type 1)
+//   bits 6-11 succ   the next position of that Variable in its item, 4 * row + wire             (type 1)
+//   bits 12-13 rank  of this position among the item's foreign positions, in recording order    (type 2)
+// derived on the host (template_rows), passed by value, copied to LDS by the workgroup.
+struct TemplateRows {
+    uint64_t row[2][kTmplRows];
+    uint8_t L[2], V[2], F[2];  // rows, Variables, foreign positions of a full / a short item
+    uint8_t Fmax, pad;
+};
+inline TemplateRows template_rows(uint32_t kind) {
+    const SegTemplate &T = kSegTemplates[kind - WIRES_MIX];
+    TemplateRows R{};
+    for (uint32_t sh = 0; sh < 2; sh++) {
+        R.L[sh] = T.L[sh];
+        R.V[sh] = T.V[sh];
+        uint32_t foreign = 0;
+        const uint32_t n = (uint32_t)T.L[sh] * 3;
+        for (uint32_t p = 0; p < n; p++) {
+            const uint8_t code = T.wire[sh][p / 3][p % 3];
+            uint64_t b = 0;
+            if (code < kTmplForeign) {  // an own Variable: the next entry that names it, or -- from the last -- the first
+                uint32_t first = 0xff, next = 0xff;
+                for (uint32_t q = 0; q < n; q++)
+                    if (T.wire[sh][q / 3][q % 3] == code) {
+                        if (first == 0xff) first = q;
+                        if (q > p && next == 0xff) next = q;
+                    }
+                const uint32_t z = next != 0xff ? next : first;
+                b = 1u | (uint64_t)code << 2 | (uint64_t)(4 * (z / 3) + z % 3) << 6;
+            } else if (code < kTmplZero) {
+                b = 2u | (uint64_t)foreign++ << 12;
+            } else if (code == kTmplZero) {
+                b = 3u;
+            }
+            R.row[sh][p / 3] |= b << (16 * (p % 3));
+        }
+        R.F[sh] = (uint8_t)foreign;
+    }
+    R.Fmax = (uint8_t)template_foreign_per_item(kind);
+    return R;
+}
+
 constexpr uint32_t kTmplWindow = 1024;  // ragged: prefix sums per piece (a piece of 512 rows holds at most 513 items; a power of two)
 template <bool RAGGED>
-__global__ __launch_bounds__(kThreads) void perm_template_kernel(const PermCtx X, const PermSeg S, const PermSparse Q, uint64_t *sigma) {
+__global__ __launch_bounds__(kThreads) void perm_template_kernel(const PermCtx X, const PermSeg S, const TemplateRows T, const PermSparse Q,
+                                                                uint64_t *sigma) {
     extern __shared__ uint4 perm_template_pad[];
-    __shared__ uint8_t s_wire[2][kTmplRows][4], s_succ[2][kTmplRows][4], s_rank[2][kTmplRows][4];
-    __shared__ uint32_t s_foreign[2];                           // foreign positions of a full / short item
+    __shared__ uint64_t s_row[2][kTmplRows];
     __shared__ uint32_t s_off[RAGGED ? kTmplWindow : 1];        // RAGGED: rows before items item0 .. of the piece, from item0's first
-    static_assert(kPermLadderRows + 2 <= kTmplWindow, "a piece's items fit the window of prefix sums");
+    static_assert(kPermLadderRows + 3 <= kTmplWindow, "a piece's items fit the window of prefix sums");
     if (X.padded_n == 1) perm_template_pad[threadIdx.x] = make_uint4(0, 0, 0, 0);  // (keeps the allocation)
-    const SegTemplate &T = g_seg_templates[S.wire_kind - WIRES_MIX];
-    const uint32_t Lf = T.L[0], Ls = T.L[1], Fmax = template_foreign_per_item(S.wire_kind);
-    // ---- the table, and what follows from it: successors of own Variables' positions, ranks of the foreign ones ----
-    if (threadIdx.x < 2 * kTmplRows * 3) {
-        const uint32_t sh = threadIdx.x / (kTmplRows * 3), p = threadIdx.x % (kTmplRows * 3), row = p / 3, w = p % 3, rows = T.L[sh];
-        const uint8_t code = row < rows ? T.wire[sh][row][w] : kTmplNone;
-        s_wire[sh][row][w] = code;
-        uint32_t succ = 4 * row + w, rank = 0;
-        if (code < kTmplForeign) {  // an own Variable: the next entry that names it, or -- from the last -- the first
-            uint32_t first = 0xff, next = 0xff;
-            for (uint32_t q = 0; q < rows * 3; q++)
-                if (T.wire[sh][q / 3][q % 3] == code) {
-                    if (first == 0xff) first = q;
-                    if (q > p && next == 0xff) next = q;
-                }
-            const uint32_t z = next != 0xff ? next : first;
-            succ = 4 * (z / 3) + z % 3;
-        } else if (code < kTmplZero) {  // foreign: its rank among the item's foreign positions, in recording order
-            for (uint32_t q = 0; q < p; q++) {
-                const uint8_t c2 = T.wire[sh][q / 3][q % 3];
-                rank += c2 >= kTmplForeign && c2 < kTmplZero ? 1u : 0u;
-            }
-        }
-        s_succ[sh][row][w] = (uint8_t)succ;
-        s_rank[sh][row][w] = (uint8_t)rank;
-    }
-    if (threadIdx.x < 2) {
-        uint32_t f = 0;
-        for (uint32_t q = 0; q < (uint32_t)T.L[threadIdx.x] * 3; q++) {
-            const uint8_t c2 = T.wire[threadIdx.x][q / 3][q % 3];
-            f += c2 >= kTmplForeign && c2 < kTmplZero ? 1u : 0u;
-        }
-        s_foreign[threadIdx.x] = f;
-    }
+    const uint32_t Lf = T.L[0], Ls = T.L[1], Fmax = T.Fmax, Ff = T.F[0], Fs = T.F[1];
+    if (threadIdx.x < 2 * kTmplRows) s_row[threadIdx.x / kTmplRows][threadIdx.x % kTmplRows] = T.row[threadIdx.x / kTmplRows][threadIdx.x % kTmplRows];
     __syncthreads();
     const uint64_t first = S.gate_base & ~1ull, total = S.gate_end - first;  // (rows counted from the even gate at or before the segment's first)
     const bool wide = (reinterpret_cast<uintptr_t>(sigma) & 15) == 0 && !(X.padded_n & 1);
@@ -767,9 +779,9 @@ __global__ __launch_bounds__(kThreads) void perm_template_kernel(const PermCtx X
             rows0 = item0 * Lf;
         }
         const uint32_t j0 = (uint32_t)(rel - rows0), skip = (uint32_t)(g_first < S.gate_base ? S.gate_base - g_first : 0);
-        // where row x (counted from the piece's first item's first row) lies: item (from item0), row in it, shape; false past the segment
-        struct Row { uint32_t item, j, sh; uint64_t g_item; };
-        auto locate = [&](uint32_t x, Row &R) {
+        // a row of the piece: its item (counted from item0), its place in the item, the item's shape and first gate, the table's word
+        struct Row { uint32_t item, j, sh, rows; uint64_t g_item, word; };
+        auto locate = [&](uint32_t x, Row &R) {  // x: rows from the piece's first item's first row
             if constexpr (RAGGED) {
                 uint32_t lo = 0;  // the last entry of the window that is <= x
 #pragma unroll
@@ -777,42 +789,60 @@ __global__ __launch_bounds__(kThreads) void perm_template_kernel(const PermCtx X
                     if (s_off[lo + step] <= x) lo += step;
                 R.item = lo;
                 R.j = x - s_off[lo];
-                R.sh = s_off[lo + 1] - s_off[lo] == Lf ? 0u : 1u;
+                R.rows = s_off[lo + 1] - s_off[lo];
+                R.sh = R.rows == Lf ? 0u : 1u;
                 R.g_item = S.gate_base + rows0 + s_off[lo];
             } else {
                 R.item = Lf == 1 ? x : __umulhi(x, recip);   // (exact: x < 2^14, 2 <= L <= 10; ceil(2^32 / 1) does not fit)
                 R.j = x - R.item * Lf;
                 R.sh = 0;
+                R.rows = Lf;
                 R.g_item = S.gate_base + rows0 + (uint64_t)R.item * Lf;
             }
+            R.word = s_row[R.sh][R.j];
+        };
+        auto step = [&](Row &R) {  // the row behind R
+            if (R.j + 1 < R.rows) R.j++;
+            else {
+                R.g_item += R.rows;
+                R.item++;
+                R.j = 0;
+                if constexpr (RAGGED) {
+                    R.rows = s_off[R.item + 1] - s_off[R.item];
+                    R.sh = R.rows == Lf ? 0u : 1u;
+                }
+            }
+            R.word = s_row[R.sh][R.j];
         };
         // wires 0..2 of gate g that hold zero_var: the table's, and a Variable from elsewhere that is zero_var
-        auto zero_mask = [&](uint64_t g, const Row &R) {
+        auto zero_mask = [&](uint64_t g, uint64_t word) {
             uint32_t z = 0;
 #pragma unroll
             for (uint32_t w = 0; w < 3; w++) {
-                const uint8_t code = s_wire[R.sh][R.j][w];
-                if (code == kTmplZero) z |= 1u << w;
-                else if (code >= kTmplForeign && X.C.w[w][g] == X.zero_var) z |= 1u << w;
+                const uint32_t type = (uint32_t)(word >> (16 * w)) & 3u;
+                if (type == 3u) z |= 1u << w;
+                else if (type == 2u && X.C.w[w][g] == X.zero_var) z |= 1u << w;
             }
             return z;
         };
         for (uint32_t t = 2 * threadIdx.x; t < kPermLadderRows; t += 2 * kThreads) {
             uint64_t out[4][2];
             uint32_t keep[2] = {0, 0};  // wires whose sigma entry is written here (the others are the sparse list's)
-            bool live[2];
-            Row R[3];
+            bool live[3];
+            Row R[3];                   // the lane's two gates and the one behind them (whose zero wires the second one's chain needs)
             uint32_t zm[3] = {0, 0, 0};
 #pragma unroll
-            for (uint32_t h = 0; h < 3; h++) {  // the lane's two gates and the one behind them (whose zero wires the second one's chain needs)
+            for (uint32_t h = 0; h < 3; h++) {
                 const uint64_t g = g_first + t + h;
-                const bool in = g >= S.gate_base && g < S.gate_end;
-                if (h < 2) live[h] = in;
-                R[h] = Row{0, 0, 0, 0};
-                if (in) {
-                    locate(j0 + t + h - skip, R[h]);
-                    zm[h] = zero_mask(g, R[h]);
+                live[h] = g >= S.gate_base && g < S.gate_end;
+                if (h == 0 || !live[h - 1]) {
+                    R[h] = Row{0, 0, 0, 1, 0, 0};
+                    if (live[h]) locate(j0 + t + h - skip, R[h]);
+                } else {
+                    R[h] = R[h - 1];
+                    if (live[h]) step(R[h]);
                 }
+                if (live[h]) zm[h] = zero_mask(g, R[h].word);
             }
 #pragma unroll
             for (uint32_t h = 0; h < 2; h++) {
@@ -820,30 +850,30 @@ __global__ __launch_bounds__(kThreads) void perm_template_kernel(const PermCtx X
 #pragma unroll
                 for (uint32_t w = 0; w < 4; w++) out[w][h] = 0;
                 if (!live[h]) continue;
-                const uint32_t sh = R[h].sh, j = R[h].j, zw = zm[h];
+                const uint32_t zw = zm[h];
                 const uint64_t slot0 = S.sparse_base + (item0 + R[h].item) * Fmax;
 #pragma unroll
                 for (uint32_t w = 0; w < 3; w++) {
-                    const uint8_t code = s_wire[sh][j][w];
+                    const uint32_t b = (uint32_t)(R[h].word >> (16 * w)) & 0xffffu, type = b & 3u;
                     if (zw >> w & 1) {  // zero_var: on to the next wire of this row that holds it (the fourth at the latest)
                         const uint32_t later = (zw | 8u) & ~((2u << w) - 1);
                         out[w][h] = enc(g, (uint32_t)__ffs((int)later) - 1);
                         keep[h] |= 1u << w;
-                        if (code >= kTmplForeign && code < kTmplZero) {  // a foreign Variable that is zero_var: its slot stays a hole
-                            const uint64_t at = slot0 + s_rank[sh][j][w];
+                        if (type == 2u) {  // a Variable from elsewhere that is zero_var: its slot stays a hole
+                            const uint64_t at = slot0 + (b >> 12 & 3u);
                             if (at < Q.cap) Q.keys[at] = X.hole_key;
                             atomicAdd(Q.count + 1, 1ull);
                         }
-                    } else if (code < kTmplForeign) {
-                        const uint32_t sc = s_succ[sh][j][w];
+                    } else if (type == 1u) {
+                        const uint32_t sc = b >> 6 & 63u;
                         out[w][h] = enc(R[h].g_item + (sc >> 2), sc & 3);
                         keep[h] |= 1u << w;
-                    } else {
-                        perm_sparse_put(X, Q, slot0 + s_rank[sh][j][w], X.C.w[w][g], g, w);
+                    } else if (type == 2u) {
+                        perm_sparse_put(X, Q, slot0 + (b >> 12 & 3u), X.C.w[w][g], g, w);
                     }
                 }
-                if (j == 0)  // a short item uses fewer slots than it owns: the rest are holes
-                    for (uint32_t k = s_foreign[sh]; k < Fmax; k++) {
+                if (R[h].j == 0)  // a short item uses fewer slots than it owns: the rest are holes
+                    for (uint32_t k = R[h].sh ? Fs : Ff; k < Fmax; k++) {
                         if (slot0 + k < Q.cap) Q.keys[slot0 + k] = X.hole_key;
                         atomicAdd(Q.count + 1, 1ull);
                     }
@@ -867,6 +897,7 @@ __global__ __launch_bounds__(kThreads) void perm_template_kernel(const PermCtx X
             }
         }
     }
+    (void)Ls;
 }
 
 // the sorted sparse list: neighbours with one Variable are consecutive positions of it; the last one wraps to the
