@@ -63,6 +63,8 @@ def parse(argv=None):
     ap.add_argument("--allgather-log2-chunk", type=int, default=12, help="N>1: witnesses per rank per gathered chunk")
     ap.add_argument("--allgather-timeout", type=float, default=240.0, help="N>1: seconds before the gather-inclusive sample is abandoned")
     ap.add_argument("--allgather-chunks", type=int, default=8, help="N>1: chunks in the gather-inclusive sample (0: skip)")
+    ap.add_argument("--n1-value", type=float, default=0.0, help="N>1: the N = 1 run's `value` (constraints/s), for the two efficiency figures "
+                                                                 "of the line (absent: this run's own rank-0 rate stands in for it)")
     return ap.parse_args(argv)
 
 
@@ -513,20 +515,14 @@ def roofline_with_fill(wl: Workload, kernel_ms):
     return r
 
 
-def next_rows_secondary(eng, dev, log2_batch: int, steps: int):
-    """SURVEY 8f rows on a composer holding 2^log2_batch x range_check(0, 2^254): f1 pg_composer_materialize (per row 328 B
-    written -- seven constant columns, w_4, three wire-value columns -- and 32 B read per Variable, each once) and f2 pg_composer_permutation (24 B of wire indices read per row, four sigma columns of 8 B written per PADDED
-    row).  Both calls are synchronous; outputs are allocated once, ahead of the timed calls."""
+def f_rows_of(comp, dev, steps: int, note: dict):
+    """pg_composer_materialize (per row 328 B written -- seven constant columns, w_4, three wire-value columns -- and 32 B read per
+    Variable, each once) and pg_composer_permutation (four sigma columns of 8 B written per PADDED row) on a filled composer: median / min /
+    max of a few synchronous calls, outputs allocated once ahead of them, rows/s and the HBM roofline of each"""
     import ctypes as C
-    import numpy as np
     import torch
-    import plonk_gadgets_amd as pg
-    from plonk_gadgets_amd import _lib, synth
+    from plonk_gadgets_amd import _lib
     lib = _lib.load()
-    batch = 1 << log2_batch
-    comp = pg.StandardComposer(eng, 3 + batch * 1031 + 8, 5 + batch * 1034 + 8)
-    wit = torch.from_numpy(synth.random_scalars(batch, seed=synth.SEED + 2).view(np.int64)).to(dev)
-    comp.range_check_batch(pg.BlsScalar.from_int(0), pg.BlsScalar.from_int(2**254), wit)
     n = comp.circuit_size()
     padded = 1 << (n - 1).bit_length()
     names = ("q_4", "q_arith", "q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add", "w_4_value", "w_l_value",
@@ -548,31 +544,80 @@ def next_rows_secondary(eng, dev, log2_batch: int, steps: int):
         ms.sort()
         return ms[len(ms) // 2], ms[0], ms[-1]
 
-    out = {"config": {"workload": "composer of 2^%d x (allocate + range_check(0, 2^254)): %d rows, sigma padded to %d" % (log2_batch, n, padded)}}
+    out = {"rows": n, "sigma_padded_to": padded}
     med, lo, hi = timed(lambda: lib.pg_composer_materialize(comp._h, C.byref(fc)))
     # algorithmic bytes: 328 B written per row; read: every assignment ONCE (32 B per Variable -- the rows of a batched call take their
-    # item's Variables from an LDS window read linearly, and the ladder gadgets' wires are computed, not read back: csrc/materialize.hpp).
-    # (Rounds 1-4 counted the gather's 24 B of indices + 96 B of assignments per row as "read": 120 B per row, most of it cache hits.)
+    # item's Variables from an LDS window read linearly, and the wires of the closed-form kinds are computed, not read back: csrc/materialize.hpp).
     wr, rd = 328 * n, 32 * comp.num_variables()
     out["materialize"] = {"ms": {"min": lo, "median": med, "max": hi}, "rows_per_s": n / (med / 1e3),
                           "roofline": {"bound": "hbm", "achieved": (wr + rd) / (med / 1e3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                        "frac": (wr + rd) / (med / 1e3) / 1e9 / HBM_PEAK_GBPS,
                                        "algorithmic_bytes": {"written": wr, "read": rd},
                                        "frac_counting_writes_only": wr / (med / 1e3) / 1e9 / HBM_PEAK_GBPS,
-                                       "kernel": "pg::materialize_items_kernel<MAT_SELF, WIRES_RANGE_CHECK> (one launch per batched call: constant columns, "
-                                                 "w_4, three wire-value columns from an LDS window of the items' Variables that a wave of its own "
-                                                 "fetches ahead, wires in closed form)"}}
+                                       "kernel": note["materialize"]}}
     med, lo, hi = timed(lambda: lib.pg_composer_permutation(comp._h, padded, sigma.data_ptr()))
-    # algorithmic bytes: four sigma columns of 8 B per PADDED row written; the rows of a ladder gadget are linked in closed form (nothing
-    # read: csrc/permutation.hpp, perm_ladder_kernel).  (Rounds 1-4 read the 24 B of wire indices per row and counted them.)
+    # algorithmic bytes: four sigma columns of 8 B per PADDED row written; the rows of the batched appends are linked in closed form
+    # (nothing read: csrc/permutation.hpp, perm_ladder_kernel / perm_template_kernel)
     pb = 32 * padded
     out["permutation"] = {"ms": {"min": lo, "median": med, "max": hi}, "rows_per_s": n / (med / 1e3),
                           "roofline": {"bound": "hbm", "achieved": pb / (med / 1e3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                        "frac": pb / (med / 1e3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": pb,
-                                       "frac_with_the_wire_reads_of_rounds_1_to_4": (pb + 24 * n) / (med / 1e3) / 1e9 / HBM_PEAK_GBPS,
-                                       "kernel": "pg::perm_ladder_kernel (sigma of the ladder gadgets' rows in closed form) + perm_identity_kernel "
-                                                 "(the padding) (+ perm_gap_kernel and the sparse list's sort for the rows of single calls)"}}
-    del comp, t, sigma
+                                       "kernel": note["permutation"]}}
+    del t, sigma
+    torch.cuda.empty_cache()
+    return out
+
+
+def next_rows_secondary(eng, dev, log2_batch: int, steps: int):
+    """f1 pg_composer_materialize and f2 pg_composer_permutation on three composers -- C2-shaped (2^log2_batch x
+    range_check(0, 2^254)), C4-shaped (twice as many max_bound items with a 253-bit bound of their own: about the same number of rows)
+    and C3-shaped (2^(log2_batch + 4) fused scalar items) -- each filled by ONE batched append, as tests/test_gpu_frows_exhaustive.py
+    verifies them word for word; then the same two calls on a circuit built one call at a time (single_calls)."""
+    import numpy as np
+    import torch
+    import plonk_gadgets_amd as pg
+    from plonk_gadgets_amd import synth
+    batch = 1 << log2_batch
+
+    def to_dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
+    comp = pg.StandardComposer(eng, 3 + batch * 1031 + 8, 5 + batch * 1034 + 8)
+    comp.range_check_batch(pg.BlsScalar.from_int(0), pg.BlsScalar.from_int(2**254), to_dev(synth.random_scalars(batch, seed=synth.SEED + 2)))
+    out = f_rows_of(comp, dev, steps, {
+        "materialize": "pg::materialize_items_kernel<MAT_SELF, WIRES_RANGE_CHECK> (one launch per batched call: constant columns, w_4, three "
+                       "wire-value columns from an LDS window of the items' Variables that a wave of its own fetches ahead, wires in closed form)",
+        "permutation": "pg::perm_ladder_kernel<false> (sigma of the ladder gadgets' rows in closed form) + perm_identity_kernel (the padding)"})
+    out["config"] = {"workload": "composer of 2^%d x (allocate + range_check(0, 2^254)): %d rows, sigma padded to %d" % (log2_batch, out["rows"], out["sigma_padded_to"])}
+    comp.close()
+    del comp
+    torch.cuda.empty_cache()
+    try:  # C4's shape: per-item public bounds -- rows and Variables by the call's prefix sums
+        mr, wt = c4_inputs(2 * batch, seed=0xC4 + 9)
+        comp = pg.StandardComposer(eng, 3 + 2 * batch * 515 + 8, 5 + 2 * batch * 517 + 8)
+        comp.max_bound_ragged_batch(to_dev(mr), to_dev(wt))
+        r = f_rows_of(comp, dev, steps, {
+            "materialize": "pg::materialize_items_kernel<MAT_SELF, WIRES_MAX_BOUND, true> (ladder lengths from the call's prefix sums, through the loader wave)",
+            "permutation": "pg::perm_ladder_kernel<true> (an item's ladder length and place from a window of the call's prefix sums) + perm_identity_kernel"})
+        r["config"] = {"workload": "composer of 2^%d x (allocate + max_bound(a 253-bit bound per item)): %d rows, sigma padded to %d" % (log2_batch + 1, r["rows"], r["sigma_padded_to"])}
+        out["c4_shaped"] = r
+        comp.close()
+        del comp
+    except Exception as ex:  # (a side figure)
+        out["c4_shaped"] = {"error": repr(ex)}
+    torch.cuda.empty_cache()
+    try:  # C3's shape: ten rows and fifteen Variables per item
+        nmix = 16 * batch
+        comp = pg.StandardComposer(eng, 3 + nmix * 10 + 8, 5 + nmix * 15 + 8)
+        comp.scalar_mix_batch(*[to_dev(x) for x in mix_inputs(nmix, seed=0xC3 + 9)])
+        r = f_rows_of(comp, dev, steps, {
+            "materialize": "pg::materialize_items_kernel<MAT_SELF, WIRES_MIX> (the item's wires from a 30-entry table)",
+            "permutation": "pg::perm_template_kernel<false> (own Variables' cycles from the kind's wire table) + perm_identity_kernel"})
+        r["config"] = {"workload": "composer of 2^%d fused scalar items (C3's item): %d rows, sigma padded to %d" % (log2_batch + 4, r["rows"], r["sigma_padded_to"])}
+        out["c3_shaped"] = r
+        comp.close()
+        del comp
+    except Exception as ex:
+        out["c3_shaped"] = {"error": repr(ex)}
     torch.cuda.empty_cache()
     try:  # the same two calls on a circuit built the reference's way: ONE allocate + range_check at a time (tests/range_gadgets_tests.rs:29-44)
         out["single_calls"] = next_rows_of_single_calls(eng, dev, 4096)
@@ -773,6 +818,7 @@ def main():
     # ---- headline ------------------------------------------------------------------------------------------
     wl = Workload(args.workload, eng, dev, rank, world, args.log2_batch, args.log2_chunk)
     elapsed, kernel_ms = measure(wl, args.steps, args.warmup, sync_all)
+    own_elapsed = elapsed  # (this rank's own K steps: at N > 1 rank 0's stands in for an N = 1 run that was not given)
     elapsed = max_over_ranks(elapsed)
     if os.environ.get("PG_BENCH_VERBOSE") and rank == 0:
         print("launch ms:", " ".join("%.2f" % t for t in kernel_ms), file=sys.stderr)
@@ -939,6 +985,19 @@ def main():
         final = dict(line)
         if allgather:
             final["allgather"] = allgather
+        if world > 1:
+            # SURVEY 8(e) asks for both curves: generation only (no data-path collective: by construction close to 1) and the
+            # gather-inclusive one (bound by xGMI's ingest, the figure that matters).  Each against N x the N = 1 value: the one given
+            # with --n1-value (the driver's N = 1 run of this same command), else this run's own rank-0 rate
+            n1 = args.n1_value if args.n1_value > 0 else wl.rows_per_launch * wl.n_chunks * args.steps / own_elapsed
+            final["n1_value"] = {"value": n1, "source": "--n1-value" if args.n1_value > 0 else "this run: rank 0's own steps, not the maximum over ranks"}
+            final["efficiency_generation"] = value / (world * n1)
+            if allgather and "value" in allgather:
+                final["efficiency_gather_inclusive"] = allgather["value"] / (world * n1)
+                if isinstance(allgather.get("variables_only"), dict) and "value" in allgather["variables_only"]:
+                    final["efficiency_gather_inclusive_variables_only"] = allgather["variables_only"]["value"] / (world * n1)
+            else:
+                final["efficiency_gather_inclusive"] = None
         if world == 1 and not args.no_cpu:
             final["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample)
         emit_once(final)

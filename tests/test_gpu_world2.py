@@ -142,7 +142,7 @@ def test_bench_five_ranks_rehearsal_with_the_gather_leg():
     ranks' rows regenerated) -- with the watchdog armed and cancelled."""
     world, lg = 5, 8
     p, lines = _run_bench(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--log2-batch", str(lg), "--no-cpu", "--allgather-log2-chunk", "5",
-                           "--allgather-chunks", "3", "--allgather-timeout", "240"], {"FAKE_RCCL_PIECE_BYTES": str(1 << 20)})
+                           "--allgather-chunks", "3", "--allgather-timeout", "240", "--n1-value", "1e9"], {"FAKE_RCCL_PIECE_BYTES": str(1 << 20)})
     assert p.returncode == 0, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
     assert len(lines) == 1, p.stdout
     line = lines[0]
@@ -157,6 +157,11 @@ def test_bench_five_ranks_rehearsal_with_the_gather_leg():
     b = line["hbm_budget"]
     assert b["ranks_sharing_the_card"] == world and b["gather_pipeline_bytes"] == 2 * (world + 1) * 32 * 222_792
     assert "rank budget" in p.stderr
+    # both curves SURVEY 8(e) asks for, each against N x the N = 1 value the run was given
+    assert line["n1_value"] == {"value": 1e9, "source": "--n1-value"}
+    assert abs(line["efficiency_generation"] - line["value"] / (world * 1e9)) < 1e-12
+    assert abs(line["efficiency_gather_inclusive"] - ag["value"] / (world * 1e9)) < 1e-12
+    assert abs(line["efficiency_gather_inclusive_variables_only"] - vo["value"] / (world * 1e9)) < 1e-12
 
 
 def test_bench_watchdog_abandons_a_gather_that_hangs():
