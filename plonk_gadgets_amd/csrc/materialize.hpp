@@ -57,10 +57,13 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
     __shared__ uint4 s_win[2][2 * kMatWindowVars];
     __shared__ uint4 s_tail[2][MODE == MAT_SELF ? kMatTailRows * 6 : 1];
     __shared__ uint4 s_wit[2][MODE == MAT_SELF ? kMatWitItems * 2 : 1];  // the items' witnesses, when they are Variables from elsewhere
-    constexpr uint32_t kOff = kMatWitItems + 1;                            // RAGGED: rows before item k of the group, k = 0 .. items,
-    __shared__ uint32_t s_off[2][RAGGED ? 2 * kOff : 1];                   // then Variables before it
+    // RAGGED: rows before item k of the group, k = 0 .. items, then Variables before it (max_bound: at most kMatWitItems items of >= 264
+    // Variables; the fused mix with failing items: up to 80 items of 13 or 15 -- a power of two of entries, for the store waves' search)
+    constexpr uint32_t kOff = KIND == WIRES_MIX ? 128 : kMatWitItems + 1;
+    __shared__ uint32_t s_off[2][RAGGED ? 2 * kOff : 1];
     __shared__ uint64_t s_base[2][RAGGED ? 2 : 1];                         // RAGGED: rows / Variables of the call before the group
-    static_assert(!RAGGED || (MODE == MAT_SELF && KIND == WIRES_MAX_BOUND), "ragged closed form: max_bound with per-item bounds only");
+    static_assert(!RAGGED || (MODE == MAT_SELF && (KIND == WIRES_MAX_BOUND || KIND == WIRES_MIX)),
+                  "ragged closed forms: max_bound with per-item bounds, the fused mix with items that stopped at their error");
     const uint32_t tid = threadIdx.x;
     const bool loader = tid >= (uint32_t)kMatStoreThreads;
     FrVec one;
@@ -151,7 +154,8 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
                     const uint64_t rows0 = S.row_off[it], vars0 = S.var_off[it];
                     while (S.row_off[it + 1] - rows0 <= rr) it++;  // (the row lies inside the call: uend stops at its last row)
                     const uint64_t first = S.row_off[it];
-                    n = (uint32_t)(S.row_off[it + 1] - first - 5) >> 1;
+                    n = KIND == WIRES_MIX ? (S.row_off[it + 1] - first == 10 ? 0u : 1u)   // (seg_wire_offsets: the short item's table)
+                                          : (uint32_t)(S.row_off[it + 1] - first - 5) >> 1;
                     rr -= (uint32_t)(first - rows0);
                     vb = (uint32_t)(S.var_off[it] - vars0);
                 } else {
@@ -164,10 +168,9 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
                 s_tail[buf][2 * lane] = C.vars[2 * var];
                 s_tail[buf][2 * lane + 1] = C.vars[2 * var + 1];
             }
-            if constexpr (RAGGED) {  // lanes 48 ..: the group's prefix sums for the store waves (entries behind the last item: never reached)
+            if constexpr (RAGGED) {  // the group's prefix sums for the store waves (entries behind the last item: never reached)
                 const uint64_t i0 = g * group;
-                if (lane >= 48 && lane - 48 < kOff) {
-                    const uint32_t e = lane - 48;
+                for (uint32_t e = lane; e < kOff; e += 64) {
                     s_off[buf][e] = e <= G.items ? (uint32_t)(S.row_off[i0 + e] - S.row_off[i0]) : 0xffffffffu;
                     s_off[buf][kOff + e] = e <= G.items ? (uint32_t)(S.var_off[i0 + e] - S.var_off[i0]) : 0u;
                 }
@@ -211,12 +214,18 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
                     // its place in it; Variables relative to the window's first
                     // (floor(x / L) = umulhi(x, ceil(2^32 / L)), exact while x * L < 2^32: a group has a few thousand rows at most)
                     uint32_t rr = (uint32_t)(r - r0), it, vb, n = S.wire_n;
-                    if constexpr (RAGGED) {  // (at most kMatWitItems items: compare with the prefix sums the loader left)
+                    if constexpr (RAGGED) {  // compare with the prefix sums the loader left
                         it = 0;
+                        if constexpr (KIND == WIRES_MIX) {  // (up to 80 items: the last entry that is <= rr; entries past the group hold ~0)
 #pragma unroll
-                        for (uint32_t e = 1; e < kMatWitItems; e++) it += rr >= s_off[buf][e] ? 1u : 0u;
+                            for (uint32_t step = kOff / 2; step; step >>= 1)
+                                if (s_off[buf][it + step] <= rr) it += step;
+                        } else {                             // (at most kMatWitItems items)
+#pragma unroll
+                            for (uint32_t e = 1; e < kMatWitItems; e++) it += rr >= s_off[buf][e] ? 1u : 0u;
+                        }
                         const uint32_t first = s_off[buf][it];
-                        n = (s_off[buf][it + 1] - first - 5) >> 1;
+                        n = KIND == WIRES_MIX ? (s_off[buf][it + 1] - first == 10 ? 0u : 1u) : (s_off[buf][it + 1] - first - 5) >> 1;
                         vb = s_off[buf][kOff + it];
                         rr -= first;
                     } else {

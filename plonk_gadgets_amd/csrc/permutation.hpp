@@ -87,7 +87,12 @@ __device__ __forceinline__ void seg_wire_offsets(uint32_t kind, uint32_t n, uint
         //   5: (one', s, oms)   6: (sy, oms, out)   7: (a, b, u)   8: (z, u, yeq)   9: (yeq, u, u)
         constexpr uint64_t lo = 0xF50ull | 0x777ull << 12 | 0x760ull << 24 | 0x888ull << 36 | 0x921ull << 48;
         constexpr uint64_t hi = 0xA28ull | 0xBA9ull << 12 | 0xC43ull << 24 | 0xECDull << 36 | 0xCCEull << 48;
-        const uint32_t row = (uint32_t)((j < 5 ? lo : hi) >> (12 * (j < 5 ? j : j - 5))) & 0xFFFu;
+        // n != 0: the SHORT item (v = 0: is_non_zero stopped after its first row, scalar.rs:73-80) -- eight rows, thirteen Variables
+        // [v y s a b | va | one' sy oms out | u z yeq] = 0 .. 12:
+        //   0: (v, va, 0)   1: (one', one', one')   2: (y, s, sy)   3: (one', s, oms)   4: (sy, oms, out)   5: (a, b, u)   6: (z, u, yeq)   7: (yeq, u, u)
+        constexpr uint64_t slo = 0xF50ull | 0x666ull << 12 | 0x721ull << 24 | 0x826ull << 36 | 0x987ull << 48;
+        constexpr uint64_t shi = 0xA43ull | 0xCABull << 12 | 0xAACull << 24;
+        const uint32_t row = (uint32_t)((j < 5 ? (n ? slo : lo) : (n ? shi : hi)) >> (12 * (j < 5 ? j : j - 5))) & 0xFFFu;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const uint32_t o = row >> (4 * c) & 15u;
