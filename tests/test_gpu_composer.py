@@ -870,6 +870,12 @@ def test_fuzz_composer_programs(engine, seed):
         n = dev.circuit_size()
         padded = 1 << (n - 1).bit_length()
         assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded))
+        # unpadded: sigma's four columns n entries apart -- for an odd n no column but the first is 16-byte aligned (the closed-form
+        # kernels' two-gates-per-store path falls back to single entries)
+        assert np.array_equal(dev.permutation(n).cpu().numpy().view(np.uint64), ora.sigma(n))
+        m, cols = dev.materialize(), dev.device_columns()
+        for wname in ("w_l", "w_r", "w_o"):   # the wire-value columns == the assignments of the rows' Variables
+            assert torch.equal(m[wname + "_value"], cols.var_values[getattr(cols, wname)[:n]]), wname
     except AssertionError as e:
         raise AssertionError(f"seed {seed}, program {log}: {e}")
 

@@ -52,7 +52,7 @@ CSRC = os.path.join(ROOT, "plonk_gadgets_amd", "csrc")
 NOT_OPTIONS = {"PG_EXPERIMENT", "PG_HD"}  # the fence's own key; a function attribute macro
 
 
-def tested_options():
+def options_in_conditionals():
     """every PG_... macro a preprocessor conditional of csrc/ looks at"""
     found = set()
     for f in os.listdir(CSRC):
@@ -74,7 +74,7 @@ def test_the_library_is_built_without_build_options():
 def test_every_build_option_is_behind_the_experiment_fence():
     fence = open(os.path.join(CSRC, "experiment.hpp")).read()
     fenced = set(re.findall(r"defined\((PG_[A-Z0-9_]+)\)", fence)) - NOT_OPTIONS
-    opts = tested_options()
+    opts = options_in_conditionals()
     assert opts, "no options found: the scan is broken"
     assert opts <= fenced, f"options the sources test but the fence does not name: {sorted(opts - fenced)}"
     assert fenced <= opts, f"the fence names options no source tests any more: {sorted(fenced - opts)}"
