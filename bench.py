@@ -547,8 +547,9 @@ def f_rows_of(comp, dev, steps: int, note: dict):
     out = {"rows": n, "sigma_padded_to": padded}
     med, lo, hi = timed(lambda: lib.pg_composer_materialize(comp._h, C.byref(fc)))
     # algorithmic bytes: 328 B written per row; read: every assignment ONCE (32 B per Variable -- the rows of a batched call take their
-    # item's Variables from an LDS window read linearly, and the wires of the closed-form kinds are computed, not read back: csrc/materialize.hpp).
-    wr, rd = 328 * n, 32 * comp.num_variables()
+    # item's Variables from an LDS window read linearly, and the wires of the closed-form kinds are computed, not read back: csrc/materialize.hpp)
+    # -- but for the 256 bit Variables per bound block of a uniform ladder gadget, which are made from the block's T (note["bit_variables"]).
+    wr, rd = 328 * n, 32 * (comp.num_variables() - note.get("bit_variables", 0))
     out["materialize"] = {"ms": {"min": lo, "median": med, "max": hi}, "rows_per_s": n / (med / 1e3),
                           "roofline": {"bound": "hbm", "achieved": (wr + rd) / (med / 1e3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                        "frac": (wr + rd) / (med / 1e3) / 1e9 / HBM_PEAK_GBPS,
@@ -584,8 +585,10 @@ def next_rows_secondary(eng, dev, log2_batch: int, steps: int):
     comp = pg.StandardComposer(eng, 3 + batch * 1031 + 8, 5 + batch * 1034 + 8)
     comp.range_check_batch(pg.BlsScalar.from_int(0), pg.BlsScalar.from_int(2**254), to_dev(synth.random_scalars(batch, seed=synth.SEED + 2)))
     out = f_rows_of(comp, dev, steps, {
+        "bit_variables": 512 * batch,
         "materialize": "pg::materialize_items_kernel<MAT_SELF, WIRES_RANGE_CHECK> (one launch per batched call: constant columns, w_4, three "
-                       "wire-value columns from an LDS window of the items' Variables that a wave of its own fetches ahead, wires in closed form)",
+                       "wire-value columns from an LDS window of the items' Variables that a wave of its own fetches ahead, wires in closed form, "
+                       "the bits' assignments from the blocks' T)",
         "permutation": "pg::perm_ladder_kernel<false> (sigma of the ladder gadgets' rows in closed form) + perm_identity_kernel (the padding)"})
     out["config"] = {"workload": "composer of 2^%d x (allocate + range_check(0, 2^254)): %d rows, sigma padded to %d" % (log2_batch, out["rows"], out["sigma_padded_to"])}
     comp.close()

@@ -6,7 +6,8 @@
 // batched call (PermSeg: `items` items of L rows that created V Variables each, one after the other) reference almost
 // nothing but their own item's Variables -- a run of V consecutive entries of the variable table.  So a workgroup takes a
 // GROUP of consecutive items whose Variables fit its LDS window, reads that run LINEARLY (coalesced 16-byte loads, every
-// byte of the table exactly once), and serves the rows' look-ups from LDS.  Where the call's wires are known in closed form
+// byte of the table at most once -- the 256 bit Variables per bound block of the uniform ladder kinds not at all: they are made
+// from the block's T, round 6), and serves the rows' look-ups from LDS.  Where the call's wires are known in closed form
 // (PermSeg::wire_kind: the five ladder kinds, per-item bounds, the complete scalar mix) the rows' Variables are computed from
 // their place in their item and nothing else is read: one linear stream in and eleven out (MAT_SELF).  Any other batched
 // append, present or future, has its wire indices read linearly too, and a reference outside the window fetched from memory
@@ -57,6 +58,15 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
     __shared__ uint4 s_win[2][2 * kMatWindowVars];
     __shared__ uint4 s_tail[2][MODE == MAT_SELF ? kMatTailRows * 6 : 1];
     __shared__ uint4 s_wit[2][MODE == MAT_SELF ? kMatWitItems * 2 : 1];  // the items' witnesses, when they are Variables from elsewhere
+    // BITS (the uniform ladder kinds whose blocks start with T): half of an item's Variables are the 256 bits of canonical(T) per block
+    // (range.rs:128-131), i.e. a function of ONE Variable the window holds anyway.  The loader leaves them in memory -- it copies the
+    // runs between them and puts canonical(T) of every block beside the window -- and the store waves make a bit's assignment from that:
+    // the call reads half of what it did (what its reads cost against the saturated store stream is what separates it from the ceiling).
+    constexpr bool BITS = MODE == MAT_SELF && !RAGGED && (KIND == WIRES_RANGE_CHECK || KIND == WIRES_MAX_BOUND ||
+                                                            KIND == WIRES_RANGE_CHECK_ALLOCATED || KIND == WIRES_MAX_BOUND_ALLOCATED);
+    constexpr uint32_t kBlocks = (KIND == WIRES_RANGE_CHECK || KIND == WIRES_RANGE_CHECK_ALLOCATED) ? 2u : 1u;
+    constexpr uint32_t kX0 = (KIND == WIRES_RANGE_CHECK || KIND == WIRES_MAX_BOUND) ? 1u : 0u;  // the item's own witness Variable
+    __shared__ uint4 s_tc[2][BITS ? kMatWitItems * 2 * 2 : 1];  // canonical T of block b of item i of the group: [(i * kBlocks + b) * 2 + half]
     // RAGGED: rows before item k of the group, k = 0 .. items, then Variables before it (max_bound: at most kMatWitItems items of >= 264
     // Variables; the fused mix with failing items: up to 80 items of 13 or 15 -- a power of two of entries, for the store waves' search)
     constexpr uint32_t kOff = KIND == WIRES_MIX ? 128 : kMatWitItems + 1;
@@ -125,7 +135,21 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
         uint4 *win = s_win[buf];
         // PG_MAT_LOADS loads in flight per lane (named registers: as an array this staging area went through scratch memory in two of
         // the three instantiations)
-        uint32_t u = lane;
+        // (BITS: the runs between the items' bit Variables, one after the other -- run r of item i: [rb, re) in units of the window)
+        constexpr uint32_t kRuns = BITS ? kBlocks + 1 : 1;
+        const uint32_t n_runs = BITS ? G.items * kRuns : 1;
+        const uint32_t VBk = S.wire_n + 261;
+#pragma unroll 1
+        for (uint32_t run = 0; run < n_runs; run++) {
+        uint32_t rb = 0, re = units;
+        if constexpr (BITS) {
+            const uint32_t it = run / kRuns, r = run - it * kRuns, vb = it * S.V;
+            // r = 0: [x] T_0 | r = 1: A.. U z y of block 0 (and T_1) | r = 2: A.. U z y of block 1, R
+            rb = 2 * (vb + (r == 0 ? 0 : kX0 + (r - 1) * VBk + 257));
+            re = 2 * (vb + (r == kBlocks ? S.V : kX0 + r * VBk + 1));
+        }
+        uint32_t u = rb + lane;
+        const uint32_t units = re;
         for (; u + (PG_MAT_LOADS - 1) * 64 < units; u += PG_MAT_LOADS * 64) {
             const uint4 *q = src + u;
             uint4 *d = win + u;
@@ -144,6 +168,19 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
 #endif
         }
         for (; u < units; u += 64) win[u] = src[u];
+        }
+        if constexpr (BITS) {  // canonical(T) of every block of the group, from the T the window has just received (this wave's own writes)
+            if (lane < G.items * kBlocks) {
+                const uint32_t it = lane / kBlocks, b = lane - it * kBlocks;
+                const uint4 *tp = win + 2 * (it * S.V + kX0 + b * VBk);
+                FrVec t;
+                t.v[0] = tp[0];
+                t.v[1] = tp[1];
+                t.f = fr_from_mont(t.f);  // scalar_to_bits -> to_bytes, range.rs:163
+                s_tc[buf][2 * lane] = t.v[0];
+                s_tc[buf][2 * lane + 1] = t.v[1];
+            }
+        }
         if constexpr (MODE == MAT_SELF) {
             const uint32_t rows = (uint32_t)((G.uend - 2 * G.r1) >> 1);  // (2 r1 <= uend: whole rows, at most 15)
             if (lane < 3 * rows) {
@@ -247,6 +284,16 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
                                 if (off[k] == kWitnessWire) src = s_wit[buf] + 2 * (it < kMatWitItems ? it : 0) + half;
                             if (along) src = s_tail[buf] + t + 2 * k;
                             got[j][k] = *src;
+                            if constexpr (BITS) {  // a bit of canonical(T): mont(1) or mont(0), from the block's T (range.rs:128-131)
+                                uint32_t kk = off[k] - kX0, blk = 0;
+                                if (kBlocks == 2 && kk >= S.wire_n + 261 && off[k] != kWitnessWire) { kk -= S.wire_n + 261; blk = 1; }
+                                if (kk - 1 < 256u && off[k] != kWitnessWire && !along) {
+                                    const uint32_t bit = kk - 1, w = bit >> 5;
+                                    const uint4 q = s_tc[buf][2 * ((it < kMatWitItems ? it : 0) * kBlocks + blk) + (w >> 2)];
+                                    const uint32_t word = (w & 3) == 0 ? q.x : (w & 3) == 1 ? q.y : (w & 3) == 2 ? q.z : q.w;
+                                    got[j][k] = (word >> (bit & 31)) & 1u ? v1 : v0;
+                                }
+                            }
                             if constexpr (KIND == WIRES_MIX)
                                 if (off[k] == kZeroWire && !along) got[j][k] = make_uint4(0, 0, 0, 0);
                         }
