@@ -599,6 +599,7 @@ def next_rows_secondary(eng, dev, log2_batch: int, steps: int):
         comp = pg.StandardComposer(eng, 3 + 2 * batch * 515 + 8, 5 + 2 * batch * 517 + 8)
         comp.max_bound_ragged_batch(to_dev(mr), to_dev(wt))
         r = f_rows_of(comp, dev, steps, {
+            "bit_variables": 256 * 2 * batch,
             "materialize": "pg::materialize_items_kernel<MAT_SELF, WIRES_MAX_BOUND, true> (ladder lengths from the call's prefix sums, through the loader wave)",
             "permutation": "pg::perm_ladder_kernel<true> (an item's ladder length and place from a window of the call's prefix sums) + perm_identity_kernel"})
         r["config"] = {"workload": "composer of 2^%d x (allocate + max_bound(a 253-bit bound per item)): %d rows, sigma padded to %d" % (log2_batch + 1, r["rows"], r["sigma_padded_to"])}

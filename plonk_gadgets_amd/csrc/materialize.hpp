@@ -62,8 +62,8 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
     // (range.rs:128-131), i.e. a function of ONE Variable the window holds anyway.  The loader leaves them in memory -- it copies the
     // runs between them and puts canonical(T) of every block beside the window -- and the store waves make a bit's assignment from that:
     // the call reads half of what it did (what its reads cost against the saturated store stream is what separates it from the ceiling).
-    constexpr bool BITS = MODE == MAT_SELF && !RAGGED && (KIND == WIRES_RANGE_CHECK || KIND == WIRES_MAX_BOUND ||
-                                                            KIND == WIRES_RANGE_CHECK_ALLOCATED || KIND == WIRES_MAX_BOUND_ALLOCATED);
+    constexpr bool BITS = MODE == MAT_SELF && (KIND == WIRES_MAX_BOUND || (!RAGGED && (KIND == WIRES_RANGE_CHECK ||
+                                                KIND == WIRES_RANGE_CHECK_ALLOCATED || KIND == WIRES_MAX_BOUND_ALLOCATED)));
     constexpr uint32_t kBlocks = (KIND == WIRES_RANGE_CHECK || KIND == WIRES_RANGE_CHECK_ALLOCATED) ? 2u : 1u;
     constexpr uint32_t kX0 = (KIND == WIRES_RANGE_CHECK || KIND == WIRES_MAX_BOUND) ? 1u : 0u;  // the item's own witness Variable
     __shared__ uint4 s_tc[2][BITS ? kMatWitItems * 2 * 2 : 1];  // canonical T of block b of item i of the group: [(i * kBlocks + b) * 2 + half]
@@ -143,10 +143,16 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
         for (uint32_t run = 0; run < n_runs; run++) {
         uint32_t rb = 0, re = units;
         if constexpr (BITS) {
-            const uint32_t it = run / kRuns, r = run - it * kRuns, vb = it * S.V;
+            const uint32_t it = run / kRuns, r = run - it * kRuns;
+            uint32_t vb = it * S.V, Vi = S.V;
+            if constexpr (RAGGED) {  // (max_bound with a bound per item: the item's Variables from the call's prefix sums)
+                const uint64_t i0 = g * group;
+                vb = (uint32_t)(S.var_off[i0 + it] - S.var_off[i0]);
+                Vi = (uint32_t)(S.var_off[i0 + it + 1] - S.var_off[i0 + it]);
+            }
             // r = 0: [x] T_0 | r = 1: A.. U z y of block 0 (and T_1) | r = 2: A.. U z y of block 1, R
             rb = 2 * (vb + (r == 0 ? 0 : kX0 + (r - 1) * VBk + 257));
-            re = 2 * (vb + (r == kBlocks ? S.V : kX0 + r * VBk + 1));
+            re = 2 * (vb + (r == kBlocks ? Vi : kX0 + r * VBk + 1));
         }
         uint32_t u = rb + lane;
         const uint32_t units = re;
@@ -172,7 +178,9 @@ __global__ __launch_bounds__(kMatThreads) void materialize_items_kernel(const Co
         if constexpr (BITS) {  // canonical(T) of every block of the group, from the T the window has just received (this wave's own writes)
             if (lane < G.items * kBlocks) {
                 const uint32_t it = lane / kBlocks, b = lane - it * kBlocks;
-                const uint4 *tp = win + 2 * (it * S.V + kX0 + b * VBk);
+                uint32_t vb = it * S.V;
+                if constexpr (RAGGED) vb = (uint32_t)(S.var_off[g * group + it] - S.var_off[g * group]);
+                const uint4 *tp = win + 2 * (vb + kX0 + b * VBk);
                 FrVec t;
                 t.v[0] = tp[0];
                 t.v[1] = tp[1];
