@@ -873,6 +873,11 @@ def test_fuzz_composer_programs(engine, seed):
         # unpadded: sigma's four columns n entries apart -- for an odd n no column but the first is 16-byte aligned (the closed-form
         # kernels' two-gates-per-store path falls back to single entries)
         assert np.array_equal(dev.permutation(n).cpu().numpy().view(np.uint64), ora.sigma(n))
+        # the sorted list of foreign positions reserved far too short (fewer entries than the closed-form segments' own slots): the pass
+        # reports its size and runs a second time -- holes, slots and all
+        dev.permutation_reserve(16)
+        assert np.array_equal(dev.permutation(padded).cpu().numpy().view(np.uint64), ora.sigma(padded))
+        dev.permutation_reserve(0)
         m, cols = dev.materialize(), dev.device_columns()
         for wname in ("w_l", "w_r", "w_o"):   # the wire-value columns == the assignments of the rows' Variables
             assert torch.equal(m[wname + "_value"], cols.var_values[getattr(cols, wname)[:n]]), wname
