@@ -14,6 +14,33 @@ from plonk_gadgets_amd import synth
 WIRES = ("w_l", "w_r", "w_o")
 
 
+def host_memory_available() -> int:
+    """bytes of host memory this process may still take: /proc/meminfo's MemAvailable, and what is left of the cgroup's limit
+    where there is one (a box that runs out kills the process -- and the box -- without a word)"""
+    avail = 1 << 62
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) << 10
+    except OSError:
+        pass
+    for limit, used in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                        ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            lim = open(limit).read().strip()
+            if lim != "max":
+                avail = min(avail, int(lim) - int(open(used).read()))
+        except (OSError, ValueError):
+            pass
+    return avail
+
+
+def host_bytes(cap_rows: int, cap_vars: int) -> int:
+    """what a HostCircuit of this size and the oracle's sigma plan over it hold on the host: four wire columns, the assignments,
+    first / last position and the carry of every Variable, staging buffers -- an upper estimate (16 GB of slack)"""
+    return cap_rows * 32 + cap_vars * (32 + 40) + (16 << 30)
+
+
 class HostCircuit:
     def __init__(self, cap_rows: int, cap_vars: int, threads: int = 1, dummy: bool = True):
         self.threads = threads

@@ -49,6 +49,14 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(DEV)
 
 
+def require_host_memory(rows, variables):
+    """skip (and say so) rather than let the host's out-of-memory killer take the box"""
+    from tests.frows_oracle import host_bytes, host_memory_available
+    need, have = host_bytes(rows, variables), host_memory_available()
+    if have < need:
+        pytest.skip("the oracle's side of a %d-row circuit needs %.0f GB of host memory, %.0f are available" % (rows, need / 1e9, have / 1e9))
+
+
 def release_hbm():
     import gc
     gc.collect()
@@ -271,6 +279,7 @@ def test_bench_next_rows_composer_every_word(engine, stager):
     free, _ = torch.cuda.mem_get_info()
     if free < (200 << 30):
         pytest.skip("not enough free HBM for the 270 M-row composer and its f-rows")
+    require_host_memory(3 + batch * 1031, 5 + batch * 1034)
     comp = pg.StandardComposer(engine, 3 + batch * 1031 + 8, 5 + batch * 1034 + 8)
     wit = synth.random_scalars(batch, seed=synth.SEED + 2)          # (bench.py's witnesses for this composer)
     res = comp.range_check_batch(S(0), S(2**254), dev(wit))
@@ -407,6 +416,7 @@ def test_sigma_padded_to_2_pow_30(engine, stager):
     free, _ = torch.cuda.mem_get_info()
     if free < (190 << 30):
         pytest.skip("not enough free HBM for a 545 M-row composer and a 34-GB sigma")
+    require_host_memory(3 + batch * 1031, 5 + batch * 1034)
     comp = pg.StandardComposer(engine, 3 + batch * 1031 + 8, 5 + batch * 1034 + 8)
     wit = synth.random_scalars(batch, seed=synth.SEED + 30)
     res = comp.range_check_batch(S(0), S(2**254), dev(wit))
